@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/gi2d.h (libgi2d_hip.so, built by csrc/Makefile).
+
+There is deliberately no CPU fallback: if the HIP library is missing, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# torch bundles its own libamdhip64.so (soname libamdhip64.so.7).  It must be in the process BEFORE
+# libgi2d_hip.so is dlopen'ed so that our NEEDED libamdhip64.so.7 binds to that same runtime; loading
+# /opt/rocm's copy first would leave two HIP runtimes in one process (hipErrorNoDevice on the second).
+import torch  # noqa: F401  (device memory + streams; see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgi2d_hip.so")
+
+_i, _u, _f, _p, _sz = C.c_int, C.c_uint, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> argtypes; mirrors include/gi2d.h one to one (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "gi2d_project_gaussians_2d_forward": [_i, _f, _p, _p, _u, _u, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p],
+    "gi2d_project_gaussians_2d_covariance_forward": [_i, _f, _p, _p, _u, _u, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p],
+    "gi2d_project_gaussians_2d_scale_rot_forward": [_i, _f, _p, _p, _p, _u, _u, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p],
+    "gi2d_project_gaussians_2d_backward": [_i, _p, _p, _u, _u, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gi2d_project_gaussians_2d_covariance_backward": [_i, _p, _p, _u, _u, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gi2d_project_gaussians_2d_scale_rot_backward": [_i, _p, _p, _p, _u, _u, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gi2d_compute_cov2d_bounds": [_i, _f, _p, _p, _p, _p],
+    "gi2d_cumsum_tiles_hit": [_i, _p, _p, _p, _p],
+    "gi2d_map_gaussian_to_intersects": [_i, _i, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p],
+    "gi2d_sort_intersects": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gi2d_get_tile_bin_edges": [_i, _p, _i, _p, _p],
+    "gi2d_rasterize_sum_forward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gi2d_rasterize_sum_plus_forward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gi2d_rasterize_sum_backward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gi2d_rasterize_sum_plus_backward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+}
+SIZE_FUNCS = {
+    "gi2d_sort_workspace_bytes": [_i, _i],
+    "gi2d_rasterize_backward_workspace_bytes": [_i, _i],
+}
+STRING_FUNCS = ["gi2d_version", "gi2d_last_error_string"]
+
+_lib = None
+
+
+class Gi2dError(RuntimeError):
+    """A C-ABI call returned a non-zero status (mirrors the RuntimeError TORCH_CHECK raises)."""
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the gfx950 library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+            "gaussianimage_plus_amd/csrc`). There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, args in SIZE_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_size_t
+    for name in STRING_FUNCS:
+        getattr(lib, name).restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.gi2d_last_error_string().decode(errors="replace")
+        raise Gi2dError(f"{name} failed (status {rc}): {msg}")
+
+
+def version() -> str:
+    return load().gi2d_version().decode()

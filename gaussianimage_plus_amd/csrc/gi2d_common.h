@@ -1,0 +1,122 @@
+// Shared device helpers for the gfx950 2D-Gaussian path.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gi2d.h"
+
+#define GI2D_WAVE 64
+#define GI2D_BLOCK 256 /* threads per workgroup = one 16x16 tile = 4 waves */
+
+namespace gi2d {
+
+void set_error(const char *msg);
+int check_launch(const char *what);
+
+// float -> int with the semantics of CUDA's cvt.rzi.s32.f32 (truncate, saturate, NaN -> 0),
+// which get_bbox (helpers.cuh:26-29) relies on for huge / non-finite centres.
+__device__ __forceinline__ int cvt_rzi(float x) {
+    if (x != x) return 0;
+    x = fminf(fmaxf(x, -2147483648.f), 2147483520.f);
+    return (int)x;
+}
+
+// helpers.cuh:16-50 get_bbox/get_tile_bbox: inclusive min, exclusive max, clamped to the grid.
+__device__ __forceinline__ void tile_bbox(float cx, float cy, float pix_radius, int tiles_x,
+                                          int tiles_y, int &min_x, int &min_y, int &max_x,
+                                          int &max_y) {
+    const float tcx = cx / (float)GI2D_TILE, tcy = cy / (float)GI2D_TILE;
+    const float tr = pix_radius / (float)GI2D_TILE;
+    min_x = min(max(0, cvt_rzi(tcx - tr)), tiles_x);
+    max_x = min(max(0, cvt_rzi(tcx + tr + 1)), tiles_x);
+    min_y = min(max(0, cvt_rzi(tcy - tr)), tiles_y);
+    max_y = min(max(0, cvt_rzi(tcy + tr + 1)), tiles_y);
+}
+
+// helpers.cuh:179-206 compute_cov2d_bounds.
+__device__ __forceinline__ bool cov2d_bounds(float cxx, float cxy, float cyy, float clip_coe,
+                                             float &k0, float &k1, float &k2, float &rad_major,
+                                             float &rad_minor) {
+    const float det = cxx * cyy - cxy * cxy;
+    if (det == 0.f) return false;
+    const float inv_det = 1.f / det;
+    k0 = cyy * inv_det;
+    k1 = -cxy * inv_det;
+    k2 = cxx * inv_det;
+    const float b = 0.5f * (cxx + cyy);
+    const float s = sqrtf(fmaxf(0.1f, b * b - det));
+    const float v1 = b + s, v2 = b - s;
+    rad_major = ceilf(clip_coe * sqrtf(fmaxf(v1, v2)));
+    rad_minor = ceilf(clip_coe * sqrtf(fminf(v1, v2)));
+    return true;
+}
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    const unsigned lane = threadIdx.x & 63u;
+    return lane == 0 ? 0ull : (~0ull >> (64u - lane));
+}
+
+// Inclusive scan of one int per lane across the 64-lane wave.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// ---- pair evaluation shared (bitwise) by the forward and backward rasterizers -------------
+// The conic is pre-scaled by log2(e) so the exponential is a bare v_exp_f32:
+//   sigma' = log2e * (0.5*(a dx^2 + c dy^2) + b dx dy) = dx*(ha*dx + hb*dy) + hc*dy*dy.
+// sigma' < 0  <=>  sigma < 0 (forward.cu:539).  Both kernels call these two functions with
+// the same operands so a pair that contributed in the forward pass contributes in the backward.
+struct ConicS {
+    float ha, hb, hc;  // 0.5*a*log2e, b*log2e, 0.5*c*log2e
+};
+__device__ __forceinline__ ConicS scale_conic(float a, float b, float c) {
+    const float l2e = 1.4426950408889634f;
+    ConicS s;
+    s.ha = 0.5f * a * l2e;
+    s.hb = b * l2e;
+    s.hc = 0.5f * c * l2e;
+    return s;
+}
+__device__ __forceinline__ float row_term_b(const ConicS &s, float dy) { return s.hb * dy; }
+__device__ __forceinline__ float row_term_c(const ConicS &s, float dy) { return s.hc * dy * dy; }
+__device__ __forceinline__ float pair_sigma(const ConicS &s, float dx, float bdy, float cdy2) {
+    return __builtin_fmaf(dx, __builtin_fmaf(s.ha, dx, bdy), cdy2);
+}
+__device__ __forceinline__ float pair_vis(float sigma_l2) { return __builtin_amdgcn_exp2f(-sigma_l2); }
+
+// Conservative pixel-space bounding box of {sigma <= ln(255*opac)} (the only place where a
+// pair can pass `alpha >= 1/255`, forward.cu:541), widened by a safety margin.  Returns false
+// when the gaussian can never contribute; full=true when no finite box exists (non positive
+// definite conic or non-finite inputs) and every pixel must be evaluated.
+struct CullBox {
+    float x0, x1, y0, y1;  // inclusive pixel-coordinate range
+};
+__device__ __forceinline__ bool cull_box(float gx, float gy, float a, float b, float c, float opac,
+                                         CullBox &box) {
+    const float big = 3.0e38f;
+    box.x0 = -big;
+    box.x1 = big;
+    box.y0 = -big;
+    box.y1 = big;
+    if (!(opac == opac)) return true;      // NaN opacity: min(1, NaN) = 1 in the reference
+    if (!(opac * 255.f >= 1.f)) return false;  // alpha <= opac < 1/255 whenever sigma >= 0
+    const float det = a * c - b * b;
+    if (!(a > 0.f) || !(c > 0.f) || !(det > 0.f)) return true;  // not PD / NaN: no box
+    const float tau2 = 2.f * __logf(opac * 255.f) * 1.0002f + 1e-3f;
+    const float hx = sqrtf(tau2 * c / det) * 1.0002f + 0.75f;
+    const float hy = sqrtf(tau2 * a / det) * 1.0002f + 0.75f;
+    if (!(hx < big) || !(hy < big) || !(gx == gx) || !(gy == gy)) return true;
+    box.x0 = gx - hx;
+    box.x1 = gx + hx;
+    box.y0 = gy - hy;
+    box.y1 = gy + hy;
+    return true;
+}
+
+}  // namespace gi2d

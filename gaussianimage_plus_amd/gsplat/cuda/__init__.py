@@ -1,0 +1,322 @@
+"""Native op table: what `import gsplat.cuda as _C` resolves to.
+
+Same names, argument order and return arity as the reference's pybind table
+(/root/reference/gsplat/gsplat/cuda/csrc/ext.cpp:16-66, signatures bindings.h), but every op
+is a thin torch<->pointer shim over the gfx950 C ABI (include/gi2d.h): torch only provides the
+HBM allocations and the current HIP stream.  Inputs must be device tensors and contiguous
+(`CHECK_INPUT`, bindings.h:9-14 -> RuntimeError).  Nothing here computes on the CPU.
+
+Where the reference's Python wrappers and its C++ bindings disagree the op
+follows the WRAPPER's intent: rasterize_sum_forward returns 4 tensors (with the never-filled
+cnt_gs_counts, bindings.cu:506-508) and rasterize_sum_backward returns 5 (with v_abs_xys).
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import _lib
+
+_TILE = 16
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(*shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _i32(*shape, like):
+    return torch.empty(shape, dtype=torch.int32, device=like.device)
+
+
+def _workspace(nbytes: int, like) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+
+
+# ------------------------------------------------------------------------------- projection
+def _project_fwd(cname, num_points, clip_coe, means2d, params, img_height, img_width, tile_bounds,
+                 clip_thresh, radius_clip):
+    _chk(means2d, "means2d", torch.float32)
+    n = int(num_points)
+    xys, depths, radii = _f32(n, 2, like=means2d), _f32(n, like=means2d), _i32(n, like=means2d)
+    conics, nth = _f32(n, 3, like=means2d), _i32(n, like=means2d)
+    with torch.cuda.device(means2d.device):
+        _lib.call(cname, n, float(clip_coe), means2d.data_ptr(), *[p.data_ptr() for p in params],
+                  int(img_height), int(img_width), int(tile_bounds[0]), int(tile_bounds[1]),
+                  float(clip_thresh), float(radius_clip), xys.data_ptr(), depths.data_ptr(),
+                  radii.data_ptr(), conics.data_ptr(), nth.data_ptr(), _stream(means2d))
+    return xys, depths, radii, conics, nth
+
+
+def project_gaussians_2d_forward(num_points, clip_coe, means2d, L_elements, img_height, img_width,
+                                 tile_bounds, clip_thresh, radius_clip, isprint=False):
+    """bindings.cu:1317-1381 -> (xys, depths, radii, conics, num_tiles_hit)"""
+    _chk(L_elements, "L_elements", torch.float32)
+    return _project_fwd("gi2d_project_gaussians_2d_forward", num_points, clip_coe, means2d, [L_elements],
+                        img_height, img_width, tile_bounds, clip_thresh, radius_clip)
+
+
+def project_gaussians_2d_covariance_forward(num_points, clip_coe, means2d, L_elements, img_height,
+                                            img_width, tile_bounds, clip_thresh, radius_clip,
+                                            isprint=False):
+    """bindings.cu:1449-1513"""
+    _chk(L_elements, "L_elements", torch.float32)
+    return _project_fwd("gi2d_project_gaussians_2d_covariance_forward", num_points, clip_coe, means2d,
+                        [L_elements], img_height, img_width, tile_bounds, clip_thresh, radius_clip)
+
+
+def project_gaussians_2d_scale_rot_forward(num_points, clip_coe, means2d, scales2d, rotation, img_height,
+                                           img_width, tile_bounds, clip_thresh, radius_clip,
+                                           isprint=False):
+    """bindings.cu:1384-1448"""
+    _chk(scales2d, "scales2d", torch.float32)
+    _chk(rotation, "rotation", torch.float32)
+    return _project_fwd("gi2d_project_gaussians_2d_scale_rot_forward", num_points, clip_coe, means2d,
+                        [scales2d, rotation], img_height, img_width, tile_bounds, clip_thresh, radius_clip)
+
+
+def _project_bwd(cname, num_points, means2d, params, img_height, img_width, radii, conics, v_xy, v_depth,
+                 v_conic, out_shapes):
+    for t, nm in ((means2d, "means2d"), (conics, "conics"), (v_xy, "v_xy"), (v_conic, "v_conic")):
+        _chk(t, nm, torch.float32)
+    _chk(radii, "radii", torch.int32)
+    n = int(num_points)
+    v_cov2d, v_mean2d = _f32(n, 3, like=means2d), _f32(n, 2, like=means2d)
+    outs = [_f32(*s, like=means2d) for s in out_shapes]
+    with torch.cuda.device(means2d.device):
+        _lib.call(cname, n, means2d.data_ptr(), *[p.data_ptr() for p in params], int(img_height),
+                  int(img_width), radii.data_ptr(), conics.data_ptr(), v_xy.data_ptr(), _ptr(v_depth),
+                  v_conic.data_ptr(), v_cov2d.data_ptr(), v_mean2d.data_ptr(),
+                  *[o.data_ptr() for o in outs], _stream(means2d))
+    return (v_cov2d, v_mean2d, *outs)
+
+
+def project_gaussians_2d_backward(num_points, means2d, L_elements, img_height, img_width, radii, conics,
+                                  v_xy, v_depth, v_conic):
+    """bindings.cu:1517-1564 -> (v_cov2d, v_mean2d, v_L_elements)"""
+    _chk(L_elements, "L_elements", torch.float32)
+    return _project_bwd("gi2d_project_gaussians_2d_backward", num_points, means2d, [L_elements], img_height,
+                        img_width, radii, conics, v_xy, v_depth, v_conic, [(int(num_points), 3)])
+
+
+def project_gaussians_2d_covariance_backward(num_points, means2d, L_elements, img_height, img_width, radii,
+                                             conics, v_xy, v_depth, v_conic):
+    """bindings.cu:1565-1612"""
+    _chk(L_elements, "L_elements", torch.float32)
+    return _project_bwd("gi2d_project_gaussians_2d_covariance_backward", num_points, means2d, [L_elements],
+                        img_height, img_width, radii, conics, v_xy, v_depth, v_conic, [(int(num_points), 3)])
+
+
+def project_gaussians_2d_scale_rot_backward(num_points, means2d, scales2d, rotation, img_height, img_width,
+                                            radii, conics, v_xy, v_depth, v_conic):
+    """bindings.cu:1614-1668 -> (v_cov2d, v_mean2d, v_scale[N,2], v_rot[N,1])"""
+    _chk(scales2d, "scales2d", torch.float32)
+    _chk(rotation, "rotation", torch.float32)
+    n = int(num_points)
+    return _project_bwd("gi2d_project_gaussians_2d_scale_rot_backward", num_points, means2d,
+                        [scales2d, rotation], img_height, img_width, radii, conics, v_xy, v_depth, v_conic,
+                        [(n, 2), (n, 1)])
+
+
+def compute_cov2d_bounds(num_pts, clip_coe, covs2d):
+    """bindings.cu:44-63 -> (conics[N,3], radii[N,1])"""
+    _chk(covs2d, "covs2d", torch.float32)
+    n = int(num_pts)
+    conics, radii = _f32(n, 3, like=covs2d), _f32(n, 1, like=covs2d)
+    with torch.cuda.device(covs2d.device):
+        _lib.call("gi2d_compute_cov2d_bounds", n, float(clip_coe), covs2d.data_ptr(), conics.data_ptr(),
+                  radii.data_ptr(), _stream(covs2d))
+    return conics, radii
+
+
+compute_cov2d_bounds_xy = compute_cov2d_bounds  # ext.cpp:55 binds both names to the same function
+
+
+# ------------------------------------------------------------------------------- binning
+def cumsum_tiles_hit(num_tiles_hit):
+    """Device-side replacement of torch.cumsum (utils.py:248) -> (cum i32[N], total i32[1] on device)."""
+    _chk(num_tiles_hit, "num_tiles_hit", torch.int32)
+    n = num_tiles_hit.numel()
+    cum, total = _i32(n, like=num_tiles_hit), _i32(1, like=num_tiles_hit)
+    with torch.cuda.device(num_tiles_hit.device):
+        _lib.call("gi2d_cumsum_tiles_hit", n, num_tiles_hit.data_ptr(), cum.data_ptr(), total.data_ptr(),
+                  _stream(num_tiles_hit))
+    return cum, total
+
+
+def map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds,
+                               radius_clip=1.0, isprint=False):
+    """bindings.cu:283-365 -> (isect_ids i64[M], gaussian_ids i32[M])"""
+    _chk(xys, "xys", torch.float32)
+    _chk(depths, "depths", torch.float32)
+    _chk(radii, "radii", torch.int32)
+    _chk(cum_tiles_hit, "cum_tiles_hit", torch.int32)
+    m = int(num_intersects)
+    isect = torch.empty(m, dtype=torch.int64, device=xys.device)
+    gids = _i32(m, like=xys)
+    with torch.cuda.device(xys.device):
+        _lib.call("gi2d_map_gaussian_to_intersects", int(num_points), m, xys.data_ptr(), depths.data_ptr(),
+                  radii.data_ptr(), cum_tiles_hit.data_ptr(), int(tile_bounds[0]), int(tile_bounds[1]),
+                  float(radius_clip), isect.data_ptr(), gids.data_ptr(), _stream(xys))
+    return isect, gids
+
+
+def sort_intersects(isect_ids, gaussian_ids, num_tiles, want_perm=False, want_inv_perm=False,
+                    want_bins=False, want_keys=True):
+    """Stable sort of (key, gaussian id) pairs by key: the native stand-in for torch.sort + torch.gather
+    (utils.py:301-302).  -> dict(isect_ids_sorted, gaussian_ids_sorted, perm, inv_perm, tile_bins)"""
+    _chk(isect_ids, "isect_ids", torch.int64)
+    _chk(gaussian_ids, "gaussian_ids", torch.int32)
+    m, t = isect_ids.numel(), int(num_tiles)
+    dev = isect_ids
+    keys = torch.empty(m, dtype=torch.int64, device=dev.device) if want_keys else None
+    gids = _i32(m, like=dev)
+    perm = _i32(m, like=dev) if want_perm else None
+    inv = _i32(m, like=dev) if want_inv_perm else None
+    bins = _i32(t, 2, like=dev) if want_bins else None
+    nbytes = _lib.load().gi2d_sort_workspace_bytes(m, t)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev.device):
+        _lib.call("gi2d_sort_intersects", m, t, isect_ids.data_ptr(), gaussian_ids.data_ptr(), _ptr(keys),
+                  gids.data_ptr(), _ptr(perm), _ptr(inv), _ptr(bins), ws.data_ptr(), ws.numel(), _stream(dev))
+    return dict(isect_ids_sorted=keys, gaussian_ids_sorted=gids, perm=perm, inv_perm=inv, tile_bins=bins,
+                status=ws[:16].view(torch.int32))
+
+
+def get_tile_bin_edges(num_intersects, isect_ids_sorted, rows=None):
+    """bindings.cu:368-383 -> tile_bins i32[rows,2] (rows = num_intersects as in the reference)."""
+    _chk(isect_ids_sorted, "isect_ids_sorted", torch.int64)
+    m = int(num_intersects)
+    rows = m if rows is None else int(rows)
+    bins = _i32(rows, 2, like=isect_ids_sorted)
+    with torch.cuda.device(isect_ids_sorted.device):
+        _lib.call("gi2d_get_tile_bin_edges", m, isect_ids_sorted.data_ptr(), rows, bins.data_ptr(),
+                  _stream(isect_ids_sorted))
+    return bins
+
+
+# ------------------------------------------------------------------------------- rasterizer
+def _check_block(block):
+    if int(block[0]) != _TILE or int(block[1]) != _TILE:
+        raise RuntimeError(f"only {_TILE}x{_TILE} tiles are supported (csrc/config.h BLOCK_X/BLOCK_Y), got {block}")
+
+
+def _raster_fwd(cname, tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                opacities, background, num_intersects_dev=None):
+    for t, nm in ((gaussian_ids_sorted, "gaussian_ids_sorted"), (tile_bins, "tile_bins")):
+        _chk(t, nm, torch.int32)
+    for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (opacities, "opacities"),
+                  (background, "background")):
+        _chk(t, nm, torch.float32)
+    _check_block(block)
+    if colors.dim() != 2 or colors.size(1) != 3:
+        raise RuntimeError("colors must have dimensions (num_points, 3)")
+    w, h = int(img_size[0]), int(img_size[1])
+    out_img, final_Ts, final_idx = _f32(h, w, 3, like=xys), _f32(h, w, like=xys), _i32(h, w, like=xys)
+    with torch.cuda.device(xys.device):
+        _lib.call(cname, int(tile_bounds[0]), int(tile_bounds[1]), w, h, gaussian_ids_sorted.data_ptr(),
+                  tile_bins.data_ptr(), tile_bins.size(0), xys.data_ptr(), conics.data_ptr(),
+                  colors.data_ptr(), opacities.data_ptr(), background.data_ptr(), _ptr(num_intersects_dev),
+                  final_Ts.data_ptr(), final_idx.data_ptr(), out_img.data_ptr(), _stream(xys))
+    return out_img, final_Ts, final_idx
+
+
+def rasterize_sum_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                          opacities, background, isprint=False, num_intersects_dev=None):
+    """bindings.cu:453-526 (+ the 4th result rasterize_sum.py:157 unpacks)
+    -> (out_img, final_Ts, final_idx, cnt_gs_counts)"""
+    out_img, final_Ts, final_idx = _raster_fwd("gi2d_rasterize_sum_forward", tile_bounds, block, img_size,
+                                               gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                                               background, num_intersects_dev)
+    cnt_gs_counts = torch.zeros_like(final_idx)  # allocated, never filled (bindings.cu:506-508)
+    return out_img, final_Ts, final_idx, cnt_gs_counts
+
+
+def rasterize_sum_plus_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
+                               colors, opacities, background, isprint=False, num_intersects_dev=None):
+    """bindings.cu:529-610 -> (out_img, final_Ts, final_idx)"""
+    return _raster_fwd("gi2d_rasterize_sum_plus_forward", tile_bounds, block, img_size, gaussian_ids_sorted,
+                       tile_bins, xys, conics, colors, opacities, background, num_intersects_dev)
+
+
+def _raster_bwd(cname, with_abs, img_height, img_width, BLOCK_H, BLOCK_W, gaussian_ids_sorted, tile_bins, xys,
+                conics, colors, opacities, final_idx, v_output, cum_tiles_hit, inv_perm):
+    _chk(xys, "xys", torch.float32)
+    _chk(colors, "colors", torch.float32)
+    if xys.dim() != 2 or xys.size(1) != 2:
+        raise RuntimeError("xys must have dimensions (num_points, 2)")  # bindings.cu:1193-1195
+    if colors.dim() != 2 or colors.size(1) != 3:
+        raise RuntimeError("colors must have 2 dimensions")  # bindings.cu:1197-1199
+    _check_block((BLOCK_W, BLOCK_H))
+    for t, nm in ((gaussian_ids_sorted, "gaussian_ids_sorted"), (tile_bins, "tile_bins"),
+                  (final_idx, "final_idx")):
+        _chk(t, nm, torch.int32)
+    for t, nm in ((conics, "conics"), (opacities, "opacities"), (v_output, "v_output")):
+        _chk(t, nm, torch.float32)
+    n, m = xys.size(0), gaussian_ids_sorted.numel()
+    v_xy, v_conic = _f32(n, 2, like=xys), _f32(n, 3, like=xys)
+    v_colors, v_opacity = _f32(n, 3, like=xys), _f32(n, 1, like=xys)
+    v_abs = _f32(n, 4, like=xys) if with_abs else None
+    ws = _workspace(_lib.load().gi2d_rasterize_backward_workspace_bytes(n, m), xys)
+    args = [n, m, int(img_height), int(img_width), gaussian_ids_sorted.data_ptr(), tile_bins.data_ptr(),
+            tile_bins.size(0), xys.data_ptr(), conics.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+            final_idx.data_ptr(), v_output.data_ptr(), _ptr(cum_tiles_hit), _ptr(inv_perm), v_xy.data_ptr(),
+            v_conic.data_ptr(), v_colors.data_ptr(), v_opacity.data_ptr()]
+    if with_abs:
+        args.append(v_abs.data_ptr())
+    with torch.cuda.device(xys.device):
+        _lib.call(cname, *args, ws.data_ptr(), ws.numel(), _stream(xys))
+    return v_xy, v_conic, v_colors, v_opacity, v_abs
+
+
+def rasterize_sum_backward(img_height, img_width, BLOCK_H, BLOCK_W, gaussian_ids_sorted, tile_bins, xys,
+                           conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                           v_output_alpha=None, cum_tiles_hit=None, inv_perm=None):
+    """bindings.cu:1166-1240 (+ v_abs_xys, rasterize_sum.py:308)
+    -> (v_xy, v_conic, v_colors, v_opacity[N,1], v_abs_xys[N,4])"""
+    return _raster_bwd("gi2d_rasterize_sum_backward", True, img_height, img_width, BLOCK_H, BLOCK_W,
+                       gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, final_idx, v_output,
+                       cum_tiles_hit, inv_perm)
+
+
+def rasterize_sum_plus_backward(img_height, img_width, BLOCK_H, BLOCK_W, gaussian_ids_sorted, tile_bins, xys,
+                                conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                                v_output_alpha=None, cum_tiles_hit=None, inv_perm=None):
+    """bindings.cu:1241-1314 -> (v_xy, v_conic, v_colors, v_opacity[N,1])"""
+    return _raster_bwd("gi2d_rasterize_sum_plus_backward", False, img_height, img_width, BLOCK_H, BLOCK_W,
+                       gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, final_idx, v_output,
+                       cum_tiles_hit, inv_perm)[:4]
+
+
+# ------------------------------------------------------------------------------- out of scope
+def _unsupported(name):
+    def f(*a, **k):
+        raise NotImplementedError(f"gsplat.cuda.{name}: the 3D / N-channel paths are outside this build "
+                                  "(SURVEY.md section 2, items 16-17)")
+    f.__name__ = name
+    return f
+
+
+for _n in ("nd_rasterize_forward", "nd_rasterize_backward", "nd_rasterize_sum_forward",
+           "nd_rasterize_sum_backward", "nd_rasterize_gs_sum_forward", "nd_rasterize_gs_sum_backward",
+           "rasterize_forward", "rasterize_backward", "project_gaussians_forward",
+           "project_gaussians_backward", "compute_sh_forward", "compute_sh_backward"):
+    globals()[_n] = _unsupported(_n)

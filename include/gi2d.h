@@ -1,0 +1,193 @@
+/*
+ * gi2d.h -- C ABI of the MI355X (gfx950) 2D-Gaussian rasterizer that replaces the CUDA
+ * extension behind GaussianImage++'s `gsplat` operator surface.
+ *
+ * Boundary being replaced: the 12 hot-path entries of the reference's pybind table
+ *   gsplat/gsplat/cuda/csrc/ext.cpp:16-66 (C++ signatures in csrc/bindings.h).
+ * Each function below cites the binding it stands in for.  Conventions:
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`;
+ *   - inputs are borrowed, outputs are caller-allocated and are fully written by the call
+ *     (no pre-zeroing needed: the reference's torch::zeros + kernel pair is fused);
+ *   - layouts are the reference's: fp32 row-major [N,2]/[N,3]/[H,W,3], int32 ids, int64 keys;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls only enqueue work, they never
+ *     synchronise, allocate or free -- safe for hipGraph capture;
+ *   - return value: 0 (GI2D_OK) or a negative GI2D_ERR_* / positive hipError_t code.
+ *     gi2d_last_error_string() describes the last failure of the calling thread.
+ * Tiles are 16x16 pixels (csrc/config.h:1-4); tiles_x = ceil(W/16), tiles_y = ceil(H/16).
+ */
+#ifndef GI2D_H
+#define GI2D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GI2D_OK 0
+#define GI2D_ERR_INVALID_ARGUMENT (-1)
+#define GI2D_ERR_WORKSPACE_TOO_SMALL (-2)
+#define GI2D_ERR_UNSUPPORTED (-3)
+
+#define GI2D_TILE 16
+#define GI2D_TILE_LIST_CAP 256 /* forward.cu:553: only the first 256 entries of a tile are consumed */
+
+typedef void *gi2d_stream_t;
+
+const char *gi2d_version(void);
+const char *gi2d_last_error_string(void);
+
+/* ------------------------------------------------------------------ projection (a1-a4)
+ * bindings.cu:1317-1381  project_gaussians_2d_forward_tensor      (Cholesky, means in NDC)
+ * bindings.cu:1449-1513  project_gaussians_2d_covariance_forward_tensor (means in pixels)
+ * bindings.cu:1384-1448  project_gaussians_2d_scale_rot_forward_tensor  (means in pixels)
+ * Outputs: xys f32[N,2], depths f32[N] (=0), radii i32[N], conics f32[N,3], num_tiles_hit i32[N].
+ * clip_thresh is accepted and unused, as in the reference kernels. */
+int gi2d_project_gaussians_2d_forward(int num_points, float clip_coe, const float *means2d,
+                                      const float *L_elements, unsigned img_height,
+                                      unsigned img_width, int tiles_x, int tiles_y,
+                                      float clip_thresh, float radius_clip, float *xys,
+                                      float *depths, int32_t *radii, float *conics,
+                                      int32_t *num_tiles_hit, gi2d_stream_t stream);
+int gi2d_project_gaussians_2d_covariance_forward(int num_points, float clip_coe,
+                                                 const float *means2d, const float *cov2d,
+                                                 unsigned img_height, unsigned img_width,
+                                                 int tiles_x, int tiles_y, float clip_thresh,
+                                                 float radius_clip, float *xys, float *depths,
+                                                 int32_t *radii, float *conics,
+                                                 int32_t *num_tiles_hit, gi2d_stream_t stream);
+int gi2d_project_gaussians_2d_scale_rot_forward(int num_points, float clip_coe,
+                                                const float *means2d, const float *scales2d,
+                                                const float *rotation, unsigned img_height,
+                                                unsigned img_width, int tiles_x, int tiles_y,
+                                                float clip_thresh, float radius_clip, float *xys,
+                                                float *depths, int32_t *radii, float *conics,
+                                                int32_t *num_tiles_hit, gi2d_stream_t stream);
+
+/* bindings.cu:1517-1564 / :1565-1612 / :1614-1668  *_backward_tensor.
+ * Outputs v_cov2d f32[N,3], v_mean2d f32[N,2], then v_L f32[N,3] (Cholesky / covariance) or
+ * v_scale f32[N,2] + v_rot f32[N] (scale-rot).  Rows with radii<=0 are written as zeros.
+ * The Cholesky and scale-rot variants reproduce the reference's double-counted off-diagonal
+ * (backward2d.cu:39-40, :94-96). */
+int gi2d_project_gaussians_2d_backward(int num_points, const float *means2d,
+                                       const float *L_elements, unsigned img_height,
+                                       unsigned img_width, const int32_t *radii,
+                                       const float *conics, const float *v_xy,
+                                       const float *v_depth, const float *v_conic, float *v_cov2d,
+                                       float *v_mean2d, float *v_L_elements, gi2d_stream_t stream);
+int gi2d_project_gaussians_2d_covariance_backward(int num_points, const float *means2d,
+                                                  const float *cov2d, unsigned img_height,
+                                                  unsigned img_width, const int32_t *radii,
+                                                  const float *conics, const float *v_xy,
+                                                  const float *v_depth, const float *v_conic,
+                                                  float *v_cov2d, float *v_mean2d,
+                                                  float *v_cov2d_elements, gi2d_stream_t stream);
+int gi2d_project_gaussians_2d_scale_rot_backward(int num_points, const float *means2d,
+                                                 const float *scales2d, const float *rotation,
+                                                 unsigned img_height, unsigned img_width,
+                                                 const int32_t *radii, const float *conics,
+                                                 const float *v_xy, const float *v_depth,
+                                                 const float *v_conic, float *v_cov2d,
+                                                 float *v_mean2d, float *v_scale, float *v_rot,
+                                                 gi2d_stream_t stream);
+
+/* bindings.cu:44-63 compute_cov2d_bounds_tensor: conics f32[N,3], radii f32[N] (= radius.x). */
+int gi2d_compute_cov2d_bounds(int num_pts, float clip_coe, const float *covs2d, float *conics,
+                              float *radii, gi2d_stream_t stream);
+
+/* ------------------------------------------------------------------ binning (a5-a8)
+ * gsplat/gsplat/utils.py:248-249 (torch.cumsum + .item()): inclusive int32 scan; the total is
+ * written to the DEVICE word *total (the caller decides whether/when to read it back). */
+int gi2d_cumsum_tiles_hit(int num_points, const int32_t *num_tiles_hit, int32_t *cum_tiles_hit,
+                          int32_t *total, gi2d_stream_t stream);
+
+/* bindings.cu:283-365 map_gaussian_to_intersects_tensor.  isect_ids i64[M], gaussian_ids i32[M];
+ * every element is written (zeros where the reference leaves its torch::zeros untouched);
+ * writes beyond num_intersects are dropped instead of corrupting memory. */
+int gi2d_map_gaussian_to_intersects(int num_points, int num_intersects, const float *xys,
+                                    const float *depths, const int32_t *radii,
+                                    const int32_t *cum_tiles_hit, int tiles_x, int tiles_y,
+                                    float radius_clip, int64_t *isect_ids, int32_t *gaussian_ids,
+                                    gi2d_stream_t stream);
+
+/* gsplat/gsplat/utils.py:301-302 (torch.sort + torch.gather): STABLE sort of the pairs by key.
+ * Keys must have a tile id (bits 63..32) in [0, num_tiles) and non-negative depth bits.
+ * Optional outputs (may be NULL): isect_ids_sorted; perm i32[M] (sorted position -> input
+ * position); inv_perm i32[M] (input position -> sorted position); tile_bins i32[num_tiles,2]
+ * ([start,end) per tile, (0,0) when empty -- same content as gi2d_get_tile_bin_edges on the
+ * first num_tiles rows).  workspace: device scratch of at least
+ * gi2d_sort_workspace_bytes(M, num_tiles) bytes; after the call its first four int32 words hold
+ * status flags {any non-zero depth bits, tile id out of range (pair dropped), tile longer than
+ * 1024 entries with non-zero depth bits (unsupported, tile left unsorted), 0}. */
+size_t gi2d_sort_workspace_bytes(int num_intersects, int num_tiles);
+int gi2d_sort_intersects(int num_intersects, int num_tiles, const int64_t *isect_ids,
+                         const int32_t *gaussian_ids, int64_t *isect_ids_sorted,
+                         int32_t *gaussian_ids_sorted, int32_t *perm, int32_t *inv_perm,
+                         int32_t *tile_bins, void *workspace, size_t workspace_bytes,
+                         gi2d_stream_t stream);
+
+/* bindings.cu:368-383 get_tile_bin_edges_tensor.  tile_bins i32[rows,2], indexed by tile id; the
+ * reference allocates rows = num_intersects and writes out of bounds for larger tile ids --
+ * here such writes are dropped. */
+int gi2d_get_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted, int rows,
+                            int32_t *tile_bins, gi2d_stream_t stream);
+
+/* ------------------------------------------------------------------ rasterizer (a9, a10)
+ * bindings.cu:453-526 rasterize_forward_sum_tensor == :529-610 rasterize_sum_plus_forward_tensor.
+ * out_img f32[H,W,3], final_Ts f32[H,W] (=1), final_idx i32[H,W].  tile_bins has
+ * tile_bins_rows rows; tiles with id >= rows are empty.  `background` (device f32[3]) is only
+ * used when num_intersects_dev != NULL and *num_intersects_dev < 1, reproducing
+ * rasterize_sum_plus.py:110-118 (image = background) without a host round trip; pass NULL for
+ * the plain kernel semantics. */
+int gi2d_rasterize_sum_forward(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
+                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                               int tile_bins_rows, const float *xys, const float *conics,
+                               const float *colors, const float *opacities,
+                               const float *background, const int32_t *num_intersects_dev,
+                               float *final_Ts, int32_t *final_idx, float *out_img,
+                               gi2d_stream_t stream);
+int gi2d_rasterize_sum_plus_forward(int tiles_x, int tiles_y, unsigned img_width,
+                                    unsigned img_height, const int32_t *gaussian_ids_sorted,
+                                    const int32_t *tile_bins, int tile_bins_rows,
+                                    const float *xys, const float *conics, const float *colors,
+                                    const float *opacities, const float *background,
+                                    const int32_t *num_intersects_dev, float *final_Ts,
+                                    int32_t *final_idx, float *out_img, gi2d_stream_t stream);
+
+/* bindings.cu:1166-1240 rasterize_backward_sum_tensor == :1241-1314 rasterize_sum_plus_backward_tensor.
+ * v_xy f32[N,2], v_conic f32[N,3], v_rgb f32[N,3], v_opacity f32[N]; every row is written.
+ * v_abs_xy (sum form only, may be NULL) f32[N,4] = per-gaussian sums over pixels of
+ * (v_x, v_y, |v_x|, |v_y|): the gradient rasterize_sum.py:308,328 hands back for
+ * `screenspace_points` (backward.cu:932,959-960, commented out in the shipped kernel).
+ * No float atomics: each (tile, gaussian) partial is stored once and summed per gaussian in a
+ * fixed order, so gradients are bitwise reproducible.
+ * Two ways to provide the gaussian-major index used by the final sum:
+ *   - plan form: cum_tiles_hit i32[N] + inv_perm i32[M] (input position -> sorted position,
+ *     as written by gi2d_sort_intersects) from the forward binning;
+ *   - generic form: pass both NULL; the index is rebuilt from gaussian_ids_sorted.
+ * workspace >= gi2d_rasterize_backward_workspace_bytes(N, M). */
+size_t gi2d_rasterize_backward_workspace_bytes(int num_points, int num_intersects);
+int gi2d_rasterize_sum_backward(int num_points, int num_intersects, unsigned img_height,
+                                unsigned img_width, const int32_t *gaussian_ids_sorted,
+                                const int32_t *tile_bins, int tile_bins_rows, const float *xys,
+                                const float *conics, const float *colors, const float *opacities,
+                                const int32_t *final_idx, const float *v_output,
+                                const int32_t *cum_tiles_hit, const int32_t *inv_perm,
+                                float *v_xy, float *v_conic, float *v_rgb, float *v_opacity,
+                                float *v_abs_xy, void *workspace, size_t workspace_bytes,
+                                gi2d_stream_t stream);
+int gi2d_rasterize_sum_plus_backward(int num_points, int num_intersects, unsigned img_height,
+                                     unsigned img_width, const int32_t *gaussian_ids_sorted,
+                                     const int32_t *tile_bins, int tile_bins_rows,
+                                     const float *xys, const float *conics, const float *colors,
+                                     const float *opacities, const int32_t *final_idx,
+                                     const float *v_output, const int32_t *cum_tiles_hit,
+                                     const int32_t *inv_perm, float *v_xy, float *v_conic,
+                                     float *v_rgb, float *v_opacity, void *workspace,
+                                     size_t workspace_bytes, gi2d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GI2D_H */

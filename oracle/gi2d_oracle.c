@@ -424,6 +424,17 @@ void gi2d_oracle_get_tile_bin_edges(int m, const int64_t *isect_sorted, int rows
 #define GI2D_AMBIG_REL 2e-5f
 #define GI2D_AMBIG_SIGMA 1e-6f
 
+/* Conditioning weight of a pair for the tolerance scales reported next to the results:
+ * T = |a dx^2|/2 + |c dy^2|/2 + |b dx dy| is the magnitude of the terms sigma is summed
+ * from; every fp32 evaluation order of sigma (this file, nvcc's FMA-contracted code, the
+ * HIP kernels) carries a rounding error of a few ulp(T), i.e. a relative error of a few
+ * 6e-8*T in alpha.  The scale is |term| * max(1, T/16): "1e-5 relative" where the
+ * quadratic form is well conditioned, proportionally wider where it is not. */
+static inline float pair_weight(float a, float b, float c, float dx, float dy) {
+    float T = 0.5f * fabsf(a * dx * dx) + 0.5f * fabsf(c * dy * dy) + fabsf(b * dx * dy);
+    return fmaxf(1.f, T / 16.f);
+}
+
 static inline int pair_eval(float a, float b, float c, float gx, float gy, float opac, float px,
                             float py, float *dx_, float *dy_, float *vis_, float *alpha_,
                             int *ambig) {
@@ -453,7 +464,7 @@ static inline int pair_eval(float a, float b, float c, float gx, float gy, float
  * integer coordinate (:477-478).  final_Ts is always 1 (:497,:558); final_idx is the
  * absolute sorted-list index of the last contributor, 0 if none (:550,:559).
  * Optional (may be NULL): `ambig` u8[H*W] flags pixels touched by a near-threshold
- * pair; `abs_img` f32[H*W*3] receives sum |colour*alpha| for tolerance scaling. */
+ * pair; `abs_img` f32[H*W*3] receives sum |colour*alpha|*pair_weight for tolerance scaling. */
 void gi2d_oracle_rasterize_forward_sum(int tiles_x, int tiles_y, int img_w, int img_h,
                                        const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
                                        int tile_bins_rows, const float *xys, const float *conics,
@@ -487,9 +498,12 @@ void gi2d_oracle_rasterize_forward_sum(int tiles_x, int tiles_y, int img_w, int 
                     o0 = o0 + colors[3 * g] * alpha;
                     o1 = o1 + colors[3 * g + 1] * alpha;
                     o2 = o2 + colors[3 * g + 2] * alpha;
-                    a0 += fabsf(colors[3 * g] * alpha);
-                    a1 += fabsf(colors[3 * g + 1] * alpha);
-                    a2 += fabsf(colors[3 * g + 2] * alpha);
+                    if (abs_img) {
+                        float wgt = pair_weight(conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], dx, dy);
+                        a0 += fabsf(colors[3 * g] * alpha) * wgt;
+                        a1 += fabsf(colors[3 * g + 1] * alpha) * wgt;
+                        a2 += fabsf(colors[3 * g + 2] * alpha) * wgt;
+                    }
                     cur_idx = idx;
                 }
                 int pix = i * img_w + j;
@@ -514,7 +528,11 @@ void gi2d_oracle_rasterize_forward_sum(int tiles_x, int tiles_y, int img_w, int 
  * min(1,.) clamp (:948).  Outputs are zero-initialised (bindings.cu:1212-1216) and
  * accumulated here in double (the reference uses order-unspecified float atomics).
  * Optional (may be NULL): `ambig` u8[N] flags gaussians touched by a near-threshold
- * pair; `abs9` f32[N*9] = sum of |term| for (v_xy[2], v_conic[3], v_rgb[3], v_opacity). */
+ * pair; `abs9` f32[N*9] = tolerance scales: sum of |term|*pair_weight for (v_xy[2],
+ * v_conic[3], v_rgb[3], v_opacity), with the two v_xy terms taken part by part
+ * (|v_sigma a dx| + |v_sigma b dy|, ...);
+ * `v_abs_xy` f32[N*4] = (sum v_x, sum v_y, sum |v_x|, sum |v_y|) over pixels, the quantity
+ * rasterize_sum.py:308,328 returns for `screenspace_points` (backward.cu:932,959-960). */
 void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img_w, int img_h,
                                         const int32_t *gaussian_ids_sorted,
                                         const int32_t *tile_bins, int tile_bins_rows,
@@ -522,14 +540,15 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
                                         const float *opacities, const int32_t *final_idx,
                                         const float *v_output, float *v_xy, float *v_conic,
                                         float *v_rgb, float *v_opacity, uint8_t *ambig,
-                                        float *abs9) {
+                                        float *abs9, float *v_abs_xy) {
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
 #endif
     size_t stride = (size_t)n * 9;
     double *acc = (double *)calloc(stride * (size_t)nthreads, sizeof(double));
-    double *aacc = abs9 ? (double *)calloc(stride * (size_t)nthreads, sizeof(double)) : NULL;
+    double *aacc = v_abs_xy ? (double *)calloc(stride * (size_t)nthreads, sizeof(double)) : NULL;
+    double *wacc = abs9 ? (double *)calloc(stride * (size_t)nthreads, sizeof(double)) : NULL;
     uint8_t *amb_t = ambig ? (uint8_t *)calloc((size_t)n * (size_t)nthreads, 1) : NULL;
 #pragma omp parallel
     {
@@ -539,6 +558,7 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
 #endif
         double *A = acc + stride * (size_t)tid;
         double *AA = aacc ? aacc + stride * (size_t)tid : NULL;
+        double *AW = wacc ? wacc + stride * (size_t)tid : NULL;
         uint8_t *AM = amb_t ? amb_t + (size_t)n * (size_t)tid : NULL;
 #pragma omp for schedule(dynamic, 4)
         for (int tile = 0; tile < tiles_x * tiles_y; ++tile) {
@@ -553,7 +573,7 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
                 float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
                 float gx = xys[2 * g], gy = xys[2 * g + 1], opac = opacities[g];
                 float r0 = rgbs[3 * g], r1 = rgbs[3 * g + 1], r2 = rgbs[3 * g + 2];
-                double s[9] = {0}, sa[9] = {0};
+                double s[9] = {0}, sa[9] = {0}, sw[9] = {0};
                 int amb = 0, any = 0;
                 for (int ly = 0; ly < GI2D_BLOCK_Y; ++ly)
                     for (int lx = 0; lx < GI2D_BLOCK_X; ++lx) {
@@ -586,12 +606,19 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
                             s[k] += (double)t[k];
                             sa[k] += fabs((double)t[k]);
                         }
+                        if (AW) {
+                            double wgt = (double)pair_weight(a, b, c, dx, dy);
+                            sw[0] += wgt * (fabs((double)(v_sigma * a * dx)) + fabs((double)(v_sigma * b * dy)));
+                            sw[1] += wgt * (fabs((double)(v_sigma * b * dx)) + fabs((double)(v_sigma * c * dy)));
+                            for (int k = 2; k < 9; ++k) sw[k] += wgt * fabs((double)t[k]);
+                        }
                         any = 1;
                     }
                 if (any)
                     for (int k = 0; k < 9; ++k) {
                         A[(size_t)g * 9 + k] += s[k];
                         if (AA) AA[(size_t)g * 9 + k] += sa[k];
+                        if (AW) AW[(size_t)g * 9 + k] += sw[k];
                     }
                 if (AM && amb) AM[g] = 1;
             }
@@ -599,12 +626,13 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
     }
 #pragma omp parallel for schedule(static)
     for (int g = 0; g < n; ++g) {
-        double s[9] = {0}, sa[9] = {0};
+        double s[9] = {0}, sa[9] = {0}, sw[9] = {0};
         int amb = 0;
         for (int t = 0; t < nthreads; ++t) {
             for (int k = 0; k < 9; ++k) {
                 s[k] += acc[stride * (size_t)t + (size_t)g * 9 + k];
                 if (aacc) sa[k] += aacc[stride * (size_t)t + (size_t)g * 9 + k];
+                if (wacc) sw[k] += wacc[stride * (size_t)t + (size_t)g * 9 + k];
             }
             if (amb_t) amb |= amb_t[(size_t)n * (size_t)t + g];
         }
@@ -618,11 +646,18 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
         v_rgb[3 * g + 2] = (float)s[7];
         v_opacity[g] = (float)s[8];
         if (abs9)
-            for (int k = 0; k < 9; ++k) abs9[(size_t)g * 9 + k] = (float)sa[k];
+            for (int k = 0; k < 9; ++k) abs9[(size_t)g * 9 + k] = (float)sw[k];
+        if (v_abs_xy) {
+            v_abs_xy[4 * g] = (float)s[0];
+            v_abs_xy[4 * g + 1] = (float)s[1];
+            v_abs_xy[4 * g + 2] = (float)sa[0];
+            v_abs_xy[4 * g + 3] = (float)sa[1];
+        }
         if (ambig) ambig[g] = (uint8_t)amb;
     }
     free(acc);
     free(aacc);
+    free(wacc);
     free(amb_t);
 }
 

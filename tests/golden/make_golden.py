@@ -254,7 +254,7 @@ def golden_case(name, n, h, w, seed, kind_="cholesky", mutate=None):
                                                          op, with_aux=True)
     gt = rng.random((h, w, 3)).astype(np.float32)
     v_out = (2 * (np.clip(out, 0, 1) - gt) / (3 * h * w)).astype(np.float32)
-    v_xy, v_conic, v_rgb, v_op, gamb, abs9 = O.rasterize_sum_backward(h, w, 16, 16, go, bins, xys, conics, col, op,
+    v_xy, v_conic, v_rgb, v_op, gamb, abs9, vabs = O.rasterize_sum_backward(h, w, 16, 16, go, bins, xys, conics, col, op,
                                                                       None, fT, fidx, v_out, with_aux=True)
     if kind_ == "cholesky":
         pb = O.project_gaussians_2d_backward(n, d["in_means"], d["in_L"], h, w, radii, conics, v_xy, None, v_conic)
@@ -270,7 +270,7 @@ def golden_case(name, n, h, w, seed, kind_="cholesky", mutate=None):
     d.update(colors=col, opacity=op, xys=xys, depths=depths, radii=radii, conics=conics, num_tiles_hit=nth,
              cum_tiles_hit=cum, M=m, isect_ids=isect, gaussian_ids=gids, isect_sorted=so, gids_sorted=go,
              tile_bins=bins, out_img=out, final_Ts=fT, final_idx=fidx, pix_ambig=amb, pix_abs=absimg,
-             v_out=v_out, v_xy=v_xy, v_conic=v_conic, v_rgb=v_rgb, v_opacity=v_op, g_ambig=gamb, g_abs9=abs9)
+             v_out=v_out, v_xy=v_xy, v_conic=v_conic, v_rgb=v_rgb, v_opacity=v_op, g_ambig=gamb, g_abs9=abs9, v_abs_xy=vabs)
     np.savez_compressed(os.path.join(HERE, f"case_{name}.npz"), **d)
     return dict(name=name, n=n, h=h, w=w, M=int(m), max_per_tile=int((bins[:, 1] - bins[:, 0]).max()))
 
