@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's measurement contract for the 2D-Gaussian hot path.
+
+One STEP = one pass of the hot path over one image's gaussians, everything resident in HBM:
+    project_gaussians_2d (fwd) -> tile binning -> rasterize_sum forward
+    -> rasterize_sum backward (gradient image given) -> project_gaussians_2d (bwd)
+i.e. the work one training iteration of models/gaussianimage_cholesky.py:302-317 hands to the `gsplat`
+operator surface.  Model-side glue (tanh, +bound, clamp, MSE, optimizer) is not part of the metric
+(BASELINE.json: "training iters/sec (fwd+bwd rasterize)"); the gradient image v_out is fixed.
+
+N GPUs: one process per GPU, one independent image per rank (images shard embarrassingly,
+no data-path collective) -> weak scaling; value = ranks * K / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--num-points", type=int, default=50000)
+    p.add_argument("--height", type=int, default=512)
+    p.add_argument("--width", type=int, default=768)
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU, no number"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from helpers import synth_cholesky, synth_gt
+    from gaussianimage_plus_amd.hotpath import HotPath
+
+    n, h, w = args.num_points, args.height, args.width
+    xyz, L, col, op = synth_cholesky(n, h, w, 3047 + rank)  # reference default seed (train.py:225) + rank
+    hp = HotPath(n, h, w, device=dev)
+    hp.set_inputs(xyz, L, col, op)
+    # gradient image from the first render against a seeded smooth target
+    out = hp.forward()
+    gt = torch.from_numpy(synth_gt(h, w, 1 + rank)).to(dev)
+    hp.set_v_out((2 * (out.clamp(0, 1) - gt) / (3 * h * w)).contiguous())
+    m = hp.num_intersects()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hp.step()
+    barrier()
+    ev = hp.kernel_timers(args.steps)  # HIP events around the dominant kernel, on the launch stream
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        hp.step(timer=ev, index=i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hp.check_status()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ms = torch.tensor([float(m)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ms, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    value = world * args.steps / elapsed
+
+    if rank == 0:
+        dom = hp.dominant_kernel_stats(ev)  # name, avg_us, algorithmic bytes per launch
+        achieved = dom["bytes"] / (dom["avg_us"] * 1e-6) / 1e9
+        pair_bytes = 80 * m + 36 * h * w + 36 * n  # SURVEY 8d north-star figure (fwd + bwd rasterize)
+        line = {
+            "metric": "training iters/sec (fwd+bwd rasterize) at N Gaussians, 768x512",
+            "value": value,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Cholesky model, N={n} Gaussians, {w}x{h}, one image per GPU: project fwd + tile binning + "
+                            f"rasterize_sum fwd + bwd + project bwd per step (fixed gradient image)",
+                "num_points": n, "height": h, "width": w, "num_intersects_rank0": m,
+                "num_intersects_mean": float(ms.item()) / world, "seed": 3047,
+                "host_path": hp.describe(),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": dom["bytes"], "avg_kernel_us": dom["avg_us"],
+                "note": "VALU-bound by construction (each staged gaussian is reused by up to 256 pixels); see DESIGN.md",
+            },
+            "rasterize_pair": hp.pair_stats(ev, pair_bytes),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(xyz, L, col, op, h, w, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(xyz, L, col, op, h, w, budget_s):
+    """The CPU oracle (oracle/gi2d_oracle.c, OpenMP) on the host cores of this box, same workload,
+    bounded to ~budget_s seconds.  kind "port": the reference has no CPU implementation of this path."""
+    from oracle import oracle as O
+    O.build()
+    cores = O.num_threads()
+    n = xyz.shape[0]
+    tb = O.tile_bounds(h, w)
+
+    def one():
+        xys, depths, radii, conics, nth = O.project_gaussians_2d_forward(n, 3.0, xyz, L, h, w, tb, 0.01, 1.0)
+        m, cum = O.compute_cumulative_intersects(nth)
+        _, _, so, go, bins = O.bin_and_sort_gaussians(n, m, xys, depths, radii, cum, tb, 1.0)
+        out, fT, fidx = O.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, xys, conics, col, op)
+        v_out = (2 * (np.clip(out, 0, 1) - 0.5) / (3 * h * w)).astype(np.float32)
+        v_xy, v_conic, v_rgb, v_op = O.rasterize_sum_backward(h, w, 16, 16, go, bins, xys, conics, col, op, None, fT,
+                                                               fidx, v_out)
+        O.project_gaussians_2d_backward(n, xyz, L, h, w, radii, conics, v_xy, None, v_conic)
+
+    one()
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget_s and k < 200:
+        one()
+        k += 1
+    dt = time.perf_counter() - t0
+    return {"value": k / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"{k} full steps (project+bin+rasterize fwd+bwd, same N/size) of the OpenMP oracle in {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -33,11 +33,15 @@ SIGNATURES = {
     "gi2d_rasterize_sum_forward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_rasterize_sum_plus_forward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_rasterize_sum_backward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gi2d_bin_gaussians": [_i, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p, _sz, _p],
+    "gi2d_rasterize_backward_tiles": [_u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gi2d_rasterize_backward_reduce": [_i, _p, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_rasterize_sum_plus_backward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
 }
 SIZE_FUNCS = {
     "gi2d_sort_workspace_bytes": [_i, _i],
     "gi2d_rasterize_backward_workspace_bytes": [_i, _i],
+    "gi2d_bin_workspace_bytes": [_i, _i],
 }
 STRING_FUNCS = ["gi2d_version", "gi2d_last_error_string"]
 

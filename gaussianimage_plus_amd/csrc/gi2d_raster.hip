@@ -391,6 +391,83 @@ __global__ __launch_bounds__(256) void gather_plan_kernel(int n, int m,
     store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
 }
 
+// Box form (fast path, pairs with gi2d_bin_gaussians): gaussian g re-derives the tiles it was binned
+// into from (xys, radii) exactly as the binning did, and finds its entry in each tile's ascending id
+// list by binary search.  Tiles are visited in ascending tile id -> reproducible sums.  Gaussians that
+// cover more than GI2D_BIG_TILES tiles are handled by the whole wave (lanes stride over the tiles, fixed
+// butterfly reduction) so one huge gaussian does not serialise a lane.
+#define GI2D_BIG_TILES 32
+__device__ __forceinline__ int find_in_tile(const int32_t *__restrict__ gids_sorted,
+                                            const int2 *__restrict__ tile_bins, int tile, int rows, int g) {
+    if (tile >= rows) return -1;
+    const int2 r = tile_bins[tile];
+    int lo = r.x, hi = min(r.y, r.x + GI2D_TILE_LIST_CAP);  // entries past the cap carry no gradient
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = gids_sorted[mid];
+        if (v == g) return mid;
+        if (v < g)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void gather_bbox_kernel(
+    int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
+    float radius_clip, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins, int rows,
+    const float4 *__restrict__ partials, float2 *__restrict__ v_xy, float *__restrict__ v_conic,
+    float *__restrict__ v_rgb, float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float acc[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) acc[q] = 0.f;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0;
+    bool mapped = false;
+    if (g < n) {
+        const int rad = radii[g];
+        if (rad > 0 && !((float)rad < radius_clip)) {
+            const float2 c = xys[g];
+            tile_bbox(c.x, c.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+            mapped = mxx > mnx && mxy > mny;
+        }
+    }
+    const int ntiles = mapped ? (mxx - mnx) * (mxy - mny) : 0;
+    if (mapped && ntiles <= GI2D_BIG_TILES) {
+        for (int i = mny; i < mxy; ++i)
+            for (int j = mnx; j < mxx; ++j) {
+                const int pos = find_in_tile(gids_sorted, tile_bins, i * tiles_x + j, rows, g);
+                if (pos >= 0) add_partial(acc, partials, pos);
+            }
+    }
+    unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(mnx, src, 64), by0 = __shfl(mny, src, 64);
+        const int bw = __shfl(mxx, src, 64) - bx0, bn = __shfl(ntiles, src, 64);
+        const int bg = __shfl(g, src, 64);
+        float part[11];
+#pragma unroll
+        for (int q = 0; q < 11; ++q) part[q] = 0.f;
+        for (int t = lane; t < bn; t += 64) {
+            const int tile = (by0 + t / bw) * tiles_x + bx0 + t % bw;
+            const int pos = find_in_tile(gids_sorted, tile_bins, tile, rows, bg);
+            if (pos >= 0) add_partial(part, partials, pos);
+        }
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            float v = part[q];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == src) acc[q] = v;
+        }
+    }
+    if (g < n) store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
+}
+
 // Generic form: rebuild the gaussian-major index from gaussian_ids_sorted.
 __global__ __launch_bounds__(256) void gidx_count_kernel(int m, int n,
                                                          const int32_t *__restrict__ gids_sorted,
@@ -583,6 +660,47 @@ extern "C" {
 
 size_t gi2d_rasterize_backward_workspace_bytes(int n, int m) {
     return carve_bwd_ws(nullptr, n, m).bytes;
+}
+
+int gi2d_rasterize_backward_tiles(unsigned h, unsigned w, const int32_t *gids, const int32_t *bins,
+                                  int rows, const float *xys, const float *conics, const float *colors,
+                                  const float *opac, const int32_t *final_idx, const float *v_output,
+                                  int with_abs, float *partials, gi2d_stream_t st) {
+    const int tiles_x = (int)((w + GI2D_TILE - 1) / GI2D_TILE), tiles_y = (int)((h + GI2D_TILE - 1) / GI2D_TILE);
+    const long long t = (long long)tiles_x * tiles_y;
+    if (t == 0 || rows <= 0) return GI2D_OK;
+    if (!gids || !bins || !xys || !conics || !colors || !opac || !final_idx || !v_output || !partials) {
+        set_error("rasterize backward tiles: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (with_abs)
+        hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x,
+                           tiles_y, (int)w, (int)h, gids, (const int2 *)bins, rows, (const float2 *)xys, conics,
+                           colors, opac, final_idx, v_output, (float4 *)partials);
+    else
+        hipLaunchKernelGGL(raster_bwd_kernel<false>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x,
+                           tiles_y, (int)w, (int)h, gids, (const int2 *)bins, rows, (const float2 *)xys, conics,
+                           colors, opac, final_idx, v_output, (float4 *)partials);
+    return check_launch("rasterize backward tiles");
+}
+
+int gi2d_rasterize_backward_reduce(int n, const float *xys, const int32_t *radii, int tiles_x, int tiles_y,
+                                   float radius_clip, const int32_t *gids, const int32_t *bins, int rows,
+                                   const float *partials, float *v_xy, float *v_conic, float *v_rgb,
+                                   float *v_opacity, float *v_abs_xy, gi2d_stream_t st) {
+    if (n < 0 || rows < 0) {
+        set_error("rasterize backward reduce: negative size");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return GI2D_OK;
+    if (!xys || !radii || !v_xy || !v_conic || !v_rgb || !v_opacity || (rows > 0 && (!gids || !bins || !partials))) {
+        set_error("rasterize backward reduce: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(gather_bbox_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, n,
+                       (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, gids, (const int2 *)bins, rows,
+                       (const float4 *)partials, (float2 *)v_xy, v_conic, v_rgb, v_opacity, (float4 *)v_abs_xy);
+    return check_launch("rasterize backward reduce");
 }
 
 int gi2d_rasterize_sum_forward(int tiles_x, int tiles_y, unsigned w, unsigned h,

@@ -213,6 +213,51 @@ def get_tile_bin_edges(num_intersects, isect_ids_sorted, rows=None):
     return bins
 
 
+def bin_gaussians(xys, radii, tile_bounds, radius_clip, capacity):
+    """Sync-free binning (include/gi2d.h gi2d_bin_gaussians): the native replacement of
+    compute_cumulative_intersects + bin_and_sort_gaussians for depth == 0.
+    -> (gaussian_ids_sorted i32[capacity], tile_bins i32[T,2], status i32[4] = {M, overflow, 0, 0})"""
+    _chk(xys, "xys", torch.float32)
+    _chk(radii, "radii", torch.int32)
+    n, cap = xys.size(0), int(capacity)
+    t = int(tile_bounds[0]) * int(tile_bounds[1])
+    gids, bins, status = _i32(cap, like=xys), _i32(t, 2, like=xys), _i32(4, like=xys)
+    ws = _workspace(_lib.load().gi2d_bin_workspace_bytes(cap, t), xys)
+    with torch.cuda.device(xys.device):
+        _lib.call("gi2d_bin_gaussians", n, cap, xys.data_ptr(), radii.data_ptr(), int(tile_bounds[0]),
+                  int(tile_bounds[1]), float(radius_clip), gids.data_ptr(), bins.data_ptr(), status.data_ptr(),
+                  ws.data_ptr(), ws.numel(), _stream(xys))
+    return gids, bins, status
+
+
+def rasterize_backward_fast(img_height, img_width, gaussian_ids_sorted, tile_bins, xys, radii, conics, colors,
+                            opacities, final_idx, v_output, radius_clip, with_abs=False):
+    """gi2d_rasterize_backward_tiles + gi2d_rasterize_backward_reduce (box form: the per-gaussian sum
+    re-derives the tile box from xys/radii).  -> (v_xy, v_conic, v_colors, v_opacity[N,1], v_abs_xys|None)"""
+    for t, nm in ((gaussian_ids_sorted, "gaussian_ids_sorted"), (tile_bins, "tile_bins"), (final_idx, "final_idx"),
+                  (radii, "radii")):
+        _chk(t, nm, torch.int32)
+    for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (opacities, "opacities"),
+                  (v_output, "v_output")):
+        _chk(t, nm, torch.float32)
+    n, cap = xys.size(0), gaussian_ids_sorted.numel()
+    h, w = int(img_height), int(img_width)
+    tx, ty = (w + _TILE - 1) // _TILE, (h + _TILE - 1) // _TILE
+    partials = _f32(max(cap, 1), 12, like=xys)
+    v_xy, v_conic = _f32(n, 2, like=xys), _f32(n, 3, like=xys)
+    v_colors, v_opacity = _f32(n, 3, like=xys), _f32(n, 1, like=xys)
+    v_abs = _f32(n, 4, like=xys) if with_abs else None
+    with torch.cuda.device(xys.device):
+        st = _stream(xys)
+        _lib.call("gi2d_rasterize_backward_tiles", h, w, gaussian_ids_sorted.data_ptr(), tile_bins.data_ptr(),
+                  tile_bins.size(0), xys.data_ptr(), conics.data_ptr(), colors.data_ptr(), opacities.data_ptr(),
+                  final_idx.data_ptr(), v_output.data_ptr(), 1 if with_abs else 0, partials.data_ptr(), st)
+        _lib.call("gi2d_rasterize_backward_reduce", n, xys.data_ptr(), radii.data_ptr(), tx, ty, float(radius_clip),
+                  gaussian_ids_sorted.data_ptr(), tile_bins.data_ptr(), tile_bins.size(0), partials.data_ptr(),
+                  v_xy.data_ptr(), v_conic.data_ptr(), v_colors.data_ptr(), v_opacity.data_ptr(), _ptr(v_abs), st)
+    return v_xy, v_conic, v_colors, v_opacity, v_abs
+
+
 # ------------------------------------------------------------------------------- rasterizer
 def _check_block(block):
     if int(block[0]) != _TILE or int(block[1]) != _TILE:

@@ -187,6 +187,49 @@ int gi2d_rasterize_sum_plus_backward(int num_points, int num_intersects, unsigne
                                      float *v_rgb, float *v_opacity, void *workspace,
                                      size_t workspace_bytes, gi2d_stream_t stream);
 
+/* ------------------------------------------------------------------ sync-free fast path
+ * The same results as the ops above, with the host round trip of the reference orchestration
+ * (rasterize_sum_plus.py:108 -> utils.py:249 `.item()`) removed: buffers are sized by a
+ * caller-chosen `capacity` (>= the expected number of intersections) and the true count lives on
+ * the device.  Every call only enqueues kernels, so project -> bin -> rasterize fwd/bwd can be
+ * captured in one hipGraph.
+ *
+ * gi2d_bin_gaussians replaces compute_cumulative_intersects + map_gaussian_to_intersects +
+ * torch.sort/gather + get_tile_bin_edges (utils.py:231-311) for the 2D path (depth == 0):
+ *   gaussian_ids_sorted i32[capacity] : per tile, ascending ids of the gaussians with radii > 0,
+ *                                       radii >= radius_clip whose tile box covers it
+ *   tile_bins i32[tiles_x*tiles_y, 2] : [start, end) per tile, (0,0) when empty
+ *   status i32[4]                     : {M = number of intersections, M > capacity (lists were
+ *                                       truncated -- enlarge capacity and redo), 0, 0}
+ * &status[0] is what gi2d_rasterize_sum_forward takes as num_intersects_dev. */
+size_t gi2d_bin_workspace_bytes(int capacity, int num_tiles);
+int gi2d_bin_gaussians(int num_points, int capacity, const float *xys, const int32_t *radii,
+                       int tiles_x, int tiles_y, float radius_clip, int32_t *gaussian_ids_sorted,
+                       int32_t *tile_bins, int32_t *status, void *workspace, size_t workspace_bytes,
+                       gi2d_stream_t stream);
+
+/* The two halves of rasterize_sum[_plus]_backward, callable on their own:
+ *  _tiles  : the tile kernel; partials f32[capacity,12] receives one row per sorted position:
+ *            (v_x, v_y, v_conic[3], v_rgb[3], v_opacity, sum|v_x|, sum|v_y|, 0); rows of positions
+ *            past a tile's 256-entry cap are zero; the abs sums are computed iff with_abs != 0.
+ *  _reduce : per-gaussian sum of those rows in ascending tile order.  The rows are located by
+ *            re-deriving the gaussian's tile box from (xys, radii, radius_clip) as
+ *            gi2d_bin_gaussians / map_gaussian_to_intersects do and binary-searching its id in
+ *            each tile's ascending list, so no index from the forward pass is needed.
+ *            v_abs_xy may be NULL. */
+int gi2d_rasterize_backward_tiles(unsigned img_height, unsigned img_width,
+                                  const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                  int tile_bins_rows, const float *xys, const float *conics,
+                                  const float *colors, const float *opacities,
+                                  const int32_t *final_idx, const float *v_output, int with_abs,
+                                  float *partials, gi2d_stream_t stream);
+int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32_t *radii,
+                                   int tiles_x, int tiles_y, float radius_clip,
+                                   const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                   int tile_bins_rows, const float *partials, float *v_xy,
+                                   float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                   gi2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

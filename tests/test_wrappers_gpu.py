@@ -1,0 +1,131 @@
+"""GPU: the drop-in `gsplat` surface end to end (autograd Functions), including the legacy call
+shapes the Cholesky / RS model files use, against the oracle run stage by stage on the same tensors."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_close, synth_cholesky
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gs():
+    assert torch.cuda.is_available()
+    import gaussianimage_plus_amd
+    gaussianimage_plus_amd.install_as_gsplat()
+    import gsplat
+    return gsplat
+
+
+def _stage_check(oracle, h, w, d_xys, d_depths, d_radii, d_conics, d_nth, col, op, img, v_img, grads, rclip=1.0):
+    tb = oracle.tile_bounds(h, w)
+    npts = d_xys.shape[0]
+    m, cum = oracle.compute_cumulative_intersects(d_nth)
+    _, _, so, go, bins = oracle.bin_and_sort_gaussians(npts, m, d_xys, d_depths, d_radii, cum, tb, rclip)
+    out_o, fT, fidx, amb, absimg = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, d_xys, d_conics,
+                                                                col, op, with_aux=True)
+    ok = np.repeat((amb == 0)[..., None], 3, -1)
+    check_close("wrapper out_img", img, out_o, absimg, mask=ok)
+    want = oracle.rasterize_sum_backward(h, w, 16, 16, go, bins, d_xys, d_conics, col, op, None, fT, fidx, v_img,
+                                         with_aux=True)
+    okg = want[4] == 0
+    check_close("wrapper v_colors", grads["colors"], want[2], want[5][:, 5:8], mask=np.repeat(okg[:, None], 3, 1),
+                atol=1e-12)
+    return want, okg
+
+
+def test_cholesky_model_call_shape_end_to_end(gs, oracle):
+    """models/gaussianimage_cholesky.py:206-221 verbatim call shapes (legacy 6-return projection +
+    rasterize_gaussians_sum 3-return)."""
+    from gsplat.project_gaussians_2d import project_gaussians_2d
+    from gsplat.rasterize_sum import rasterize_gaussians_sum
+    npts, h, w = 3000, 112, 176
+    xyz, L, col, op = synth_cholesky(npts, h, w, 21)
+    tb = oracle.tile_bounds(h, w)
+    x_t = torch.from_numpy(xyz).to(DEV).requires_grad_(True)
+    L_t = torch.from_numpy(L).to(DEV).requires_grad_(True)
+    c_t = torch.from_numpy(col).to(DEV).requires_grad_(True)
+    o_t = torch.from_numpy(op).to(DEV)
+    screen0 = torch.zeros((npts, 4), dtype=torch.float32, requires_grad=True, device=DEV)
+    screen = screen0 + 0
+    xys, screen, depths, radii, conics, nth = project_gaussians_2d(x_t, screen, L_t, h, w, tb, isprint=False)
+    out_img, per_pix, screen = rasterize_gaussians_sum(xys, screen, depths, radii, conics, nth, c_t, o_t, h, w, 16, 16,
+                                                       background=torch.ones(3, device=DEV), return_alpha=False)
+    assert out_img.shape == (h, w, 3) and per_pix.shape == (h, w) and per_pix.dtype == torch.int32
+    xys.retain_grad()
+    conics.retain_grad()
+    v_img = torch.from_numpy(np.random.default_rng(0).normal(size=(h, w, 3)).astype(np.float32) * 1e-3).to(DEV)
+    (out_img * v_img).sum().backward()
+    want, okg = _stage_check(oracle, h, w, xys.detach().cpu().numpy(), depths.detach().cpu().numpy(),
+                             radii.cpu().numpy(), conics.detach().cpu().numpy(), nth.cpu().numpy(), col, op,
+                             out_img.detach().cpu().numpy(), v_img.cpu().numpy(),
+                             {"colors": c_t.grad.cpu().numpy()})
+    # gradient handed back for screenspace_points = v_abs_xys (rasterize_sum.py:308,328)
+    assert screen0.grad is not None and screen0.grad.shape == (npts, 4)
+    sg = screen0.grad.cpu().numpy()
+    assert np.array_equal(sg[:, :2], xys.grad.cpu().numpy())
+    check_close("v_abs_xy", sg[:, 2:], want[6][:, 2:], want[6][:, 2:], mask=np.repeat(okg[:, None], 2, 1), atol=1e-12)
+    # projection backward (reference-faithful Cholesky VJP) on the rasterizer's own gradients
+    pb = oracle.project_gaussians_2d_backward(npts, xyz, L, h, w, radii.cpu().numpy(), conics.detach().cpu().numpy(),
+                                              xys.grad.cpu().numpy(), None, conics.grad.cpu().numpy())
+    sc = np.abs(pb[2]).max(axis=-1, keepdims=True) + 1e-30
+    check_close("v_L", L_t.grad.cpu().numpy(), pb[2], sc, rtol=4e-5)
+    check_close("v_mean", x_t.grad.cpu().numpy(), pb[1], np.abs(pb[1]).max(axis=-1, keepdims=True) + 1e-30, rtol=4e-5)
+
+
+def test_covariance_model_call_shape_end_to_end(gs, oracle):
+    """models/gaussianimage_covariance.py:194-208: project_gaussians_2d_covariance + rasterize_gaussians_plus."""
+    npts, h, w = 2500, 90, 130
+    rng = np.random.default_rng(4)
+    mean_px = (rng.random((npts, 2)) * np.array([w, h])).astype(np.float32)
+    cov = (rng.random((npts, 3)) * np.array([1, 0.5, 1]) + np.array([3, -0.25, 3])).astype(np.float32)
+    col = rng.random((npts, 3)).astype(np.float32)
+    op = (0.3 + 0.7 * rng.random((npts, 1))).astype(np.float32)
+    tb = oracle.tile_bounds(h, w)
+    m_t = torch.from_numpy(mean_px).to(DEV).requires_grad_(True)
+    c_t = torch.from_numpy(cov).to(DEV).requires_grad_(True)
+    col_t = torch.from_numpy(col).to(DEV).requires_grad_(True)
+    op_t = torch.from_numpy(op).to(DEV).requires_grad_(True)
+    xys, depths, radii, conics, nth = gs.project_gaussians_2d_covariance(m_t, c_t, h, w, tb, coords_norm=False,
+                                                                        clip_coe=2.5, radius_clip=2.0, isprint=False)
+    img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, col_t, op_t, h, w, 16, 16,
+                                      background=torch.ones(3, device=DEV), isprint=False, radius_clip=2.0)
+    v_img = torch.from_numpy(rng.normal(size=(h, w, 3)).astype(np.float32) * 1e-3).to(DEV)
+    (img * v_img).sum().backward()
+    want, okg = _stage_check(oracle, h, w, xys.detach().cpu().numpy(), depths.detach().cpu().numpy(),
+                             radii.cpu().numpy(), conics.detach().cpu().numpy(), nth.cpu().numpy(), col, op,
+                             img.detach().cpu().numpy(), v_img.cpu().numpy(), {"colors": col_t.grad.cpu().numpy()},
+                             rclip=2.0)
+    check_close("v_opacity", op_t.grad.cpu().numpy(), want[3], want[5][:, 8:9], mask=okg[:, None], atol=1e-12)
+    assert m_t.grad is not None and c_t.grad is not None and torch.isfinite(c_t.grad).all()
+
+
+def test_zero_intersections_gives_background_and_zero_grads(gs):
+    npts, h, w = 16, 40, 40
+    tb = ((w + 15) // 16, (h + 15) // 16, 1)
+    m_t = torch.full((npts, 2), 20.0, device=DEV, requires_grad=True)
+    c_t = torch.zeros(npts, 3, device=DEV, requires_grad=True)  # det == 0 -> every gaussian culled
+    col = torch.rand(npts, 3, device=DEV, requires_grad=True)
+    op = torch.ones(npts, 1, device=DEV)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    xys, depths, radii, conics, nth = gs.project_gaussians_2d_covariance(m_t, c_t, h, w, tb)
+    img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, col, op, h, w, background=bg)
+    assert torch.equal(img, bg.expand(h, w, 3))
+    img.sum().backward()
+    assert float(col.grad.abs().max()) == 0.0
+
+
+def test_wrapper_errors(gs):
+    with pytest.raises(ValueError):
+        gs.rasterize_gaussians_plus(torch.zeros(4, 3, device=DEV), None, None, None, None, torch.zeros(4, 3, device=DEV),
+                                    None, 16, 16)
+    with pytest.raises(ValueError):
+        gs.project_gaussians_2d_scale_rot(torch.zeros(0, 2, device=DEV), torch.zeros(0, 2, device=DEV),
+                                          torch.zeros(0, 1, device=DEV), 16, 16, (1, 1, 1))
+    with pytest.raises(AssertionError):
+        gs.rasterize_gaussians_plus(torch.zeros(4, 2, device=DEV), None, None, None, None, torch.zeros(4, 3, device=DEV),
+                                    None, 16, 16, background=torch.ones(4, device=DEV))
+    with pytest.raises(NotImplementedError):
+        gs.spherical_harmonics(3, None, None)
