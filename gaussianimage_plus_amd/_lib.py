@@ -38,7 +38,20 @@ SIGNATURES = {
     "gi2d_rasterize_backward_reduce": [_i, _p, _p, _i, _i, _f, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_rasterize_sum_plus_backward": [_i, _i, _u, _u, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p],
 }
+SIGNATURES.update({
+    "gi2d_fast_workspace_init": [_p, _sz, _i, _i, _i, _p],
+    "gi2d_fast_workspace_views": [_p, _sz, _i, _i, _i, _p, _p],
+    "gi2d_fast_bin": [_i, _p, _p, _i, _i, _f, _p, _sz, _p, _p],
+    "gi2d_fast_project_bin": [_i, _i, _f, _p, _p, _p, _u, _u, _i, _i, _f, _p, _p, _p, _p, _p, _p, _sz, _p, _p],
+    "gi2d_fast_rasterize_forward": [_i, _i, _i, _u, _u, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p, _p],
+    "gi2d_fast_rasterize_backward_tiles": [_i, _i, _i, _u, _u, _p, _p, _i, _p, _sz, _p],
+    "gi2d_fast_rasterize_backward_reduce": [_i, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p, _p],
+    "gi2d_fast_reduce_project_backward": [_i, _i, _p, _p, _u, _u, _p, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p,
+                                          _p, _p, _p, _p, _p],
+    "gi2d_fast_tile_capacity": [],
+})
 SIZE_FUNCS = {
+    "gi2d_fast_workspace_bytes": [_i, _i, _i],
     "gi2d_sort_workspace_bytes": [_i, _i],
     "gi2d_rasterize_backward_workspace_bytes": [_i, _i],
     "gi2d_bin_workspace_bytes": [_i, _i],

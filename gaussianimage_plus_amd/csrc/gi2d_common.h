@@ -25,6 +25,7 @@ __device__ __forceinline__ int cvt_rzi(float x) {
 __device__ __forceinline__ void tile_bbox(float cx, float cy, float pix_radius, int tiles_x,
                                           int tiles_y, int &min_x, int &min_y, int &max_x,
                                           int &max_y) {
+#pragma clang fp contract(off)
     const float tcx = cx / (float)GI2D_TILE, tcy = cy / (float)GI2D_TILE;
     const float tr = pix_radius / (float)GI2D_TILE;
     min_x = min(max(0, cvt_rzi(tcx - tr)), tiles_x);
@@ -37,6 +38,7 @@ __device__ __forceinline__ void tile_bbox(float cx, float cy, float pix_radius, 
 __device__ __forceinline__ bool cov2d_bounds(float cxx, float cxy, float cyy, float clip_coe,
                                              float &k0, float &k1, float &k2, float &rad_major,
                                              float &rad_minor) {
+#pragma clang fp contract(off)
     const float det = cxx * cyy - cxy * cxy;
     if (det == 0.f) return false;
     const float inv_det = 1.f / det;

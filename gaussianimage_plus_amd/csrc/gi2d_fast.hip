@@ -1,0 +1,565 @@
+// Fused fast path of the 2D-Gaussian hot path (what the rasterize wrappers and bench.py run).
+//
+// Same results as the reference-shaped ops (gi2d_project / gi2d_binning / gi2d_raster), restructured
+// around what actually costs time on MI355X at these sizes -- kernel boundaries and the serial
+// dependent-load chains at the head of every tile workgroup -- rather than HBM bytes:
+//
+//   fill     one lane per gaussian drops its id into fixed-capacity per-tile buckets (returning int
+//            atomics on 4 sub-cursors per tile).  No count pass, no scan, no keys, no sort launch;
+//            optionally fused with the projection itself (project_fill).
+//   forward  one workgroup per tile: ranks the bucket's ids in LDS (ascending id == the stable key
+//            sort of the reference pipeline), gathers each gaussian ONCE, writes the tile-sorted
+//            48-byte records ("packed list") + ids + tile_bins for the backward, resets the bucket
+//            cursors for the next call, and rasterizes (same code as the plain forward).
+//   backward one workgroup per tile reads the packed records with coalesced 16-byte loads (no
+//            gather), runs the strip items, and stores each (tile, gaussian) partial straight into
+//            a gaussian-major row (gaussians on <= 16 tiles), so that
+//   reduce   is a single level of coalesced loads per gaussian (fixed ascending-tile order: bitwise
+//            reproducible); optionally fused with the projection backward (reduce_project).
+//
+// Capacity contract: at most GI2D_FAST_CSUB ids per (tile, sub-bucket).  A fuller bucket sets
+// status[1] and the caller must fall back to the exact path (gi2d_bin_gaussians + plain ops).
+#include "gi2d_project_core.h"
+#include "gi2d_raster_core.h"
+
+namespace gi2d {
+
+#define GI2D_FAST_SUB 4
+#define GI2D_FAST_CSUB 128
+#define GI2D_FAST_C (GI2D_FAST_SUB * GI2D_FAST_CSUB) /* list slots per tile */
+#define GI2D_FAST_S 16                               /* gaussian-major partial rows per gaussian */
+#define GI2D_BIG_TILES_F 32
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+struct FastWs {
+    int32_t *cursors;      // [T * SUB]          zero between calls
+    int32_t *buckets;      // [T * C]            unsorted ids per (tile, sub)
+    int32_t *gids_sorted;  // [T * C]            ascending ids per tile (stride C)
+    int32_t *tile_bins;    // [T * 2]            [t*C, t*C + len)
+    GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
+    float4 *partial_g;     // [N * S * 3]        gaussian-major partial rows
+    float4 *partial_big;   // [T * 256 * 3]      partial rows of gaussians on > S tiles, by (tile, rank)
+    size_t bytes;
+};
+static FastWs carve_fast(void *base, int n, int num_tiles) {
+    FastWs w;
+    char *b = (char *)base;
+    size_t off = 0;
+    const size_t t = (size_t)(num_tiles > 0 ? num_tiles : 1), nn = (size_t)(n > 0 ? n : 1);
+    w.cursors = (int32_t *)(b + off);
+    off += align_up(t * GI2D_FAST_SUB * sizeof(int32_t));
+    w.buckets = (int32_t *)(b + off);
+    off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
+    w.gids_sorted = (int32_t *)(b + off);
+    off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
+    w.tile_bins = (int32_t *)(b + off);
+    off += align_up(t * 2 * sizeof(int32_t));
+    w.packed = (GaussRec *)(b + off);
+    off += align_up(t * GI2D_TILE_LIST_CAP * sizeof(GaussRec));
+    w.partial_g = (float4 *)(b + off);
+    off += align_up(nn * GI2D_FAST_S * 3 * sizeof(float4));
+    w.partial_big = (float4 *)(b + off);
+    off += align_up(t * GI2D_TILE_LIST_CAP * 3 * sizeof(float4));
+    w.bytes = off;
+    return w;
+}
+
+// ----------------------------------------------------------------------------------------- fill
+__device__ __forceinline__ void fill_one(int g, int mnx, int mny, int mxx, int mxy, int tiles_x,
+                                         int32_t *__restrict__ cursors, int32_t *__restrict__ buckets) {
+    const int sub = g & (GI2D_FAST_SUB - 1);
+    for (int i = mny; i < mxy; ++i)
+        for (int j = mnx; j < mxx; ++j) {
+            const int c = (i * tiles_x + j) * GI2D_FAST_SUB + sub;
+            const int p = atomicAdd(&cursors[c], 1);
+            if (p < GI2D_FAST_CSUB) buckets[c * GI2D_FAST_CSUB + p] = g;
+        }
+}
+
+__global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__restrict__ xys,
+                                                        const int32_t *__restrict__ radii, int tiles_x,
+                                                        int tiles_y, float radius_clip,
+                                                        int32_t *__restrict__ cursors,
+                                                        int32_t *__restrict__ buckets,
+                                                        int32_t *__restrict__ status) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        status[0] = 0;
+        status[1] = 0;
+        status[2] = 0;
+        status[3] = 0;
+    }
+    if (g >= n) return;
+    const int rad = radii[g];
+    if (rad <= 0 || (float)rad < radius_clip) return;  // forward.cu:161; culled gaussians own no slot
+    const float2 c = xys[g];
+    int mnx, mny, mxx, mxy;
+    tile_bbox(c.x, c.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+    fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void fast_project_fill_kernel(
+    int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
+    const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
+    float2 *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors,
+    int32_t *__restrict__ buckets, int32_t *__restrict__ status) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        status[0] = 0;
+        status[1] = 0;
+        status[2] = 0;
+        status[3] = 0;
+    }
+    if (g >= n) return;
+    const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
+    xys[g] = o.xy;
+    depths[g] = 0.f;
+    radii[g] = o.radius;
+    conics[3 * g] = o.k0;
+    conics[3 * g + 1] = o.k1;
+    conics[3 * g + 2] = o.k2;
+    num_tiles_hit[g] = o.tiles_hit;
+    // same membership rule as fast_fill_kernel / map_gaussian_to_intersects; the rasterizer's radius_clip
+    // equals the projection's on this path
+    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
+        int mnx, mny, mxx, mxy;  // the binning box always uses the INT radius (forward.cu:166)
+        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
+    }
+}
+
+// partial-row code of gaussian g in tile (tx, ty): >= 0 gaussian-major row, < 0: -(big row) - 1
+__device__ __forceinline__ int partial_slot(int g, const float2 xy, int rad, int tiles_x, int tiles_y, int tx,
+                                            int ty, int big_row) {
+    int mnx, mny, mxx, mxy;
+    tile_bbox(xy.x, xy.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+    const int w = mxx - mnx, ntiles = w * (mxy - mny);
+    if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + (ty - mny) * w + (tx - mnx);
+    return -big_row - 1;
+}
+
+// -------------------------------------------------------------------------------------- forward
+struct FastFwdLds {
+    FwdLds f;
+    int ids[GI2D_FAST_C];
+    int cnt[GI2D_FAST_SUB];
+};
+
+__global__ __launch_bounds__(256) void fast_fwd_kernel(
+    int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacities, const float *__restrict__ background, int32_t *__restrict__ cursors,
+    const int32_t *__restrict__ buckets, int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins,
+    GaussRec *__restrict__ packed, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
+    int32_t *__restrict__ status, float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
+    float *__restrict__ out_img) {
+    __shared__ FastFwdLds sm;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x;
+    if (tid < GI2D_FAST_SUB) {
+        const int c = cursors[tile * GI2D_FAST_SUB + tid];
+        cursors[tile * GI2D_FAST_SUB + tid] = 0;  // ready for the next call
+        if (c > GI2D_FAST_CSUB) atomicOr(&status[1], 1);
+        sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
+    }
+    if (tid == 0) fwd_stage_dummy(sm.f);
+    __syncthreads();
+    const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
+    if (tid == 0) {
+        tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
+        if (L > 0) atomicAdd(&status[0], L);
+    }
+    // my (up to two) bucket entries
+    int my_id[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        my_id[u] = -1;
+        if (e < L) {
+            const int sub = (e >= c0) + (e >= c1) + (e >= c2);
+            const int off = e - (sub == 0 ? 0 : (sub == 1 ? c0 : (sub == 2 ? c1 : c2)));
+            my_id[u] = buckets[(tile * GI2D_FAST_SUB + sub) * GI2D_FAST_CSUB + off];
+            sm.ids[e] = my_id[u];
+        }
+    }
+    __syncthreads();
+    const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (my_id[u] < 0) continue;
+        const int g = my_id[u];
+        // issue the gathers first; the rank loop below runs under their latency
+        GaussRec r = load_gaussian(g, xys, conics, colors, opacities);
+        const int rad = radii[g];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) rank += (sm.ids[j] < g) ? 1 : 0;
+        gids_sorted[tile * GI2D_FAST_C + rank] = g;
+        const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
+        const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
+        if (rank < GI2D_TILE_LIST_CAP) {
+            const unsigned mask = strip_mask(r, tx0, ty0, img_h);
+            fwd_stage_entry(sm.f, rank, r, mask);
+            float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
+            dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
+            dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
+            dst[2] = make_float4(r.cb, __int_as_float(slot), __int_as_float(g), __int_as_float((int)mask));
+        } else if (slot >= 0) {
+            // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            partial_g[3 * (size_t)slot] = z;
+            partial_g[3 * (size_t)slot + 1] = z;
+            partial_g[3 * (size_t)slot + 2] = z;
+        }
+    }
+    __syncthreads();
+    const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
+    // status[0] (total count) is still being accumulated by other workgroups: "no intersections at all"
+    // cannot be decided here; the host entry runs a 1-block fix-up kernel for that corner case.
+    fwd_rasterize_staged(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background, final_Ts,
+                         final_idx, out_img);
+}
+
+// rasterize_sum_plus.py:110-118: if there is not a single intersection the image is the background.
+__global__ __launch_bounds__(256) void fast_background_kernel(int img_w, int img_h,
+                                                              const int32_t *__restrict__ status,
+                                                              const float *__restrict__ background,
+                                                              float *__restrict__ out_img) {
+    if (status[0] > 0) return;
+    const size_t npix = (size_t)img_w * img_h;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        out_img[3 * p] = background[0];
+        out_img[3 * p + 1] = background[1];
+        out_img[3 * p + 2] = background[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward
+template <bool WITH_ABS>
+__global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_kernel(
+    int tiles_x, int tiles_y, int img_w, int img_h, const int2 *__restrict__ tile_bins,
+    const GaussRec *__restrict__ packed, const int32_t *__restrict__ final_idx,
+    const float *__restrict__ v_output, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big) {
+    __shared__ BwdLds<WITH_ABS> sm;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x;
+    const int2 range = tile_bins[tile];
+    const int full_len = range.y - range.x;
+    if (full_len <= 0) return;
+    const int len = full_len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : full_len;
+    bwd_stage_pixels(sm, tx, ty, img_w, img_h, final_idx, v_output);
+    unsigned mask = 0;
+    int slot = 0;
+    if (tid < len) {
+        const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + tid);
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+        sm.gA[tid] = q0;
+        sm.gB[tid] = q1;
+        sm.gCb[tid] = q2.x;
+        slot = __float_as_int(q2.y);
+        mask = (unsigned)__float_as_int(q2.w);
+    }
+    float acc[BwdLds<WITH_ABS>::PSTR];
+    bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), acc);
+    if (tid < len) {
+        float4 *dst = slot >= 0 ? partial_g + 3 * (size_t)slot : partial_big + 3 * (size_t)(-slot - 1);
+        store_partial_row(dst, acc);
+    }
+}
+
+// --------------------------------------------------------------------------------------- reduce
+// acc[11] <- ordered sum of gaussian g's partial rows.  Must be called by whole waves.
+__device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restrict__ xys,
+                                           const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
+                                           float radius_clip, const int32_t *__restrict__ gids_sorted,
+                                           const int2 *__restrict__ tile_bins, int num_tiles,
+                                           const float4 *__restrict__ partial_g,
+                                           const float4 *__restrict__ partial_big, float (&acc)[11]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) acc[q] = 0.f;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0;
+    bool mapped = false;
+    if (g < n) {
+        const int rad = radii[g];
+        if (rad > 0 && !((float)rad < radius_clip)) {
+            const float2 c = xys[g];
+            tile_bbox(c.x, c.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+            mapped = mxx > mnx && mxy > mny;
+        }
+    }
+    const int ntiles = mapped ? (mxx - mnx) * (mxy - mny) : 0;
+    if (mapped && ntiles <= GI2D_FAST_S) {
+        for (int k = 0; k < ntiles; ++k) add_partial(acc, partial_g, (size_t)g * GI2D_FAST_S + k);
+    } else if (mapped && ntiles <= GI2D_BIG_TILES_F) {
+        for (int i = mny; i < mxy; ++i)
+            for (int j = mnx; j < mxx; ++j) {
+                const int tile = i * tiles_x + j;
+                const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, g);
+                if (pos >= 0)
+                    add_partial(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
+            }
+    }
+    unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F);
+    while (big) {  // a gaussian on > 32 tiles: the whole wave strides over its tiles
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(mnx, src, 64), by0 = __shfl(mny, src, 64);
+        const int bw = __shfl(mxx, src, 64) - bx0, bn = __shfl(ntiles, src, 64);
+        const int bg = __shfl(g, src, 64);
+        float part[11];
+#pragma unroll
+        for (int q = 0; q < 11; ++q) part[q] = 0.f;
+        for (int t = lane; t < bn; t += 64) {
+            const int tile = (by0 + t / bw) * tiles_x + bx0 + t % bw;
+            const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, bg);
+            if (pos >= 0)
+                add_partial(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
+        }
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            float v = part[q];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == src) acc[q] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fast_reduce_kernel(
+    int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
+    float radius_clip, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float2 *__restrict__ v_xy,
+    float *__restrict__ v_conic, float *__restrict__ v_rgb, float *__restrict__ v_opacity,
+    float4 *__restrict__ v_abs_xy) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc[11];
+    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
+               partial_g, partial_big, acc);
+    if (g < n) store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void fast_reduce_project_kernel(
+    int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    int tiles_x, int tiles_y, float radius_clip, const int32_t *__restrict__ gids_sorted,
+    const int2 *__restrict__ tile_bins, const float4 *__restrict__ partial_g,
+    const float4 *__restrict__ partial_big, const float *__restrict__ p0, const float *__restrict__ p1,
+    float img_w, float img_h, float2 *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_rgb,
+    float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy, float *__restrict__ v_cov2d,
+    float2 *__restrict__ v_mean2d, float *__restrict__ v_p0, float *__restrict__ v_p1) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc[11];
+    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
+               partial_g, partial_big, acc);
+    if (g >= n) return;
+    store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
+    ProjGrad r;
+    r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
+    r.v_mean = make_float2(0.f, 0.f);
+    if (radii[g] > 0) {
+        const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
+        const float vc[3] = {acc[2], acc[3], acc[4]};
+        r = project_bwd_one<KIND>(g, p0, p1, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
+    }
+    store_proj_grad(g, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
+}
+
+static int check_ws(const char *what, void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y) {
+    if (n < 0 || tiles_x < 0 || tiles_y < 0) {
+        set_error("fast path: negative size");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if ((long long)tiles_x * tiles_y * GI2D_FAST_C > 0x7fffffffLL || (long long)n * GI2D_FAST_S > 0x7fffffffLL) {
+        set_error("fast path: problem too large for 32-bit slot indices");
+        return GI2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < carve_fast(nullptr, n, tiles_x * tiles_y).bytes) {
+        set_error(what);
+        return GI2D_ERR_WORKSPACE_TOO_SMALL;
+    }
+    return GI2D_OK;
+}
+
+}  // namespace gi2d
+
+using namespace gi2d;
+
+extern "C" {
+
+size_t gi2d_fast_workspace_bytes(int n, int tiles_x, int tiles_y) {
+    return carve_fast(nullptr, n, tiles_x * tiles_y).bytes;
+}
+int gi2d_fast_tile_capacity(void) { return GI2D_FAST_CSUB; }
+
+int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y, gi2d_stream_t st) {
+    int rc = check_ws("fast workspace init: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    const size_t t = (size_t)tiles_x * tiles_y;
+    if (t == 0) return GI2D_OK;
+    hipError_t e = hipMemsetAsync(w.cursors, 0, t * GI2D_FAST_SUB * sizeof(int32_t), (hipStream_t)st);
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        return (int)e;
+    }
+    return GI2D_OK;
+}
+
+int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, int tiles_x, int tiles_y, float radius_clip,
+                  void *ws, size_t ws_bytes, int32_t *status, gi2d_stream_t st) {
+    int rc = check_ws("fast bin: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    if (!status || (n > 0 && (!xys || !radii))) {
+        set_error("fast bin: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    hipLaunchKernelGGL(fast_fill_kernel, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0,
+                       (hipStream_t)st, n, (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.cursors,
+                       w.buckets, status);
+    return check_launch("fast bin");
+}
+
+int gi2d_fast_project_bin(int kind, int n, float clip_coe, const float *means2d, const float *p0,
+                          const float *p1, unsigned h, unsigned w_, int tiles_x, int tiles_y, float radius_clip,
+                          float *xys, float *depths, int32_t *radii, float *conics, int32_t *nth, void *ws,
+                          size_t ws_bytes, int32_t *status, gi2d_stream_t st) {
+    int rc = check_ws("fast project+bin: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    if (kind < 0 || kind > 2 || !status ||
+        (n > 0 && (!means2d || !p0 || !xys || !depths || !radii || !conics || !nth || (kind == 2 && !p1)))) {
+        set_error("fast project+bin: bad argument");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    const dim3 grid((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), block(256);
+#define GI2D_LAUNCH_PF(K)                                                                                       \
+    hipLaunchKernelGGL(fast_project_fill_kernel<K>, grid, block, 0, (hipStream_t)st, n, clip_coe,              \
+                       (const float2 *)means2d, p0, p1, (float)w_, (float)h, tiles_x, tiles_y, radius_clip,    \
+                       (float2 *)xys, depths, radii, conics, nth, w.cursors, w.buckets, status)
+    if (kind == 0)
+        GI2D_LAUNCH_PF(kCholesky);
+    else if (kind == 1)
+        GI2D_LAUNCH_PF(kCovariance);
+    else
+        GI2D_LAUNCH_PF(kScaleRot);
+#undef GI2D_LAUNCH_PF
+    return check_launch("fast project+bin");
+}
+
+int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *xys,
+                                const int32_t *radii, const float *conics, const float *colors,
+                                const float *opac, const float *background, void *ws, size_t ws_bytes,
+                                int32_t *status, float *final_Ts, int32_t *final_idx, float *out_img,
+                                gi2d_stream_t st) {
+    int rc = check_ws("fast rasterize forward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    const long long t = (long long)tiles_x * tiles_y;
+    if (t == 0 || w_ == 0 || h == 0) return GI2D_OK;
+    if ((unsigned)tiles_x * GI2D_TILE < w_ || (unsigned)tiles_y * GI2D_TILE < h) {
+        set_error("fast rasterize forward: tile grid does not cover the image");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (!status || !final_idx || !out_img || (n > 0 && (!xys || !radii || !conics || !colors || !opac))) {
+        set_error("fast rasterize forward: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, (int)t);
+    hipLaunchKernelGGL(fast_fwd_kernel, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
+                       (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, background, w.cursors,
+                       w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.packed, w.partial_g, w.partial_big, status,
+                       final_Ts, final_idx, out_img);
+    if (background)
+        hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
+                           status, background, out_img);
+    return check_launch("fast rasterize forward");
+}
+
+int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h,
+                                       const int32_t *final_idx, const float *v_output, int with_abs, void *ws,
+                                       size_t ws_bytes, gi2d_stream_t st) {
+    int rc = check_ws("fast rasterize backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    const long long t = (long long)tiles_x * tiles_y;
+    if (t == 0) return GI2D_OK;
+    if (!final_idx || !v_output) {
+        set_error("fast rasterize backward: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, (int)t);
+    if (with_abs)
+        hipLaunchKernelGGL(fast_bwd_kernel<true>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x,
+                           tiles_y, (int)w_, (int)h, (const int2 *)w.tile_bins, w.packed, final_idx, v_output,
+                           w.partial_g, w.partial_big);
+    else
+        hipLaunchKernelGGL(fast_bwd_kernel<false>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x,
+                           tiles_y, (int)w_, (int)h, (const int2 *)w.tile_bins, w.packed, final_idx, v_output,
+                           w.partial_g, w.partial_big);
+    return check_launch("fast rasterize backward tiles");
+}
+
+int gi2d_fast_rasterize_backward_reduce(int n, const float *xys, const int32_t *radii, int tiles_x, int tiles_y,
+                                        float radius_clip, void *ws, size_t ws_bytes, float *v_xy, float *v_conic,
+                                        float *v_rgb, float *v_opacity, float *v_abs_xy, gi2d_stream_t st) {
+    int rc = check_ws("fast rasterize backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    if (n == 0) return GI2D_OK;
+    if (!xys || !radii || !v_xy || !v_conic || !v_rgb || !v_opacity) {
+        set_error("fast rasterize backward reduce: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    hipLaunchKernelGGL(fast_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, n,
+                       (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.gids_sorted,
+                       (const int2 *)w.tile_bins, w.partial_g, w.partial_big, (float2 *)v_xy, v_conic, v_rgb,
+                       v_opacity, (float4 *)v_abs_xy);
+    return check_launch("fast rasterize backward reduce");
+}
+
+int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const float *p1, unsigned h, unsigned w_,
+                                      const float *xys, const int32_t *radii, const float *conics, int tiles_x,
+                                      int tiles_y, float radius_clip, void *ws, size_t ws_bytes, float *v_xy,
+                                      float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                      float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
+                                      gi2d_stream_t st) {
+    int rc = check_ws("fast reduce+project backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    if (n == 0) return GI2D_OK;
+    if (kind < 0 || kind > 2 || !p0 || !xys || !radii || !conics || !v_xy || !v_conic || !v_rgb || !v_opacity ||
+        !v_mean2d || !v_p0 || (kind == 2 && (!p1 || !v_p1))) {
+        set_error("fast reduce+project backward: bad argument");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    const dim3 grid((n + 255) / 256), block(256);
+#define GI2D_LAUNCH_RP(K)                                                                                      \
+    hipLaunchKernelGGL(fast_reduce_project_kernel<K>, grid, block, 0, (hipStream_t)st, n, (const float2 *)xys, \
+                       radii, conics, tiles_x, tiles_y, radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, \
+                       w.partial_g, w.partial_big, p0, p1, (float)w_, (float)h, (float2 *)v_xy, v_conic, v_rgb, \
+                       v_opacity, (float4 *)v_abs_xy, v_cov2d, (float2 *)v_mean2d, v_p0, v_p1)
+    if (kind == 0)
+        GI2D_LAUNCH_RP(kCholesky);
+    else if (kind == 1)
+        GI2D_LAUNCH_RP(kCovariance);
+    else
+        GI2D_LAUNCH_RP(kScaleRot);
+#undef GI2D_LAUNCH_RP
+    return check_launch("fast reduce+project backward");
+}
+
+// Views into the workspace for callers that want the binning result itself (tests, debugging).
+int gi2d_fast_workspace_views(void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y,
+                              int32_t **gaussian_ids_sorted, int32_t **tile_bins) {
+    int rc = check_ws("fast workspace views: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    if (gaussian_ids_sorted) *gaussian_ids_sorted = w.gids_sorted;
+    if (tile_bins) *tile_bins = w.tile_bins;
+    return GI2D_OK;
+}
+
+}  // extern "C"

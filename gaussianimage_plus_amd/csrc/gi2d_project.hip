@@ -2,25 +2,9 @@
 // HBM-bound elementwise work: 20 B in / 32 B out per gaussian (fwd), 48 B in / 32 B out (bwd).
 // Unlike the reference (bindings.cu:1347-1356: five torch::zeros memsets + kernel) every
 // output element is written here, culled rows as zeros, so no memset launches are needed.
-#include "gi2d_common.h"
+#include "gi2d_project_core.h"
 
 namespace gi2d {
-
-enum ProjKind { kCholesky = 0, kCovariance = 1, kScaleRot = 2 };
-
-// glm::mat2 product in glm's evaluation order; m = {col0.row0, col0.row1, col1.row0, col1.row1}.
-struct M2 {
-    float v[4];
-};
-__device__ __forceinline__ M2 mul(const M2 &a, const M2 &b) {
-    M2 r;
-    r.v[0] = a.v[0] * b.v[0] + a.v[2] * b.v[1];
-    r.v[1] = a.v[1] * b.v[0] + a.v[3] * b.v[1];
-    r.v[2] = a.v[0] * b.v[2] + a.v[2] * b.v[3];
-    r.v[3] = a.v[1] * b.v[2] + a.v[3] * b.v[3];
-    return r;
-}
-__device__ __forceinline__ M2 tr(const M2 &a) { return M2{{a.v[0], a.v[2], a.v[1], a.v[3]}}; }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
@@ -30,69 +14,14 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     int32_t *__restrict__ radii, float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const float2 m = means2d[idx];
-    float cx, cy, cxx, cxy, cyy;
-    if (KIND == kCholesky) {  // foward2d.cu:41-48
-        cx = 0.5f * img_w * m.x + 0.5f * img_w;
-        cy = 0.5f * img_h * m.y + 0.5f * img_h;
-        const float l11 = p0[3 * idx], l21 = p0[3 * idx + 1], l22 = p0[3 * idx + 2];
-        cxx = l11 * l11;
-        cxy = l11 * l21;
-        cyy = l21 * l21 + l22 * l22;
-    } else if (KIND == kCovariance) {  // foward2d.cu:226-236
-        cx = m.x;
-        cy = m.y;
-        cxx = p0[3 * idx];
-        cxy = p0[3 * idx + 1];
-        cyy = p0[3 * idx + 2];
-    } else {  // foward2d.cu:155-164, helpers.cuh:579-598
-        cx = m.x;
-        cy = m.y;
-        const float rot = p1[idx];
-        const float c = cosf(rot), s = sinf(rot);
-        const M2 R{{c, -s, s, c}};
-        const M2 S{{p0[2 * idx], 0.f, 0.f, p0[2 * idx + 1]}};
-        const M2 M = mul(R, S);
-        const M2 T = mul(M, tr(M));
-        cxx = T.v[0];
-        cxy = T.v[1];
-        cyy = T.v[3];
-    }
-    float2 o_xy = make_float2(0.f, 0.f);
-    float k0 = 0.f, k1 = 0.f, k2 = 0.f;
-    int o_rad = 0, o_hit = 0;
-    float rmaj, rmin;
-    if (cov2d_bounds(cxx, cxy, cyy, clip_coe, k0, k1, k2, rmaj, rmin) && !(rmin < radius_clip)) {
-        o_xy = make_float2(cx, cy);
-        o_rad = cvt_rzi(rmaj);
-        int mnx, mny, mxx, mxy;
-        // scale-rot passes the int radius (foward2d.cu:177), the others radius.x (:60, :277)
-        tile_bbox(cx, cy, KIND == kScaleRot ? (float)o_rad : rmaj, tiles_x, tiles_y, mnx, mny, mxx,
-                  mxy);
-        const int area = (int)((unsigned)(mxx - mnx) * (unsigned)(mxy - mny));
-        if (area > 0) o_hit = area;
-    } else {
-        k0 = k1 = k2 = 0.f;
-    }
-    xys[idx] = o_xy;
+    const ProjOut o = project_one<KIND>(idx, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
+    xys[idx] = o.xy;
     depths[idx] = 0.f;
-    radii[idx] = o_rad;
-    conics[3 * idx] = k0;
-    conics[3 * idx + 1] = k1;
-    conics[3 * idx + 2] = k2;
-    num_tiles_hit[idx] = o_hit;
-}
-
-// helpers.cuh:384-395 cov2d_to_conic_vjp
-__device__ __forceinline__ void conic_vjp(const float *conic, const float *vc, float &g11,
-                                          float &g12, float &g22) {
-    const M2 X{{conic[0], conic[1], conic[1], conic[2]}};
-    const M2 nX{{-conic[0], -conic[1], -conic[1], -conic[2]}};
-    const M2 G{{vc[0], vc[1], vc[1], vc[2]}};
-    const M2 s = mul(mul(nX, G), X);
-    g11 = s.v[0];
-    g12 = s.v[2] + s.v[1];
-    g22 = s.v[3];
+    radii[idx] = o.radius;
+    conics[3 * idx] = o.k0;
+    conics[3 * idx + 1] = o.k1;
+    conics[3 * idx + 2] = o.k2;
+    num_tiles_hit[idx] = o.tiles_hit;
 }
 
 template <int KIND>
@@ -103,51 +32,15 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     float2 *__restrict__ v_mean2d, float *__restrict__ v_p0, float *__restrict__ v_p1) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    float g11 = 0.f, g12 = 0.f, g22 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    float2 vm = make_float2(0.f, 0.f);
+    ProjGrad r;
+    r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
+    r.v_mean = make_float2(0.f, 0.f);
     if (radii[idx] > 0) {
-        conic_vjp(conics + 3 * idx, v_conic + 3 * idx, g11, g12, g22);
-        const float2 vxy = v_xy[idx];
-        if (KIND == kCholesky) {  // backward2d.cu:39-49 (double-counted off-diagonal, on purpose)
-            const float l11 = p0[3 * idx], l21 = p0[3 * idx + 1], l22 = p0[3 * idx + 2];
-            o0 = 2 * l11 * g11 + 2 * g12 * l21;
-            o1 = 2 * l11 * g12 + 2 * l21 * g22;
-            o2 = 2 * l22 * g22;
-            vm = make_float2(vxy.x * (0.5f * img_w), vxy.y * (0.5f * img_h));
-        } else if (KIND == kCovariance) {  // backward2d.cu:194-206
-            o0 = g11;
-            o1 = g12;
-            o2 = g22;
-            vm = vxy;
-        } else {  // backward2d.cu:72-99
-            const float rot = p1[idx];
-            const float c = cosf(rot), s = sinf(rot);
-            const float sx = p0[2 * idx], sy = p0[2 * idx + 1];
-            const M2 R{{c, -s, s, c}}, Rg{{-s, -c, c, -s}}, S{{sx, 0.f, 0.f, sy}};
-            const M2 M = mul(R, S);
-            const M2 A = mul(mul(Rg, S), tr(M));
-            const M2 B = mul(mul(M, tr(S)), tr(Rg));
-            const M2 sgx = mul(mul(R, M2{{2.f * sx, 0.f, 0.f, 0.f}}), tr(R));
-            const M2 sgy = mul(mul(R, M2{{0.f, 0.f, 0.f, 2.f * sy}}), tr(R));
-            o0 = g11 * sgx.v[0] + 2 * g12 * sgx.v[1] + g22 * sgx.v[3];
-            o1 = g11 * sgy.v[0] + 2 * g12 * sgy.v[1] + g22 * sgy.v[3];
-            o2 = g11 * (A.v[0] + B.v[0]) + 2 * g12 * (A.v[1] + B.v[1]) + g22 * (A.v[3] + B.v[3]);
-            vm = vxy;
-        }
+        const float conic[3] = {conics[3 * idx], conics[3 * idx + 1], conics[3 * idx + 2]};
+        const float vc[3] = {v_conic[3 * idx], v_conic[3 * idx + 1], v_conic[3 * idx + 2]};
+        r = project_bwd_one<KIND>(idx, p0, p1, img_w, img_h, conic, v_xy[idx], vc);
     }
-    v_cov2d[3 * idx] = g11;
-    v_cov2d[3 * idx + 1] = g12;
-    v_cov2d[3 * idx + 2] = g22;
-    v_mean2d[idx] = vm;
-    if (KIND == kScaleRot) {
-        v_p0[2 * idx] = o0;
-        v_p0[2 * idx + 1] = o1;
-        v_p1[idx] = o2;
-    } else {
-        v_p0[3 * idx] = o0;
-        v_p0[3 * idx + 1] = o1;
-        v_p0[3 * idx + 2] = o2;
-    }
+    store_proj_grad(idx, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
 }
 
 // bindings.cu:21-39 compute_cov2d_bounds_kernel (zeros where the reference leaves garbage).

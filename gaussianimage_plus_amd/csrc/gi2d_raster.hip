@@ -23,19 +23,11 @@
 // Roofline: algorithmic HBM bytes are 40*M + 20*H*W (fwd) and 40*M + 16*H*W + 36*N (bwd)
 // (SURVEY 8d); every staged gaussian is reused by up to 256 pixels, so the kernels are bound by
 // VALU issue (v_exp_f32 + ~25 fp32 ops per pixel-gaussian pair), not by HBM.
-#include "gi2d_common.h"
+#include "gi2d_raster_core.h"
 
 namespace gi2d {
 
-#define GI2D_ALPHA_MIN (1.f / 255.f)
-
 // ------------------------------------------------------------------------------------ forward
-struct FwdWaveLds {
-    float4 A[GI2D_TILE_LIST_CAP];  // gx, gy, ha, hb
-    float4 B[GI2D_TILE_LIST_CAP];  // hc, opac, cr, cg
-    float2 C[GI2D_TILE_LIST_CAP];  // cb, list position k (as int bits)
-};
-
 __global__ __launch_bounds__(256) void raster_fwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, const int32_t *__restrict__ gids_sorted,
     const int2 *__restrict__ tile_bins, int tile_bins_rows, const float2 *__restrict__ xys,
@@ -43,149 +35,44 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     const float *__restrict__ opacities, const float *__restrict__ background,
     const int32_t *__restrict__ num_intersects_dev, float *__restrict__ final_Ts,
     int32_t *__restrict__ final_idx, float *__restrict__ out_img) {
-    __shared__ FwdWaveLds lds[4];
+    __shared__ FwdLds sm;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    FwdWaveLds &my = lds[wv];
-    const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
-    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
-    const bool inside = (i < img_h) && (j < img_w);
+    const int tid = threadIdx.x;
 
     int2 range = make_int2(0, 0);
     if (tile < tile_bins_rows) range = tile_bins[tile];
     int len = range.y - range.x;
     len = len < 0 ? 0 : (len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : len);  // forward.cu:553
 
-    // strip of this wave, in pixel coordinates (inclusive)
-    const float sy0 = (float)(ty * GI2D_TILE + wv * 4), sy1 = sy0 + 3.f;
-    const float sx0 = (float)(tx * GI2D_TILE), sx1 = sx0 + 15.f;
-
-    int cnt = 0;
-    for (int base = 0; base < len; base += 64) {
-        const int k = base + lane;
-        bool take = false;
-        float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A;
-        float2 C = make_float2(0.f, 0.f);
-        if (k < len) {
-            const int g = gids_sorted[range.x + k];
-            const float2 xy = xys[g];
-            const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
-            const float opac = opacities[g];
-            CullBox box;
-            const bool can = cull_box(xy.x, xy.y, a, b, c, opac, box);
-            take = can && (box.y1 >= sy0) && (box.y0 <= sy1) && (box.x1 >= sx0) && (box.x0 <= sx1);
-            if (take) {
-                const ConicS s = scale_conic(a, b, c);
-                A = make_float4(xy.x, xy.y, s.ha, s.hb);
-                B = make_float4(s.hc, opac, colors[3 * g], colors[3 * g + 1]);
-                C = make_float2(colors[3 * g + 2], __int_as_float(k));
-            }
-        }
-        const unsigned long long m = __ballot(take);
-        if (take) {
-            const int pos = cnt + __popcll(m & lanemask_lt());
-            my.A[pos] = A;
-            my.B[pos] = B;
-            my.C[pos] = C;
-        }
-        cnt += __popcll(m);
+    // phase 1: the workgroup stages the tile list once, one gaussian per lane (a single round of
+    // dependent global loads), and records which 4-row strips each gaussian can reach
+    if (tid < len) {
+        const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
+        fwd_stage_entry(sm, tid, r, strip_mask(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h));
     }
-    __builtin_amdgcn_wave_barrier();  // wave-private LDS: DS ops of one wave complete in order
-
-    const float px = (float)j, py = (float)i;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    int last_k = -1;
-    for (int t = 0; t < cnt; ++t) {
-        const float4 A = my.A[t];
-        const float4 B = my.B[t];
-        const float2 C = my.C[t];
-        ConicS s;
-        s.ha = A.z;
-        s.hb = A.w;
-        s.hc = B.x;
-        const float dx = A.x - px, dy = A.y - py;
-        const float sig = pair_sigma(s, dx, row_term_b(s, dy), row_term_c(s, dy));
-        const float vis = pair_vis(sig);
-        const float alpha = fminf(1.f, B.y * vis);
-        const bool ok = !(sig < 0.f || alpha < GI2D_ALPHA_MIN);  // forward.cu:541
-        const float am = ok ? alpha : 0.f;
-        o0 = __builtin_fmaf(B.z, am, o0);
-        o1 = __builtin_fmaf(B.w, am, o1);
-        o2 = __builtin_fmaf(C.x, am, o2);
-        last_k = ok ? __float_as_int(C.y) : last_k;
-    }
-    int cur_idx = last_k < 0 ? 0 : range.x + last_k;  // forward.cu:497,550: 0 when nothing landed
-
-    if (num_intersects_dev != nullptr && *num_intersects_dev < 1) {
-        // rasterize_sum_plus.py:110-118: no intersections at all -> image = background
-        o0 = background[0];
-        o1 = background[1];
-        o2 = background[2];
-        cur_idx = 0;
-    }
-
-    const int pix = i * img_w + j;
-    if (inside) {
-        final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
-        final_idx[pix] = cur_idx;
-    }
-    // RGB: transpose through the wave's LDS so a 16-pixel row leaves as 12 x 16-byte stores.
-    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
-    if (full_tile) {
-        float *stage = reinterpret_cast<float *>(my.A);  // 4 rows x 48 floats, wave-private
-        __builtin_amdgcn_wave_barrier();
-        const int r = lane >> 4;
-        stage[r * 48 + lx * 3 + 0] = o0;
-        stage[r * 48 + lx * 3 + 1] = o1;
-        stage[r * 48 + lx * 3 + 2] = o2;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 48) {
-            const int rr = lane / 12, q = lane % 12;
-            const int ii = ty * GI2D_TILE + wv * 4 + rr;
-            if (ii < img_h) {
-                const float4 v = reinterpret_cast<const float4 *>(stage)[rr * 12 + q];
-                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
-                dst[q] = v;
-            }
-        }
-    } else if (inside) {
-        out_img[3 * (size_t)pix + 0] = o0;
-        out_img[3 * (size_t)pix + 1] = o1;
-        out_img[3 * (size_t)pix + 2] = o2;
-    }
+    if (tid == 0) fwd_stage_dummy(sm);
+    __syncthreads();
+    const bool bg = (num_intersects_dev != nullptr) && (*num_intersects_dev < 1);
+    fwd_rasterize_staged(sm, len, range.x, tx, ty, img_w, img_h, bg, background, final_Ts, final_idx, out_img);
 }
 
 // ----------------------------------------------------------------------------------- backward
-#define GI2D_BWD_ROUND 512   /* (gaussian,row) items processed between two LDS reductions */
-#define GI2D_PART_STRIDE 11  /* floats per row partial (9 grads + 2 |v_xy|); odd -> conflict-free */
-
-struct BwdLds {
-    float4 pix[GI2D_TILE * (GI2D_TILE + 1)];  // (v_out.rgb, final_idx bits), rows padded to 17
-    float4 gA[GI2D_TILE_LIST_CAP];            // gx, gy, ha, hb
-    float4 gB[GI2D_TILE_LIST_CAP];            // hc, opac, a, b
-    float4 gC[GI2D_TILE_LIST_CAP];            // c, cr, cg, cb
-    int off[GI2D_TILE_LIST_CAP + 1];          // exclusive prefix of rows per gaussian
-    unsigned short item[GI2D_TILE_LIST_CAP * GI2D_TILE];  // k | row << 8
-    float part[GI2D_BWD_ROUND * GI2D_PART_STRIDE];
-    int wsum[4];
-};
-
 template <bool WITH_ABS>
-__global__ __launch_bounds__(256) void raster_bwd_kernel(
+__global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void raster_bwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, const int32_t *__restrict__ gids_sorted,
     const int2 *__restrict__ tile_bins, int tile_bins_rows, const float2 *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacities, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_output, float4 *__restrict__ partials) {
-    __shared__ BwdLds sm;
+    __shared__ BwdLds<WITH_ABS> sm;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
 
     int2 range = make_int2(0, 0);
     if (tile < tile_bins_rows) range = tile_bins[tile];
-    int full_len = range.y - range.x;
+    const int full_len = range.y - range.x;
     if (full_len <= 0) return;
     const int len = full_len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : full_len;
     // entries beyond the forward cap never contributed (idx > final_idx everywhere)
@@ -195,175 +82,17 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(
         partials[3 * (size_t)(range.x + k) + 1] = z;
         partials[3 * (size_t)(range.x + k) + 2] = z;
     }
-
-    // stage the tile's pixels: v_out and final_idx (-1 outside the image: never valid)
-    {
-        const int lx = tid & 15, ly = tid >> 4;
-        const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
-        float4 p = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (i < img_h && j < img_w) {
-            const size_t pix = (size_t)i * img_w + j;
-            p = make_float4(v_output[3 * pix], v_output[3 * pix + 1], v_output[3 * pix + 2],
-                            __int_as_float(final_idx[pix]));
-        }
-        sm.pix[ly * (GI2D_TILE + 1) + lx] = p;
-    }
-
-    // stage gaussian tid and find the rows it can reach
+    bwd_stage_pixels(sm, tx, ty, img_w, img_h, final_idx, v_output);
     const float ty0 = (float)(ty * GI2D_TILE), tx0 = (float)(tx * GI2D_TILE);
-    int r0 = 0, nrows = 0;
+    unsigned mask = 0;
     if (tid < len) {
-        const int g = gids_sorted[range.x + tid];
-        const float2 xy = xys[g];
-        const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
-        const float opac = opacities[g];
-        const ConicS s = scale_conic(a, b, c);
-        sm.gA[tid] = make_float4(xy.x, xy.y, s.ha, s.hb);
-        sm.gB[tid] = make_float4(s.hc, opac, a, b);
-        sm.gC[tid] = make_float4(c, colors[3 * g], colors[3 * g + 1], colors[3 * g + 2]);
-        CullBox box;
-        if (cull_box(xy.x, xy.y, a, b, c, opac, box) && box.x1 >= tx0 && box.x0 <= tx0 + 15.f) {
-            const float lo = fmaxf(ceilf(box.y0 - ty0), 0.f);
-            const float hi = fminf(floorf(box.y1 - ty0), fminf(15.f, (float)(img_h - 1) - ty0));
-            if (hi >= lo) {
-                r0 = (int)lo;
-                nrows = (int)hi - r0 + 1;
-            }
-        }
+        const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
+        bwd_stage_entry(sm, tid, r);
+        mask = strip_mask(r, tx0, ty0, img_h);
     }
-    // exclusive scan of nrows over the workgroup
-    {
-        const int incl = wave_inclusive_scan(nrows);
-        if (lane == 63) sm.wsum[wv] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < wv; ++k) base += sm.wsum[k];
-        const int excl = base + incl - nrows;
-        if (tid < len) sm.off[tid] = excl;
-        if (tid == 255) sm.off[len] = excl + nrows;  // lanes >= len carry nrows = 0
-        for (int r = 0; r < nrows; ++r) sm.item[excl + r] = (unsigned short)(tid | ((r0 + r) << 8));
-    }
-    __syncthreads();
-    const int n_items = sm.off[len];
-    const int my_lo = tid < len ? sm.off[tid] : 0;
-    const int my_hi = tid < len ? sm.off[tid + 1] : 0;
-
-    constexpr int NACC = WITH_ABS ? 11 : 9;
-    float acc[NACC];
-#pragma unroll
-    for (int q = 0; q < NACC; ++q) acc[q] = 0.f;
-
-    for (int round0 = 0; round0 < n_items; round0 += GI2D_BWD_ROUND) {
-        const int round1 = min(n_items, round0 + GI2D_BWD_ROUND);
-        for (int it = round0 + tid; it < round1; it += 256) {
-            const unsigned short code = sm.item[it];
-            const int k = code & 255, row = code >> 8;
-            const float4 A = sm.gA[k], B = sm.gB[k], C = sm.gC[k];
-            ConicS s;
-            s.ha = A.z;
-            s.hb = A.w;
-            s.hc = B.x;
-            const float opac = B.y;
-            const int idx = range.x + k;
-            const float py = ty0 + (float)row;
-            const float dy = A.y - py;
-            const float bdy = row_term_b(s, dy), cdy2 = row_term_c(s, dy);
-            float S0 = 0.f, S1 = 0.f, S2 = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gop = 0.f;
-            float ax = 0.f, ay = 0.f;
-            const float a_ = B.z, b_ = B.w, c_ = C.x;
-            const float bdy_u = b_ * dy, cdy_u = c_ * dy;
-            const float4 *prow = &sm.pix[row * (GI2D_TILE + 1)];
-#pragma unroll 4
-            for (int x = 0; x < GI2D_TILE; ++x) {
-                const float4 p = prow[x];
-                const float dx = A.x - (tx0 + (float)x);
-                const float sig = pair_sigma(s, dx, bdy, cdy2);
-                const float vis = pair_vis(sig);
-                const float alpha = fminf(1.f, opac * vis);
-                const bool ok = (idx <= __float_as_int(p.w)) &&  // backward.cu:903
-                                !(sig < 0.f || alpha < GI2D_ALPHA_MIN);  // backward.cu:925
-                // backward.cu:940-961
-                const float v_alpha =
-                    __builtin_fmaf(C.w, p.z, __builtin_fmaf(C.z, p.y, C.y * p.x));
-                const float am = ok ? alpha : 0.f;
-                gr = __builtin_fmaf(am, p.x, gr);
-                gg = __builtin_fmaf(am, p.y, gg);
-                gb = __builtin_fmaf(am, p.z, gb);
-                const float vva = vis * v_alpha;
-                const float vop = ok ? vva : 0.f;
-                gop += vop;
-                const float vs = -opac * vop;  // v_sigma = -opac * vis * v_alpha
-                S0 += vs;
-                const float vsdx = vs * dx;
-                S1 += vsdx;
-                S2 = __builtin_fmaf(vsdx, dx, S2);
-                if (WITH_ABS) {  // backward.cu:959-960 (commented in the shipped kernel): sum |v_xy|
-                    ax += fabsf(vs * __builtin_fmaf(a_, dx, bdy_u));
-                    ay += fabsf(vs * __builtin_fmaf(b_, dx, cdy_u));
-                }
-            }
-            const float a = a_, b = b_, c = c_;
-            float *out = &sm.part[(it - round0) * GI2D_PART_STRIDE];
-            const float dyS0 = dy * S0;
-            out[0] = __builtin_fmaf(a, S1, b * dyS0);   // sum v_sigma*(a dx + b dy)
-            out[1] = __builtin_fmaf(b, S1, c * dyS0);   // sum v_sigma*(b dx + c dy)
-            out[2] = 0.5f * S2;                         // sum 0.5 v_sigma dx dx
-            out[3] = 0.5f * dy * S1;                    // sum 0.5 v_sigma dx dy
-            out[4] = 0.5f * dy * dyS0;                  // sum 0.5 v_sigma dy dy
-            out[5] = gr;
-            out[6] = gg;
-            out[7] = gb;
-            out[8] = gop;
-            if (WITH_ABS) {
-                out[9] = ax;
-                out[10] = ay;
-            }
-        }
-        __syncthreads();
-        // the lane that owns gaussian `tid` adds its row partials of this round, in row order
-        const int lo = max(my_lo, round0), hi = min(my_hi, round1);
-        for (int it = lo; it < hi; ++it) {
-            const float *in = &sm.part[(it - round0) * GI2D_PART_STRIDE];
-#pragma unroll
-            for (int q = 0; q < NACC; ++q) acc[q] += in[q];
-        }
-        __syncthreads();
-    }
-    if (tid < len) {
-        float4 *dst = partials + 3 * (size_t)(range.x + tid);
-        dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        dst[2] = make_float4(acc[8], WITH_ABS ? acc[NACC - 2] : 0.f, WITH_ABS ? acc[NACC - 1] : 0.f, 0.f);
-    }
-}
-
-__device__ __forceinline__ void add_partial(float acc[11], const float4 *__restrict__ partials,
-                                            int pos) {
-    const float4 p0 = partials[3 * (size_t)pos], p1 = partials[3 * (size_t)pos + 1],
-                 p2 = partials[3 * (size_t)pos + 2];
-    acc[0] += p0.x;
-    acc[1] += p0.y;
-    acc[2] += p0.z;
-    acc[3] += p0.w;
-    acc[4] += p1.x;
-    acc[5] += p1.y;
-    acc[6] += p1.z;
-    acc[7] += p1.w;
-    acc[8] += p2.x;
-    acc[9] += p2.y;
-    acc[10] += p2.z;
-}
-__device__ __forceinline__ void store_grads(int g, const float acc[11], float2 *v_xy, float *v_conic,
-                                            float *v_rgb, float *v_opacity, float4 *v_abs_xy) {
-    if (v_abs_xy) v_abs_xy[g] = make_float4(acc[0], acc[1], acc[9], acc[10]);
-    v_xy[g] = make_float2(acc[0], acc[1]);
-    v_conic[3 * g] = acc[2];
-    v_conic[3 * g + 1] = acc[3];
-    v_conic[3 * g + 2] = acc[4];
-    v_rgb[3 * g] = acc[5];
-    v_rgb[3 * g + 1] = acc[6];
-    v_rgb[3 * g + 2] = acc[7];
-    v_opacity[g] = acc[8];
+    float acc[BwdLds<WITH_ABS>::PSTR];
+    bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, tx0, ty0, acc);
+    if (tid < len) store_partial_row(partials + 3 * (size_t)(range.x + tid), acc);
 }
 
 // Plan form: gaussian g owns input positions [cum[g-1], cum[g]) (ascending tile id);
@@ -397,23 +126,6 @@ __global__ __launch_bounds__(256) void gather_plan_kernel(int n, int m,
 // cover more than GI2D_BIG_TILES tiles are handled by the whole wave (lanes stride over the tiles, fixed
 // butterfly reduction) so one huge gaussian does not serialise a lane.
 #define GI2D_BIG_TILES 32
-__device__ __forceinline__ int find_in_tile(const int32_t *__restrict__ gids_sorted,
-                                            const int2 *__restrict__ tile_bins, int tile, int rows, int g) {
-    if (tile >= rows) return -1;
-    const int2 r = tile_bins[tile];
-    int lo = r.x, hi = min(r.y, r.x + GI2D_TILE_LIST_CAP);  // entries past the cap carry no gradient
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const int v = gids_sorted[mid];
-        if (v == g) return mid;
-        if (v < g)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return -1;
-}
-
 __global__ __launch_bounds__(256) void gather_bbox_kernel(
     int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
     float radius_clip, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins, int rows,

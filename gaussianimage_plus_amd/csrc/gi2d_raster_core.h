@@ -1,0 +1,430 @@
+// Device-side core of the additive tile rasterizer, shared by the reference-shaped ops
+// (gi2d_raster.hip) and the fused fast path (gi2d_fast.hip).  See gi2d_raster.hip for the design notes.
+#pragma once
+#include "gi2d_common.h"
+
+namespace gi2d {
+
+#define GI2D_ALPHA_MIN (1.f / 255.f)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// One gaussian as the rasterizer consumes it (48 bytes): the "packed record" of the fast path.
+struct GaussRec {
+    float gx, gy, a, b;      // centre (pixels), conic a, b
+    float c, opac, cr, cg;   // conic c, opacity, colour r, g
+    float cb;                // colour b
+    int slot;                // fast path: row of the gaussian-major partial buffer (-1: none)
+    int gid;                 // gaussian id
+    int pad;
+};
+static_assert(sizeof(GaussRec) == 48, "GaussRec must be 3 x float4");
+
+__device__ __forceinline__ GaussRec load_gaussian(int g, const float2 *__restrict__ xys,
+                                                  const float *__restrict__ conics,
+                                                  const float *__restrict__ colors,
+                                                  const float *__restrict__ opacities) {
+    GaussRec r;
+    const float2 xy = xys[g];
+    r.gx = xy.x;
+    r.gy = xy.y;
+    r.a = conics[3 * g];
+    r.b = conics[3 * g + 1];
+    r.c = conics[3 * g + 2];
+    r.opac = opacities[g];
+    r.cr = colors[3 * g];
+    r.cg = colors[3 * g + 1];
+    r.cb = colors[3 * g + 2];
+    r.slot = -1;
+    r.gid = g;
+    r.pad = 0;
+    return r;
+}
+
+// Which of the tile's four 4-row strips can the gaussian reach with alpha >= 1/255?
+__device__ __forceinline__ unsigned strip_mask(const GaussRec &r, float tx0, float ty0, int img_h) {
+    CullBox box;
+    unsigned mask = 0;
+    if (cull_box(r.gx, r.gy, r.a, r.b, r.c, r.opac, box) && box.x1 >= tx0 && box.x0 <= tx0 + 15.f) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float y0 = ty0 + 4.f * s4;
+            mask |= (box.y1 >= y0 && box.y0 <= y0 + 3.f && y0 < (float)img_h) ? (1u << s4) : 0u;
+        }
+    }
+    return mask;
+}
+
+// =========================================================================================== forward
+#define GI2D_FWD_DUMMY GI2D_TILE_LIST_CAP /* index of a never-contributing entry used as list padding */
+struct FwdLds {
+    float4 AB[2 * (GI2D_TILE_LIST_CAP + 1)];  // [k]: (gx, gy, ha, hb), (hc, opac, cr, cg)
+    float C[GI2D_TILE_LIST_CAP + 4];          // cb
+    unsigned char strips[GI2D_TILE_LIST_CAP]; // bit w: the gaussian can reach pixel rows 4w..4w+3
+    unsigned short list[4][GI2D_TILE_LIST_CAP + 8];  // per-wave ascending indices, padded to x4
+    float stage[4][4 * 48];                   // per-wave RGB transpose buffer
+};
+
+// phase 1 helper: lane `k` publishes its gaussian (list position k of the tile)
+__device__ __forceinline__ void fwd_stage_entry(FwdLds &sm, int k, const GaussRec &r, unsigned mask) {
+    const ConicS s = scale_conic(r.a, r.b, r.c);
+    sm.AB[2 * k] = make_float4(r.gx, r.gy, s.ha, s.hb);
+    sm.AB[2 * k + 1] = make_float4(s.hc, r.opac, r.cr, r.cg);
+    sm.C[k] = r.cb;
+    sm.strips[k] = (unsigned char)mask;
+}
+__device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
+    // padding entry: opacity 0 -> alpha = 0 < 1/255, never contributes
+    sm.AB[2 * GI2D_FWD_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sm.AB[2 * GI2D_FWD_DUMMY + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sm.C[GI2D_FWD_DUMMY] = 0.f;
+}
+
+// phases 2-4 of the forward for one tile whose `len` (<= 256) entries are staged in ascending order.
+// Must be called by all 256 lanes after a __syncthreads() that follows the staging.
+__device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int list_base, int tx, int ty,
+                                                     int img_w, int img_h, bool background_fill,
+                                                     const float *__restrict__ background,
+                                                     float *__restrict__ final_Ts,
+                                                     int32_t *__restrict__ final_idx,
+                                                     float *__restrict__ out_img) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
+    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
+    const bool inside = (i < img_h) && (j < img_w);
+
+    // phase 2: each wave compacts the indices of the gaussians that reach its strip (ascending)
+    unsigned short *mylist = sm.list[wv];
+    int cnt = 0;
+    for (int base = 0; base < len; base += 64) {
+        const int k = base + lane;
+        const bool take = (k < len) && ((sm.strips[k] >> wv) & 1);
+        const unsigned long long m = __ballot(take);
+        if (take) mylist[cnt + __popcll(m & lanemask_lt())] = (unsigned short)k;
+        cnt += __popcll(m);
+    }
+    if (lane < 4) mylist[cnt + lane] = (unsigned short)GI2D_FWD_DUMMY;
+    __builtin_amdgcn_wave_barrier();  // wave-private list: DS ops of one wave complete in order
+
+    // phase 3: one pixel per lane, four list entries per trip (indices are wave-uniform -> scalar)
+    const float px = (float)j, py = (float)i;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    int last_k = -1;
+#ifdef GI2D_ABLATE_FWD_COMPUTE
+    if (len < 0)  // timing experiment: skip the pixel loop
+#endif
+    for (int t = 0; t < cnt; t += 4) {
+        const uint2 packed = *reinterpret_cast<const uint2 *>(mylist + t);
+        const unsigned p0 = __builtin_amdgcn_readfirstlane(packed.x);
+        const unsigned p1 = __builtin_amdgcn_readfirstlane(packed.y);
+        const int ks[4] = {(int)(p0 & 0xffffu), (int)(p0 >> 16), (int)(p1 & 0xffffu), (int)(p1 >> 16)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = ks[u];
+            const float4 A = sm.AB[2 * k];
+            const float4 B = sm.AB[2 * k + 1];
+            const float cb = sm.C[k];
+            ConicS s;
+            s.ha = A.z;
+            s.hb = A.w;
+            s.hc = B.x;
+            const float dx = A.x - px, dy = A.y - py;
+            const float sig = pair_sigma(s, dx, row_term_b(s, dy), row_term_c(s, dy));
+            const float vis = pair_vis(sig);
+            const float alpha = fminf(1.f, B.y * vis);
+            const bool ok = !(sig < 0.f || alpha < GI2D_ALPHA_MIN);  // forward.cu:541
+            const float am = ok ? alpha : 0.f;
+            o0 = __builtin_fmaf(B.z, am, o0);
+            o1 = __builtin_fmaf(B.w, am, o1);
+            o2 = __builtin_fmaf(cb, am, o2);
+            last_k = ok ? k : last_k;
+        }
+    }
+    int cur_idx = last_k < 0 ? 0 : list_base + last_k;  // forward.cu:497,550: 0 when nothing landed
+    if (background_fill) {
+        // rasterize_sum_plus.py:110-118: no intersections at all -> image = background
+        o0 = background[0];
+        o1 = background[1];
+        o2 = background[2];
+        cur_idx = 0;
+    }
+
+    const int pix = i * img_w + j;
+    if (inside) {
+        if (final_Ts) final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
+        final_idx[pix] = cur_idx;
+    }
+    // phase 4: transpose RGB through the wave's LDS so a 16-pixel row leaves as 12 x 16-byte stores
+    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
+    if (full_tile) {
+        float *stage = sm.stage[wv];  // 4 rows x 48 floats, wave-private
+        const int r = lane >> 4;
+        stage[r * 48 + lx * 3 + 0] = o0;
+        stage[r * 48 + lx * 3 + 1] = o1;
+        stage[r * 48 + lx * 3 + 2] = o2;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 48) {
+            const int rr = lane / 12, q = lane % 12;
+            const int ii = ty * GI2D_TILE + wv * 4 + rr;
+            if (ii < img_h) {
+                const float4 v = reinterpret_cast<const float4 *>(stage)[rr * 12 + q];
+                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
+                dst[q] = v;
+            }
+        }
+    } else if (inside) {
+        out_img[3 * (size_t)pix + 0] = o0;
+        out_img[3 * (size_t)pix + 1] = o1;
+        out_img[3 * (size_t)pix + 2] = o2;
+    }
+}
+
+// ========================================================================================== backward
+// Work item = (gaussian k, 4-row strip s) for the strips the gaussian's alpha>=1/255 box reaches: one
+// lane walks the strip's 4 x 16 pixels two at a time with packed fp32 (v_pk_fma_f32 & co), keeping
+// every running sum in registers.  Per row the conic/xy gradients follow from three sums
+//   S0 = sum w, S1 = sum w dx, S2 = sum w dx^2,  w = opac*vis*v_alpha = -v_sigma  (backward.cu:948)
+// because dy is constant along a row.  A gaussian owns at most 4 items, so the hand-off to the lane
+// that owns the gaussian is at most 4 LDS rows.
+#define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
+#ifndef GI2D_BWD_OCC
+#define GI2D_BWD_OCC 6 /* waves per SIMD the register allocator must leave room for (6 workgroups/CU) */
+#endif
+#ifndef GI2D_BWD_UNROLL
+#define GI2D_BWD_UNROLL 1 /* pixel pairs per trip; 2 needs > 80 VGPRs and costs the sixth workgroup */
+#endif
+
+template <bool WITH_ABS>
+struct BwdLds {
+    static constexpr int PSTR = WITH_ABS ? 11 : 9;  // odd: conflict-free hand-off rows
+    // per pixel row: 8 pairs x {(vox0,vox1,voy0,voy1), (voz0,voz1,fidx0,fidx1)} + one float4 of padding
+    float4 pix[GI2D_TILE * (GI2D_TILE + 1)];
+    float4 gA[GI2D_TILE_LIST_CAP];  // gx, gy, a, b
+    float4 gB[GI2D_TILE_LIST_CAP];  // c, opac, cr, cg
+    float gCb[GI2D_TILE_LIST_CAP];  // cb
+    unsigned short off[GI2D_TILE_LIST_CAP + 2];     // exclusive prefix of items per gaussian
+    unsigned short item[4 * GI2D_TILE_LIST_CAP];    // k | strip << 8
+    float part[GI2D_BWD_ITEMS * PSTR];
+    int wsum[4];
+};
+
+// lane (lx, ly) publishes pixel (v_out, final_idx) in pair-major order; -1 outside the image
+template <bool WITH_ABS>
+__device__ __forceinline__ void bwd_stage_pixels(BwdLds<WITH_ABS> &sm, int tx, int ty, int img_w, int img_h,
+                                                 const int32_t *__restrict__ final_idx,
+                                                 const float *__restrict__ v_output) {
+    const int tid = threadIdx.x;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
+    float vx = 0.f, vy = 0.f, vz = 0.f, fi = __int_as_float(-1);
+    if (i < img_h && j < img_w) {
+        const size_t pix = (size_t)i * img_w + j;
+        vx = v_output[3 * pix];
+        vy = v_output[3 * pix + 1];
+        vz = v_output[3 * pix + 2];
+        fi = __int_as_float(final_idx[pix]);
+    }
+    float *row = reinterpret_cast<float *>(&sm.pix[ly * (GI2D_TILE + 1)]) + (lx >> 1) * 8 + (lx & 1);
+    row[0] = vx;
+    row[2] = vy;
+    row[4] = vz;
+    row[6] = fi;
+}
+
+template <bool WITH_ABS>
+__device__ __forceinline__ void bwd_stage_entry(BwdLds<WITH_ABS> &sm, int k, const GaussRec &r) {
+    sm.gA[k] = make_float4(r.gx, r.gy, r.a, r.b);
+    sm.gB[k] = make_float4(r.c, r.opac, r.cr, r.cg);
+    sm.gCb[k] = r.cb;
+}
+
+// After pixels and the first `len` gaussians are staged (no barrier needed before the call): builds the
+// item list from each lane's strip mask, runs the items, and leaves in acc[] (lanes tid < len) the
+// gradient partial of gaussian `tid` for this tile:
+//   acc = (v_x, v_y, v_conic[3], v_rgb[3], v_opacity [, sum|v_x|, sum|v_y|]).
+// `list_base` + k is the entry's position in the sorted list (compared with final_idx, backward.cu:903).
+template <bool WITH_ABS>
+__device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsigned mask, int list_base,
+                                             float tx0, float ty0, float (&acc)[BwdLds<WITH_ABS>::PSTR]) {
+    constexpr int PSTR = BwdLds<WITH_ABS>::PSTR;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        const int nitems = __popc(mask);
+        const int incl = wave_inclusive_scan(nitems);
+        if (lane == 63) sm.wsum[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wv; ++k) base += sm.wsum[k];
+        int excl = base + incl - nitems;
+        if (tid < len) sm.off[tid] = (unsigned short)excl;
+        if (tid == 255) sm.off[len] = (unsigned short)(excl + nitems);  // lanes >= len carry 0 items
+        unsigned m = mask;
+        while (m) {
+            const int s4 = __ffs(m) - 1;
+            m &= m - 1;
+            sm.item[excl++] = (unsigned short)(tid | (s4 << 8));
+        }
+    }
+    __syncthreads();
+    const int n_items = sm.off[len];
+    const int my_lo = tid < len ? sm.off[tid] : 0;
+    const int my_hi = tid < len ? sm.off[tid + 1] : 0;
+#pragma unroll
+    for (int q = 0; q < PSTR; ++q) acc[q] = 0.f;
+
+    // pixel x coordinates of a row's first pair, exactly as the forward forms them: (float)j
+    // (small integers: stepping by 2.0 stays exact)
+    const v2f px_first = {tx0, tx0 + 1.f};
+
+    for (int round0 = 0; round0 < n_items; round0 += GI2D_BWD_ITEMS) {
+        const int round1 = min(n_items, round0 + GI2D_BWD_ITEMS);
+        const int it = round0 + tid;
+        if (it < round1) {
+            const unsigned code = sm.item[it];
+            const int k = code & 255, s4 = code >> 8;
+            const float4 A = sm.gA[k], B = sm.gB[k];
+            const float cb = sm.gCb[k];
+            const float gx = A.x, gy = A.y, a = A.z, b = A.w, c = B.x, opac = B.y;
+            const ConicS s = scale_conic(a, b, c);
+            const v2f ha2 = {s.ha, s.ha}, gx2 = {gx, gx}, opac2 = {opac, opac};
+            const v2f cr2 = {B.z, B.z}, cg2 = {B.w, B.w}, cb2 = {cb, cb};
+            const int idx = list_base + k;
+            float vx = 0.f, vy = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, gop = 0.f;
+            v2f gr = {0.f, 0.f}, gg = {0.f, 0.f}, gb = {0.f, 0.f}, ax = {0.f, 0.f}, ay = {0.f, 0.f};
+#ifdef GI2D_ABLATE_BWD_COMPUTE
+            const int rows_to_do = (n_items < 0) ? 4 : 0;  // timing experiment: skip the pixel loop
+#else
+            const int rows_to_do = 4;
+#endif
+#pragma unroll 1
+            for (int r = 0; r < rows_to_do; ++r) {
+                const int row = 4 * s4 + r;
+                const float dy = gy - (ty0 + (float)row);
+                const float bdy = row_term_b(s, dy), cdy2 = row_term_c(s, dy);
+                const v2f bdy2 = {bdy, bdy}, cdy22 = {cdy2, cdy2};
+                const float bdy_u = b * dy, cdy_u = c * dy;
+                v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
+                const float4 *prow = &sm.pix[row * (GI2D_TILE + 1)];
+                v2f px = px_first;
+#pragma unroll GI2D_BWD_UNROLL
+                for (int q = 0; q < 8; ++q) {
+                    const float4 P0 = prow[2 * q], P1 = prow[2 * q + 1];
+                    const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
+                    const v2f dx = gx2 - px;
+                    px += (v2f){2.f, 2.f};
+                    // == pair_sigma() of the forward, two pixels per instruction
+                    const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha2, dx, bdy2), cdy22);
+                    const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+                    const v2f t = opac2 * vis;
+                    // backward.cu:903 (idx <= final_idx) and :925 (alpha = min(1,t) < 1/255 <=> t < 1/255)
+                    const bool ok0 = (idx <= __float_as_int(P1.z)) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
+                    const bool ok1 = (idx <= __float_as_int(P1.w)) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
+                    const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
+                    const v2f am = {fminf(1.f, tz.x), fminf(1.f, tz.y)};
+                    // backward.cu:940-946
+                    const v2f v_alpha =
+                        __builtin_elementwise_fma(cb2, voz, __builtin_elementwise_fma(cg2, voy, cr2 * vox));
+                    gr = __builtin_elementwise_fma(am, vox, gr);
+                    gg = __builtin_elementwise_fma(am, voy, gg);
+                    gb = __builtin_elementwise_fma(am, voz, gb);
+                    const v2f w = tz * v_alpha;  // = -v_sigma (backward.cu:948), 0 when the pair is invalid
+                    S0 += w;
+                    const v2f wdx = w * dx;
+                    S1 += wdx;
+                    S2 = __builtin_elementwise_fma(wdx, dx, S2);
+                    if (WITH_ABS) {  // backward.cu:959-960 (commented in the shipped kernel): sum |v_xy|
+                        const v2f a2 = {a, a}, b2 = {b, b};
+                        const v2f ux = w * __builtin_elementwise_fma(a2, dx, (v2f){bdy_u, bdy_u});
+                        const v2f uy = w * __builtin_elementwise_fma(b2, dx, (v2f){cdy_u, cdy_u});
+                        ax += __builtin_elementwise_abs(ux);
+                        ay += __builtin_elementwise_abs(uy);
+                    }
+                }
+                const float s0 = S0.x + S0.y, s1 = S1.x + S1.y, s2 = S2.x + S2.y;
+                const float dys0 = dy * s0;
+                vx -= __builtin_fmaf(a, s1, b * dys0);   // sum v_sigma*(a dx + b dy)
+                vy -= __builtin_fmaf(b, s1, c * dys0);   // sum v_sigma*(b dx + c dy)
+                c0 -= 0.5f * s2;                         // sum 0.5 v_sigma dx dx
+                c1 -= 0.5f * dy * s1;                    // sum 0.5 v_sigma dx dy
+                c2 -= 0.5f * dy * dys0;                  // sum 0.5 v_sigma dy dy
+                gop += s0;                               // sum opac*vis*v_alpha
+            }
+            float *out = &sm.part[tid * PSTR];
+            out[0] = vx;
+            out[1] = vy;
+            out[2] = c0;
+            out[3] = c1;
+            out[4] = c2;
+            out[5] = gr.x + gr.y;
+            out[6] = gg.x + gg.y;
+            out[7] = gb.x + gb.y;
+            out[8] = (gop != 0.f) ? gop / opac : 0.f;  // v_opacity = sum vis*v_alpha (backward.cu:961)
+            if (WITH_ABS) {
+                out[9] = ax.x + ax.y;
+                out[10] = ay.x + ay.y;
+            }
+        }
+        __syncthreads();
+        // the lane that owns gaussian `tid` adds its (<= 4) strip partials of this round, in strip order
+        const int lo = max(my_lo, round0), hi = min(my_hi, round1);
+        for (int e = lo; e < hi; ++e) {
+            const float *in = &sm.part[(e - round0) * PSTR];
+#pragma unroll
+            for (int q = 0; q < PSTR; ++q) acc[q] += in[q];
+        }
+        __syncthreads();
+    }
+}
+
+template <int PSTR>
+__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR]) {
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    dst[2] = make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, 0.f);
+}
+
+__device__ __forceinline__ void add_partial(float acc[11], const float4 *__restrict__ partials, size_t row) {
+    const float4 p0 = partials[3 * row], p1 = partials[3 * row + 1], p2 = partials[3 * row + 2];
+    acc[0] += p0.x;
+    acc[1] += p0.y;
+    acc[2] += p0.z;
+    acc[3] += p0.w;
+    acc[4] += p1.x;
+    acc[5] += p1.y;
+    acc[6] += p1.z;
+    acc[7] += p1.w;
+    acc[8] += p2.x;
+    acc[9] += p2.y;
+    acc[10] += p2.z;
+}
+__device__ __forceinline__ void store_grads(int g, const float acc[11], float2 *v_xy, float *v_conic,
+                                            float *v_rgb, float *v_opacity, float4 *v_abs_xy) {
+    if (v_abs_xy) v_abs_xy[g] = make_float4(acc[0], acc[1], acc[9], acc[10]);
+    v_xy[g] = make_float2(acc[0], acc[1]);
+    v_conic[3 * g] = acc[2];
+    v_conic[3 * g + 1] = acc[3];
+    v_conic[3 * g + 2] = acc[4];
+    v_rgb[3 * g] = acc[5];
+    v_rgb[3 * g + 1] = acc[6];
+    v_rgb[3 * g + 2] = acc[7];
+    v_opacity[g] = acc[8];
+}
+
+// binary search of gaussian id g in the ascending id list of a tile (entries past the cap carry no gradient)
+__device__ __forceinline__ int find_in_tile(const int32_t *__restrict__ gids_sorted,
+                                            const int2 *__restrict__ tile_bins, int tile, int rows, int g) {
+    if (tile >= rows) return -1;
+    const int2 r = tile_bins[tile];
+    int lo = r.x, hi = min(r.y, r.x + GI2D_TILE_LIST_CAP);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = gids_sorted[mid];
+        if (v == g) return mid;
+        if (v < g)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return -1;
+}
+
+}  // namespace gi2d

@@ -1,14 +1,18 @@
 """Persistent-buffer driver of the hot path over the C ABI (include/gi2d.h).
 
-`HotPath` owns every HBM buffer one image's fitting loop needs (sized once: gaussians N, image HxW,
-intersection capacity) and issues the C-ABI calls with pre-built argument lists, so one step costs six
-native launches-worth of host work and nothing else: no allocation, no host read-back.
+`HotPath` owns every HBM buffer one image's fitting loop needs (sized once: gaussians N, image HxW) and
+issues the C-ABI calls with pre-built argument lists, so one step costs four native calls of host work and
+nothing else: no allocation, no host read-back, nothing but kernel launches on the current HIP stream
+(so a step can be captured into a hipGraph: `capture_graph()`).
 
-    forward : gi2d_project_gaussians_2d*_forward -> gi2d_bin_gaussians -> gi2d_rasterize_sum_forward
-    backward: gi2d_rasterize_backward_tiles -> gi2d_rasterize_backward_reduce -> gi2d_project_*_backward
-
-It is what bench.py times and what the multi-GPU launcher runs per rank; the autograd wrappers in
-gaussianimage_plus_amd.gsplat call the same entry points with torch-allocated outputs.
+  mode "fused" (default) -- the 4-launch fast path (csrc/gi2d_fast.hip)
+      gi2d_fast_project_bin -> gi2d_fast_rasterize_forward
+      -> gi2d_fast_rasterize_backward_tiles -> gi2d_fast_reduce_project_backward
+  mode "exact" -- the capacity-free ops (any tile population):
+      gi2d_project_*_forward -> gi2d_bin_gaussians -> gi2d_rasterize_sum_forward
+      -> gi2d_rasterize_backward_tiles -> gi2d_rasterize_backward_reduce -> gi2d_project_*_backward
+`check_status()` raises if a fused step overflowed a tile bucket; `step_safe()` re-runs such a step in
+"exact" mode.  Both modes produce the same numbers (tests/test_hotpath_gpu.py).
 """
 from __future__ import annotations
 
@@ -17,7 +21,8 @@ import torch
 
 from . import _lib
 
-_KINDS = {
+_KINDS = {"cholesky": 0, "covariance": 1, "scale_rot": 2}
+_PROJ = {
     "cholesky": ("gi2d_project_gaussians_2d_forward", "gi2d_project_gaussians_2d_backward"),
     "covariance": ("gi2d_project_gaussians_2d_covariance_forward", "gi2d_project_gaussians_2d_covariance_backward"),
 }
@@ -25,10 +30,11 @@ _KINDS = {
 
 class HotPath:
     def __init__(self, num_points: int, height: int, width: int, device, kind: str = "cholesky",
-                 capacity: int | None = None, clip_coe: float = 3.0, radius_clip: float = 1.0):
-        assert kind in _KINDS
+                 mode: str = "fused", clip_coe: float = 3.0, radius_clip: float = 1.0):
+        assert kind in _PROJ, "HotPath drives the Cholesky and covariance models"
+        assert mode in ("fused", "exact")
         self.lib = _lib.load()
-        self.n, self.h, self.w, self.kind = int(num_points), int(height), int(width), kind
+        self.n, self.h, self.w, self.kind, self.mode = int(num_points), int(height), int(width), kind, mode
         self.dev = torch.device(device)
         self.tx, self.ty = (self.w + 15) // 16, (self.h + 15) // 16
         self.T = self.tx * self.ty
@@ -40,30 +46,56 @@ class HotPath:
         self.colors, self.opac = f32(n, 3), f32(n, 1)
         self.background = torch.ones(3, dtype=torch.float32, device=dev)
         self.xys, self.depths, self.radii, self.conics, self.nth = f32(n, 2), f32(n), i32(n), f32(n, 3), i32(n)
-        self.tile_bins, self.status = i32(self.T, 2), i32(4)
-        self.out_img, self.final_Ts, self.final_idx = f32(h, w, 3), f32(h, w), i32(h, w)
+        self.status = i32(4)
+        self.out_img, self.final_idx = f32(h, w, 3), i32(h, w)
         self.v_out = f32(h, w, 3)
         self.v_xy, self.v_conic, self.v_rgb, self.v_opac = f32(n, 2), f32(n, 3), f32(n, 3), f32(n, 1)
         self.v_cov2d, self.v_mean2d, self.v_params = f32(n, 3), f32(n, 2), f32(n, 3)
+        # fused-path workspace (cursors zeroed once; every forward leaves them zero)
+        nbytes = self.lib.gi2d_fast_workspace_bytes(n, self.tx, self.ty)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._stream_ptr = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), nbytes, n, self.tx, self.ty, self._stream_ptr)
+        # exact-path buffers are created on first use
         self.capacity = 0
-        self._alloc_capacity(int(capacity) if capacity else max(4 * n, self.T, 1024))
-        self._stream = None
+        self._exact_ready = False
+        self._graph = None
+        self._build_fused_calls()
 
-    # ------------------------------------------------------------------ buffers
-    def _alloc_capacity(self, cap: int):
-        self.capacity = int(cap)
-        self.gids_sorted = torch.zeros(self.capacity, dtype=torch.int32, device=self.dev)
-        self.partials = torch.zeros(self.capacity, 12, dtype=torch.float32, device=self.dev)
-        self.ws_bin = torch.zeros(self.lib.gi2d_bin_workspace_bytes(self.capacity, self.T), dtype=torch.uint8,
-                                  device=self.dev)
-        self._build_calls()
+    # ------------------------------------------------------------------ call lists
+    def _build_fused_calls(self):
+        p = lambda t: t.data_ptr()
+        n, h, w, tx, ty, k = self.n, self.h, self.w, self.tx, self.ty, _KINDS[self.kind]
+        L = self.lib
+        ws, wsb = p(self.ws), self.ws.numel()
+        self._f_bin = (L.gi2d_fast_project_bin, "fast project+bin",
+                       [k, n, self.clip_coe, p(self.means), p(self.params), None, h, w, tx, ty, self.radius_clip,
+                        p(self.xys), p(self.depths), p(self.radii), p(self.conics), p(self.nth), ws, wsb,
+                        p(self.status)])
+        self._f_fwd = (L.gi2d_fast_rasterize_forward, "fast rasterize forward",
+                       [n, tx, ty, w, h, p(self.xys), p(self.radii), p(self.conics), p(self.colors), p(self.opac),
+                        None, ws, wsb, p(self.status), None, p(self.final_idx), p(self.out_img)])
+        self._f_tiles = (L.gi2d_fast_rasterize_backward_tiles, "fast rasterize backward tiles",
+                         [n, tx, ty, w, h, p(self.final_idx), p(self.v_out), 0, ws, wsb])
+        self._f_red = (L.gi2d_fast_reduce_project_backward, "fast reduce+project backward",
+                       [k, n, p(self.params), None, h, w, p(self.xys), p(self.radii), p(self.conics), tx, ty,
+                        self.radius_clip, ws, wsb, p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,
+                        p(self.v_cov2d), p(self.v_mean2d), p(self.v_params), None])
 
-    def _build_calls(self):
+    def _build_exact_calls(self, capacity: int):
         p = lambda t: t.data_ptr()
         n, h, w, tx, ty = self.n, self.h, self.w, self.tx, self.ty
-        fwd_name, bwd_name = _KINDS[self.kind]
         L = self.lib
-        self._calls_fwd = [
+        dev = self.dev
+        self.capacity = int(capacity)
+        self.gids_sorted = torch.zeros(self.capacity, dtype=torch.int32, device=dev)
+        self.partials = torch.zeros(self.capacity, 12, dtype=torch.float32, device=dev)
+        self.tile_bins = torch.zeros(self.T, 2, dtype=torch.int32, device=dev)
+        self.final_Ts = torch.zeros(h, w, dtype=torch.float32, device=dev)
+        self.ws_bin = torch.zeros(L.gi2d_bin_workspace_bytes(self.capacity, self.T), dtype=torch.uint8, device=dev)
+        fwd_name, bwd_name = _PROJ[self.kind]
+        self._e_fwd = [
             (getattr(L, fwd_name), "project forward",
              [n, self.clip_coe, p(self.means), p(self.params), h, w, tx, ty, 0.01, self.radius_clip, p(self.xys),
               p(self.depths), p(self.radii), p(self.conics), p(self.nth)]),
@@ -75,10 +107,10 @@ class HotPath:
               p(self.colors), p(self.opac), p(self.background), p(self.status), p(self.final_Ts),
               p(self.final_idx), p(self.out_img)]),
         ]
-        self._call_tiles = (L.gi2d_rasterize_backward_tiles, "rasterize backward tiles",
-                            [h, w, p(self.gids_sorted), p(self.tile_bins), self.T, p(self.xys), p(self.conics),
-                             p(self.colors), p(self.opac), p(self.final_idx), p(self.v_out), 0, p(self.partials)])
-        self._calls_bwd_rest = [
+        self._e_tiles = (L.gi2d_rasterize_backward_tiles, "rasterize backward tiles",
+                         [h, w, p(self.gids_sorted), p(self.tile_bins), self.T, p(self.xys), p(self.conics),
+                          p(self.colors), p(self.opac), p(self.final_idx), p(self.v_out), 0, p(self.partials)])
+        self._e_rest = [
             (L.gi2d_rasterize_backward_reduce, "rasterize backward reduce",
              [n, p(self.xys), p(self.radii), tx, ty, self.radius_clip, p(self.gids_sorted), p(self.tile_bins),
               self.T, p(self.partials), p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None]),
@@ -86,12 +118,16 @@ class HotPath:
              [n, p(self.means), p(self.params), h, w, p(self.radii), p(self.conics), p(self.v_xy), None,
               p(self.v_conic), p(self.v_cov2d), p(self.v_mean2d), p(self.v_params)]),
         ]
+        self._exact_ready = True
 
     def _run(self, call, stream):
         fn, what, args = call
         rc = fn(*args, stream)
         if rc != 0:
             raise _lib.Gi2dError(f"{what} failed (status {rc}): {self.lib.gi2d_last_error_string().decode()}")
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
 
     # ------------------------------------------------------------------ inputs
     def set_inputs(self, means, params, colors, opac):
@@ -104,41 +140,90 @@ class HotPath:
         self.v_out.copy_(v_out)
 
     # ------------------------------------------------------------------ the path
-    def forward(self, fit_capacity: bool = True) -> torch.Tensor:
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
+    def forward(self) -> torch.Tensor:
+        st = self._stream()
         with torch.cuda.device(self.dev):
-            for c in self._calls_fwd:
-                self._run(c, stream)
-            if fit_capacity:
-                m, overflow = self.status[:2].tolist()  # setup-time read-back only
-                if overflow or self.capacity > 2 * max(m, self.T) + 4096:
-                    self._alloc_capacity(int(1.3 * m) + 1024)
-                    for c in self._calls_fwd:
-                        self._run(c, stream)
+            if self.mode == "fused":
+                self._run(self._f_bin, st)
+                self._run(self._f_fwd, st)
+            else:
+                self._exact_forward(st)
         return self.out_img
 
+    def _exact_forward(self, st):
+        if not self._exact_ready:
+            self._build_exact_calls(max(4 * self.n, self.T, 1024))
+        for c in self._e_fwd:
+            self._run(c, st)
+        m, overflow = self.status[:2].tolist()  # (re)size the lists; only on the exact path
+        if overflow or self.capacity > 2 * max(m, self.T) + 4096:
+            self._build_exact_calls(int(1.3 * m) + 1024)
+            for c in self._e_fwd:
+                self._run(c, st)
+
     def backward(self, timer=None, index: int = 0):
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        st = self._stream()
         with torch.cuda.device(self.dev):
             if timer is not None:
                 timer["bwd0"][index].record()
-            self._run(self._call_tiles, stream)
+            self._run(self._f_tiles if self.mode == "fused" else self._e_tiles, st)
             if timer is not None:
                 timer["bwd1"][index].record()
-            for c in self._calls_bwd_rest:
-                self._run(c, stream)
+            if self.mode == "fused":
+                self._run(self._f_red, st)
+            else:
+                for c in self._e_rest:
+                    self._run(c, st)
 
     def step(self, timer=None, index: int = 0):
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        st = self._stream()
         with torch.cuda.device(self.dev):
-            self._run(self._calls_fwd[0], stream)
-            self._run(self._calls_fwd[1], stream)
-            if timer is not None:
-                timer["fwd0"][index].record()
-            self._run(self._calls_fwd[2], stream)
-            if timer is not None:
-                timer["fwd1"][index].record()
+            if self.mode == "fused":
+                self._run(self._f_bin, st)
+                if timer is not None:
+                    timer["fwd0"][index].record()
+                self._run(self._f_fwd, st)
+                if timer is not None:
+                    timer["fwd1"][index].record()
+            else:
+                if not self._exact_ready:
+                    self._exact_forward(st)
+                self._run(self._e_fwd[0], st)
+                self._run(self._e_fwd[1], st)
+                if timer is not None:
+                    timer["fwd0"][index].record()
+                self._run(self._e_fwd[2], st)
+                if timer is not None:
+                    timer["fwd1"][index].record()
         self.backward(timer, index)
+
+    def step_safe(self):
+        """One step with the overflow check the fused path needs (host read-back of 8 bytes)."""
+        self.step()
+        if self.mode == "fused" and self.status[1].item():
+            self.mode = "exact"
+            try:
+                self.step()
+            finally:
+                self.mode = "fused"
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture_graph(self):
+        """Capture one step (all launches, no host work) into a hipGraph; replay() re-issues it."""
+        assert self.mode == "fused"
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self.step()  # warm-up on the capture stream
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self.step()
+        self._graph = g
+        return g
+
+    def replay(self):
+        self._graph.replay()
 
     # ------------------------------------------------------------------ bookkeeping for bench.py
     def num_intersects(self) -> int:
@@ -147,7 +232,8 @@ class HotPath:
     def check_status(self):
         m, overflow = self.status[:2].tolist()
         if overflow:
-            raise RuntimeError(f"intersection capacity {self.capacity} overflowed (M={m}); results are invalid")
+            what = "a tile bucket" if self.mode == "fused" else f"the intersection capacity {self.capacity}"
+            raise RuntimeError(f"{what} overflowed (M={m}); results of the last step are invalid")
 
     def kernel_timers(self, steps: int):
         mk = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
@@ -161,8 +247,8 @@ class HotPath:
         """The backward tile kernel dominates; its algorithmic bytes: 40*M + 16*H*W + 36*N."""
         m = self.num_intersects()
         avg, mn = self._avg_us(ev, "bwd0", "bwd1")
-        return {"name": "gi2d::raster_bwd_kernel", "avg_us": avg, "min_us": mn,
-                "bytes": 40 * m + 16 * self.h * self.w + 36 * self.n}
+        name = "gi2d::fast_bwd_kernel" if self.mode == "fused" else "gi2d::raster_bwd_kernel"
+        return {"name": name, "avg_us": avg, "min_us": mn, "bytes": 40 * m + 16 * self.h * self.w + 36 * self.n}
 
     def pair_stats(self, ev, pair_bytes):
         f_avg, _ = self._avg_us(ev, "fwd0", "fwd1")
@@ -174,5 +260,7 @@ class HotPath:
                 "note": "HIP-event spans of the two rasterizer kernels inside the timed loop"}
 
     def describe(self) -> str:
-        return ("HotPath: 6 C-ABI calls/step on persistent HBM buffers, eager launches on the current HIP stream, "
-                f"intersection capacity {self.capacity}")
+        if self.mode == "fused":
+            return ("HotPath[fused]: 4 C-ABI calls/step (project+bin, rasterize fwd, bwd tiles, reduce+project bwd) on "
+                    "persistent HBM buffers, eager launches on the current HIP stream")
+        return f"HotPath[exact]: 6 C-ABI calls/step, intersection capacity {self.capacity}"

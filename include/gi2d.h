@@ -230,6 +230,61 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
                                    float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
                                    gi2d_stream_t stream);
 
+/* ------------------------------------------------------------------ fused fast path
+ * The whole per-iteration path in 4 launches (project+fill, forward, backward tiles,
+ * reduce+project backward) on one caller-owned workspace.  Results equal the ops above
+ * (bit-identical index work; the same per-pair arithmetic).  Contract:
+ *   - workspace: gi2d_fast_workspace_bytes(N, tiles_x, tiles_y) bytes, initialised ONCE with
+ *     gi2d_fast_workspace_init (zeroes the bucket cursors; every forward leaves them zero again).
+ *     The forward fills it (tile-sorted ids, tile_bins, packed 48-byte gaussian records), the
+ *     backward reads it: one workspace per in-flight forward/backward pair.
+ *   - capacity: at most gi2d_fast_tile_capacity() (=128) gaussians per (tile, id mod 4) bucket.
+ *     status i32[4] = {M, a bucket overflowed (results invalid: use gi2d_bin_gaussians + the
+ *     plain ops instead), 0, 0}; written by the bin call (reset) and the forward (accumulate).
+ *   - kind: 0 Cholesky (project_gaussians_2d), 1 covariance, 2 scale-rot (p0 = scales, p1 = rot).
+ *   - gi2d_fast_rasterize_forward: final_Ts may be NULL (it is the constant 1); `background`
+ *     non-NULL adds the "no intersection at all -> image = background" rule of
+ *     rasterize_sum_plus.py:110-118 (one extra tiny launch); NULL leaves such an image at 0.
+ *   - final_idx holds positions in the workspace's strided list (tile*512 + rank).
+ */
+size_t gi2d_fast_workspace_bytes(int num_points, int tiles_x, int tiles_y);
+int gi2d_fast_tile_capacity(void);
+int gi2d_fast_workspace_init(void *workspace, size_t workspace_bytes, int num_points, int tiles_x,
+                             int tiles_y, gi2d_stream_t stream);
+int gi2d_fast_workspace_views(void *workspace, size_t workspace_bytes, int num_points, int tiles_x,
+                              int tiles_y, int32_t **gaussian_ids_sorted, int32_t **tile_bins);
+int gi2d_fast_bin(int num_points, const float *xys, const int32_t *radii, int tiles_x, int tiles_y,
+                  float radius_clip, void *workspace, size_t workspace_bytes, int32_t *status,
+                  gi2d_stream_t stream);
+int gi2d_fast_project_bin(int kind, int num_points, float clip_coe, const float *means2d,
+                          const float *p0, const float *p1, unsigned img_height, unsigned img_width,
+                          int tiles_x, int tiles_y, float radius_clip, float *xys, float *depths,
+                          int32_t *radii, float *conics, int32_t *num_tiles_hit, void *workspace,
+                          size_t workspace_bytes, int32_t *status, gi2d_stream_t stream);
+int gi2d_fast_rasterize_forward(int num_points, int tiles_x, int tiles_y, unsigned img_width,
+                                unsigned img_height, const float *xys, const int32_t *radii,
+                                const float *conics, const float *colors, const float *opacities,
+                                const float *background, void *workspace, size_t workspace_bytes,
+                                int32_t *status, float *final_Ts, int32_t *final_idx,
+                                float *out_img, gi2d_stream_t stream);
+int gi2d_fast_rasterize_backward_tiles(int num_points, int tiles_x, int tiles_y, unsigned img_width,
+                                       unsigned img_height, const int32_t *final_idx,
+                                       const float *v_output, int with_abs, void *workspace,
+                                       size_t workspace_bytes, gi2d_stream_t stream);
+int gi2d_fast_rasterize_backward_reduce(int num_points, const float *xys, const int32_t *radii,
+                                        int tiles_x, int tiles_y, float radius_clip, void *workspace,
+                                        size_t workspace_bytes, float *v_xy, float *v_conic,
+                                        float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                        gi2d_stream_t stream);
+int gi2d_fast_reduce_project_backward(int kind, int num_points, const float *p0, const float *p1,
+                                      unsigned img_height, unsigned img_width, const float *xys,
+                                      const int32_t *radii, const float *conics, int tiles_x,
+                                      int tiles_y, float radius_clip, void *workspace,
+                                      size_t workspace_bytes, float *v_xy, float *v_conic,
+                                      float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                      float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
+                                      gi2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,151 @@
+"""GPU: the fused 4-launch fast path (gi2d_fast_*) against the capacity-free ops and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_close, synth_cholesky, synth_gt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mk(mode, n, h, w, seed=3, kind="cholesky"):
+    from gaussianimage_plus_amd.hotpath import HotPath
+    xyz, L, col, op = synth_cholesky(n, h, w, seed)
+    hp = HotPath(n, h, w, device=DEV, mode=mode, kind=kind)
+    hp.set_inputs(xyz, L, col, op)
+    return hp, (xyz, L, col, op)
+
+
+def _v_out(h, w, seed=0):
+    return torch.from_numpy(np.random.default_rng(seed).normal(size=(h, w, 3)).astype(np.float32) * 1e-3).to(DEV)
+
+
+@pytest.mark.parametrize("n,h,w", [(6000, 256, 384), (900, 70, 100), (50000, 512, 768)])
+def test_fused_equals_exact_bitwise_and_matches_oracle(oracle, n, h, w):
+    fused, (xyz, L, col, op) = _mk("fused", n, h, w)
+    exact, _ = _mk("exact", n, h, w)
+    v = _v_out(h, w)
+    outs = []
+    for hp in (fused, exact):
+        img = hp.forward().clone()
+        hp.set_v_out(v)
+        hp.backward()
+        hp.check_status()
+        outs.append([img] + [t.clone() for t in (hp.v_xy, hp.v_conic, hp.v_rgb, hp.v_opac, hp.v_mean2d, hp.v_params,
+                                                 hp.xys, hp.conics, hp.radii, hp.nth)])
+    assert fused.num_intersects() == exact.num_intersects()
+    for a, b in zip(*outs):  # same per-pair arithmetic, same list order, same summation order
+        assert torch.equal(a, b)
+    # and against the oracle, stage by stage on the device's own projection
+    tb = oracle.tile_bounds(h, w)
+    d_xys, d_conics = fused.xys.cpu().numpy(), fused.conics.cpu().numpy()
+    d_radii, d_nth = fused.radii.cpu().numpy(), fused.nth.cpu().numpy()
+    m, cum = oracle.compute_cumulative_intersects(d_nth)
+    assert m == fused.num_intersects()
+    _, _, so, go, bins = oracle.bin_and_sort_gaussians(n, m, d_xys, np.zeros(n, np.float32), d_radii, cum, tb, 1.0)
+    out_o, fT, fidx, amb, absimg = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, d_xys, d_conics,
+                                                                col, op, with_aux=True)
+    ok = np.repeat((amb == 0)[..., None], 3, -1)
+    check_close("fused out_img", outs[0][0].cpu().numpy(), out_o, absimg, mask=ok)
+    want = oracle.rasterize_sum_backward(h, w, 16, 16, go, bins, d_xys, d_conics, col, op, None, fT, fidx,
+                                         v.cpu().numpy(), with_aux=True)
+    okg = want[4] == 0
+    for got, wv, sl, nm in ((outs[0][1], want[0], slice(0, 2), "v_xy"), (outs[0][2], want[1], slice(2, 5), "v_conic"),
+                            (outs[0][3], want[2], slice(5, 8), "v_rgb"), (outs[0][4], want[3], slice(8, 9), "v_opacity")):
+        g = got.cpu().numpy().reshape(wv.shape)
+        check_close("fused " + nm, g, wv, want[5][:, sl], mask=np.repeat(okg[:, None], g.shape[1], 1), atol=1e-12)
+
+
+def test_covariance_kind_fused_equals_exact():
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n, h, w = 3000, 96, 144
+    rng = np.random.default_rng(8)
+    mean_px = (rng.random((n, 2)) * np.array([w, h])).astype(np.float32)
+    cov = (rng.random((n, 3)) * np.array([1, 0.5, 1]) + np.array([3, -0.25, 3])).astype(np.float32)
+    col = rng.random((n, 3)).astype(np.float32)
+    op = (0.3 + 0.7 * rng.random((n, 1))).astype(np.float32)
+    v = _v_out(h, w, 1)
+    res = []
+    for mode in ("fused", "exact"):
+        hp = HotPath(n, h, w, device=DEV, mode=mode, kind="covariance", radius_clip=2.0, clip_coe=2.5)
+        hp.set_inputs(mean_px, cov, col, op)
+        img = hp.forward().clone()
+        hp.set_v_out(v)
+        hp.backward()
+        hp.check_status()
+        res.append((img, hp.v_mean2d.clone(), hp.v_params.clone(), hp.v_rgb.clone(), hp.v_opac.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_bucket_overflow_is_flagged_and_step_safe_recovers(oracle):
+    """> 128 gaussians of one (tile, id mod 4) bucket: status[1] is raised and step_safe() redoes the step
+    on the capacity-free ops."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n, h, w = 1400, 32, 48
+    xyz, L, col, op = synth_cholesky(n, h, w, 4)
+    xyz = (xyz * 0.12).astype(np.float32)  # everything into the two middle tiles
+    fused = HotPath(n, h, w, device=DEV, mode="fused")
+    exact = HotPath(n, h, w, device=DEV, mode="exact")
+    v = _v_out(h, w, 2)
+    for hp in (fused, exact):
+        hp.set_inputs(xyz, L, col, op)
+        hp.set_v_out(v)
+    fused.step()
+    with pytest.raises(RuntimeError):
+        fused.check_status()
+    fused.step_safe()
+    exact.step()
+    exact.check_status()
+    assert torch.equal(fused.out_img, exact.out_img) and torch.equal(fused.v_params, exact.v_params)
+    # the cursors were left clean: a later, non-overflowing problem on the same object still works
+    xyz2, L2, col2, op2 = synth_cholesky(n, h, w, 5)
+    fused.set_inputs(xyz2, L2, col2, op2)
+    exact.set_inputs(xyz2, L2, col2, op2)
+    fused.step()
+    fused.check_status()
+    exact.step()
+    assert torch.equal(fused.out_img, exact.out_img) and torch.equal(fused.v_params, exact.v_params)
+
+
+def test_more_than_256_per_tile_keeps_lowest_ids(oracle):
+    """256 < population <= 512 in a tile: the fused forward ranks all ids and rasterizes the 256 lowest
+    (the stable-sort order the oracle uses); gradients of the others are exactly zero."""
+    n, h, w = 380, 16, 16
+    rng = np.random.default_rng(12)
+    xyz = ((rng.random((n, 2)) - 0.5) * 0.8).astype(np.float32)
+    L = (rng.random((n, 3)) * np.array([1.5, 0.3, 1.5]) + np.array([0.6, 0, 0.6])).astype(np.float32)
+    col = rng.random((n, 3)).astype(np.float32)
+    op = np.ones((n, 1), np.float32)
+    from gaussianimage_plus_amd.hotpath import HotPath
+    hp = HotPath(n, h, w, device=DEV, mode="fused")
+    hp.set_inputs(xyz, L, col, op)
+    img = hp.forward().clone()
+    hp.check_status()
+    ref = oracle.render_cholesky(xyz, L, col, op, h, w, with_aux=True)
+    assert ref["M"] > 256
+    out_o, fT, fidx, amb, absimg = ref["ras"]
+    check_close("capped out_img", img.cpu().numpy(), out_o, absimg, mask=np.repeat((amb == 0)[..., None], 3, -1),
+                rtol=3e-5)
+    hp.set_v_out(_v_out(h, w, 3))
+    hp.backward()
+    dropped = ref["gids_sorted"][256:]
+    assert float(hp.v_rgb[torch.from_numpy(dropped).long().to(DEV)].abs().max()) == 0.0
+
+
+def test_graph_replay_matches_eager():
+    hp, _ = _mk("fused", 8000, 256, 384, seed=9)
+    hp.set_v_out(_v_out(256, 384, 4))
+    hp.step()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (hp.out_img, hp.v_params, hp.v_mean2d, hp.v_rgb)]
+    hp.capture_graph()
+    for t in (hp.out_img, hp.v_params, hp.v_mean2d, hp.v_rgb):
+        t.zero_()
+    hp.replay()
+    hp.replay()
+    torch.cuda.synchronize()
+    hp.check_status()
+    for a, b in zip(want, (hp.out_img, hp.v_params, hp.v_mean2d, hp.v_rgb)):
+        assert torch.equal(a, b)
