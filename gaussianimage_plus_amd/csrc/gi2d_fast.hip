@@ -168,10 +168,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     if (tid == 0) fwd_stage_dummy(sm.f);
     __syncthreads();
     const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
-    if (tid == 0) {
-        tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
-        if (L > 0) atomicAdd(&status[0], L);
-    }
+    if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
     // my (up to two) bucket entries
     int my_id[2];
 #pragma unroll
@@ -216,10 +213,13 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     }
     __syncthreads();
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
-    // status[0] (total count) is still being accumulated by other workgroups: "no intersections at all"
-    // cannot be decided here; the host entry runs a 1-block fix-up kernel for that corner case.
+    // "No intersection at all" (image = background) is a global property no single tile can decide: every
+    // non-empty tile raises status[0] with a plain store as its LAST memory operation (no barrier waits on
+    // it; a contended atomic here would serialise all workgroups), and the host entry may append a tiny
+    // fix-up kernel for that corner case.
     fwd_rasterize_staged(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background, final_Ts,
                          final_idx, out_img);
+    if (tid == 0 && L > 0) status[0] = 1;
 }
 
 // rasterize_sum_plus.py:110-118: if there is not a single intersection the image is the background.

@@ -227,10 +227,11 @@ class HotPath:
 
     # ------------------------------------------------------------------ bookkeeping for bench.py
     def num_intersects(self) -> int:
-        return int(self.status[0].item())
+        """Intersection count M = sum(num_tiles_hit) of the last projection (a setup/teardown query)."""
+        return int(self.nth.sum().item())
 
     def check_status(self):
-        m, overflow = self.status[:2].tolist()
+        m, overflow = self.num_intersects(), int(self.status[1].item())
         if overflow:
             what = "a tile bucket" if self.mode == "fused" else f"the intersection capacity {self.capacity}"
             raise RuntimeError(f"{what} overflowed (M={m}); results of the last step are invalid")

@@ -239,8 +239,9 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
  *     The forward fills it (tile-sorted ids, tile_bins, packed 48-byte gaussian records), the
  *     backward reads it: one workspace per in-flight forward/backward pair.
  *   - capacity: at most gi2d_fast_tile_capacity() (=128) gaussians per (tile, id mod 4) bucket.
- *     status i32[4] = {M, a bucket overflowed (results invalid: use gi2d_bin_gaussians + the
- *     plain ops instead), 0, 0}; written by the bin call (reset) and the forward (accumulate).
+ *     status i32[4] = {1 if any tile is non-empty else 0, 1 if a bucket overflowed (results
+ *     invalid: use gi2d_bin_gaussians + the plain ops instead), 0, 0}; reset by the bin call,
+ *     raised by the forward.  The intersection count itself is sum(num_tiles_hit).
  *   - kind: 0 Cholesky (project_gaussians_2d), 1 covariance, 2 scale-rot (p0 = scales, p1 = rot).
  *   - gi2d_fast_rasterize_forward: final_Ts may be NULL (it is the constant 1); `background`
  *     non-NULL adds the "no intersection at all -> image = background" rule of
