@@ -1,0 +1,181 @@
+"""One-image-per-GPU fitting launcher.
+
+The reference fits images one after another on `cuda:0` (train.py:294-308) -- there is no parallelism to
+port.  Images are independent optimisation problems, so the MI355X-native scale-out is the trivial one:
+one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m gaussianimage_plus_amd.launch ...`),
+image i goes to rank i mod world_size, every rank runs the unchanged per-image loop on its own device, and a
+single RCCL all-reduce of five floats at the end reproduces the reference's "Average:" line
+(train.py:327-340).  No gradient or parameter ever crosses xGMI.
+
+The per-image loop here is the Cholesky training step of models/gaussianimage_cholesky.py:302-317 written
+against the drop-in `gsplat` surface (tanh / +bound / project / rasterize / clamp / L2 / Adam); it exists so
+that images/sec can be measured on a box that does not have the reference checked out.  With the reference
+on PYTHONPATH, its own train.py runs unmodified on top of the same operators.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import time
+from typing import Callable, Dict, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def partition(num_items: int, rank: int, world_size: int) -> List[int]:
+    """Round-robin shard of image indices: Kodak-24 -> 24/12/6/3 images per rank at 1/2/4/8 GPUs."""
+    return list(range(rank, num_items, world_size))
+
+
+def reduce_metrics(local: Dict[str, float], device="cpu") -> Dict[str, float]:
+    """Sum the per-rank totals (psnr, train seconds, eval seconds, gaussians, images) across ranks with one
+    all-reduce and return the averages the reference logs."""
+    keys = ["psnr", "train_s", "eval_s", "num_gaussians", "count"]
+    t = torch.tensor([float(local.get(k, 0.0)) for k in keys], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    tot = dict(zip(keys, t.tolist()))
+    n = max(tot["count"], 1.0)
+    return {"images": int(tot["count"]), "avg_psnr": tot["psnr"] / n, "avg_train_s": tot["train_s"] / n,
+            "avg_eval_s": tot["eval_s"] / n, "avg_num_gaussians": tot["num_gaussians"] / n,
+            "sum_train_s": tot["train_s"]}
+
+
+def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, float]], rank: int, world_size: int,
+                device="cpu") -> Dict[str, float]:
+    """Fit this rank's shard of `items` with `fit_one(index, item)` and reduce the metrics."""
+    local = {"psnr": 0.0, "train_s": 0.0, "eval_s": 0.0, "num_gaussians": 0.0, "count": 0.0}
+    rows = []
+    for i in partition(len(items), rank, world_size):
+        r = fit_one(i, items[i])
+        rows.append((i, r))
+        for k in ("psnr", "train_s", "eval_s", "num_gaussians"):
+            local[k] += float(r.get(k, 0.0))
+        local["count"] += 1
+    out = reduce_metrics(local, device)
+    out["rows"] = rows
+    return out
+
+
+# ----------------------------------------------------------------------------------- per-image loop
+def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float = 1e-3, seed: int = 3047,
+              eval_renders: int = 10) -> Dict[str, float]:
+    """Cholesky model, L2 loss, Adam (models/gaussianimage_cholesky.py:57-58,80-82,302-317 with
+    opt_type="adam").  gt_hwc: float32 [H, W, 3] in [0, 1] on the target GPU."""
+    from .gsplat.project_gaussians_2d import project_gaussians_2d
+    from .gsplat.rasterize_sum_plus import rasterize_gaussians_plus
+
+    dev = gt_hwc.device
+    h, w = int(gt_hwc.shape[0]), int(gt_hwc.shape[1])
+    tile_bounds = ((w + 15) // 16, (h + 15) // 16, 1)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xyz = torch.atanh(2 * (torch.rand(num_points, 2, generator=g) - 0.5)).to(dev).requires_grad_(True)
+    chol = torch.rand(num_points, 3, generator=g).to(dev).requires_grad_(True)
+    feat = torch.zeros(num_points, 3, device=dev, requires_grad=True)
+    opacity = torch.ones(num_points, 1, device=dev)
+    low_pass = min(h * w / (9 * math.pi * num_points), 300)
+    bound = torch.tensor([low_pass, 0.0, low_pass], device=dev).view(1, 3)
+    background = torch.ones(3, device=dev)
+    opt = torch.optim.Adam([xyz, chol, feat], lr=lr)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=20000, gamma=0.5)
+
+    def render():
+        xys, depths, radii, conics, nth = project_gaussians_2d(torch.tanh(xyz), chol + bound, h, w, tile_bounds)
+        img = rasterize_gaussians_plus(xys, depths, radii, conics, nth, feat, opacity, h, w, 16, 16,
+                                       background=background)
+        return torch.clamp(img, 0, 1)
+
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    for _ in range(iterations):
+        loss = torch.nn.functional.mse_loss(render(), gt_hwc)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        sched.step()
+    torch.cuda.synchronize(dev)
+    train_s = time.time() - t0
+    with torch.no_grad():
+        t0 = time.time()
+        for _ in range(eval_renders):
+            img = render()
+        torch.cuda.synchronize(dev)
+        eval_s = (time.time() - t0) / max(eval_renders, 1)
+        mse = torch.nn.functional.mse_loss(img, gt_hwc).item()
+    psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
+    return {"psnr": psnr, "train_s": train_s, "eval_s": eval_s, "num_gaussians": num_points, "mse": mse}
+
+
+def synthetic_image(h: int, w: int, seed: int) -> torch.Tensor:
+    """Seeded smooth test picture in [0,1], [H,W,3] (stands in for a Kodak image when no dataset is present)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    img = torch.zeros(h, w, 3)
+    for c in range(3):
+        for _ in range(6):
+            fx, fy = (torch.rand(2, generator=g) * 5.5 + 0.5).tolist()
+            p0, p1 = (torch.rand(2, generator=g) * 2 * math.pi).tolist()
+            img[..., c] += torch.sin(2 * math.pi * fx * xx / w + p0) * torch.cos(2 * math.pi * fy * yy / h + p1)
+    img = (img - img.min()) / (img.max() - img.min())
+    return img.contiguous()
+
+
+def load_images(path: str | None, count: int, h: int, w: int) -> List[torch.Tensor]:
+    if path:
+        import numpy as np
+        from PIL import Image
+        files = sorted(f for f in os.listdir(path) if f.lower().endswith((".png", ".jpg", ".jpeg")))
+        return [torch.from_numpy(np.asarray(Image.open(os.path.join(path, f)).convert("RGB"), dtype="float32") / 255.0)
+                for f in files]
+    return [synthetic_image(h, w, 100 + i) for i in range(count)]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--dataset", type=str, default=None, help="directory of images (e.g. datasets/kodak)")
+    ap.add_argument("--synthetic", type=int, default=24, help="number of synthetic 768x512 images if no dataset")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=768)
+    ap.add_argument("--num_points", type=int, default=5000)
+    ap.add_argument("--iterations", type=int, default=2000)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--seed", type=int, default=3047)
+    args = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+    if not use_gpu:
+        raise SystemExit("gaussianimage_plus_amd.launch fits on the GPU; no device found")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    images = load_images(args.dataset, args.synthetic, args.height, args.width)
+
+    def fit_one(i, img):
+        r = fit_image(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed)
+        print(f"[rank {rank}] image {i}: {img.shape[0]}x{img.shape[1]}, PSNR:{r['psnr']:.4f}, "
+              f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}", flush=True)
+        return r
+
+    t0 = time.time()
+    out = run_sharded(images, fit_one, rank, world, device=dev)
+    if world > 1:
+        dist.barrier()
+    wall = time.time() - t0
+    if rank == 0:
+        print(f"Average: {args.width}x{args.height}, PSNR:{out['avg_psnr']:.4f}, Training:{out['avg_train_s']:.4f}s, "
+              f"Eval:{out['avg_eval_s']:.8f}s, FPS:{1.0 / max(out['avg_eval_s'], 1e-12):.4f}, "
+              f"images:{out['images']}, gpus:{world}, wall:{wall:.2f}s, images/sec:{out['images'] / wall:.4f}",
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

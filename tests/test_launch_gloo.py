@@ -1,0 +1,68 @@
+"""CPU-only, world_size 2 over gloo: the one-image-per-rank sharding and the single metric all-reduce of
+gaussianimage_plus_amd.launch (the N>1 path of SURVEY.md section 8e; no data-path collective)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gaussianimage_plus_amd.launch import partition, reduce_metrics, run_sharded
+
+
+def test_partition_is_a_round_robin_cover():
+    for n, world in [(24, 1), (24, 2), (24, 4), (24, 8), (5, 8), (0, 2)]:
+        shards = [partition(n, r, world) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    assert [len(partition(24, r, 8)) for r in range(8)] == [3] * 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    items = list(range(7))  # 7 "images": rank 0 gets 0,2,4,6 and rank 1 gets 1,3,5
+    seen = []
+
+    def fit_one(i, item):
+        seen.append(i)
+        return {"psnr": 30.0 + i, "train_s": 1.0 + 0.5 * i, "eval_s": 0.001, "num_gaussians": 100 * (i + 1)}
+
+    out = run_sharded(items, fit_one, rank, world, device="cpu")
+    q.put((rank, seen, {k: v for k, v in out.items() if k != "rows"}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_images_and_agree_on_the_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]
+    a, b = res[0][2], res[1][2]
+    assert a == b  # every rank holds the same reduced metrics
+    assert a["images"] == 7
+    assert abs(a["avg_psnr"] - (30.0 + 3.0)) < 1e-9
+    assert abs(a["sum_train_s"] - sum(1.0 + 0.5 * i for i in range(7))) < 1e-9
+    assert abs(a["avg_num_gaussians"] - 400.0) < 1e-9
+
+
+def test_single_process_needs_no_process_group():
+    out = reduce_metrics({"psnr": 60.0, "train_s": 4.0, "eval_s": 0.2, "num_gaussians": 10, "count": 2})
+    assert out["images"] == 2 and out["avg_psnr"] == 30.0 and out["avg_train_s"] == 2.0
