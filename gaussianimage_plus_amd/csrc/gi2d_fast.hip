@@ -217,8 +217,12 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     // non-empty tile raises status[0] with a plain store as its LAST memory operation (no barrier waits on
     // it; a contended atomic here would serialise all workgroups), and the host entry may append a tiny
     // fix-up kernel for that corner case.
-    fwd_rasterize_staged(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background, final_Ts,
-                         final_idx, out_img);
+    if (final_idx)
+        fwd_rasterize_staged<true>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
+                                   final_Ts, final_idx, out_img);
+    else
+        fwd_rasterize_staged<false>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
+                                    final_Ts, final_idx, out_img);
     if (tid == 0 && L > 0) status[0] = 1;
 }
 
@@ -246,11 +250,20 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
+#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 0
+    if (tiles_x > 0) return;  // timing experiment: launch floor
+#endif
     const int2 range = tile_bins[tile];
     const int full_len = range.y - range.x;
     if (full_len <= 0) return;
     const int len = full_len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : full_len;
+#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 1
+    if (len > 0) return;  // + tile_bins load
+#endif
     bwd_stage_pixels(sm, tx, ty, img_w, img_h, final_idx, v_output);
+#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 2
+    if (len > 0) return;  // + pixel staging
+#endif
     unsigned mask = 0;
     int slot = 0;
     if (tid < len) {
@@ -262,8 +275,18 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
         slot = __float_as_int(q2.y);
         mask = (unsigned)__float_as_int(q2.w);
     }
+#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 3
+    if (len > 0) {  // + gaussian staging
+        __syncthreads();
+        if (sm.gCb[tid & 63] == 12345.f && mask == 77u) partial_big[0] = sm.pix[tid];
+        return;
+    }
+#endif
     float acc[BwdLds<WITH_ABS>::PSTR];
-    bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), acc);
+    bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), acc);
+#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 4
+    if (len > 0 && acc[0] != 12345.f) return;  // + items and compute, no stores
+#endif
     if (tid < len) {
         float4 *dst = slot >= 0 ? partial_g + 3 * (size_t)slot : partial_big + 3 * (size_t)(-slot - 1);
         store_partial_row(dst, acc);
@@ -464,7 +487,7 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
         set_error("fast rasterize forward: tile grid does not cover the image");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
-    if (!status || !final_idx || !out_img || (n > 0 && (!xys || !radii || !conics || !colors || !opac))) {
+    if (!status || !out_img || (n > 0 && (!xys || !radii || !conics || !colors || !opac))) {
         set_error("fast rasterize forward: null pointer");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
@@ -486,7 +509,7 @@ int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned
     if (rc != GI2D_OK) return rc;
     const long long t = (long long)tiles_x * tiles_y;
     if (t == 0) return GI2D_OK;
-    if (!final_idx || !v_output) {
+    if (!v_output) {
         set_error("fast rasterize backward: null pointer");
         return GI2D_ERR_INVALID_ARGUMENT;
     }

@@ -81,6 +81,8 @@ __device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
 
 // phases 2-4 of the forward for one tile whose `len` (<= 256) entries are staged in ascending order.
 // Must be called by all 256 lanes after a __syncthreads() that follows the staging.
+// NEED_FIDX=false (fast path: nobody consumes final_idx) drops the per-pair index tracking and the store.
+template <bool NEED_FIDX = true>
 __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int list_base, int tx, int ty,
                                                      int img_w, int img_h, bool background_fill,
                                                      const float *__restrict__ background,
@@ -136,7 +138,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
             o0 = __builtin_fmaf(B.z, am, o0);
             o1 = __builtin_fmaf(B.w, am, o1);
             o2 = __builtin_fmaf(cb, am, o2);
-            last_k = ok ? k : last_k;
+            if (NEED_FIDX) last_k = ok ? k : last_k;
         }
     }
     int cur_idx = last_k < 0 ? 0 : list_base + last_k;  // forward.cu:497,550: 0 when nothing landed
@@ -151,7 +153,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
     const int pix = i * img_w + j;
     if (inside) {
         if (final_Ts) final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
-        final_idx[pix] = cur_idx;
+        if (NEED_FIDX) final_idx[pix] = cur_idx;
     }
     // phase 4: transpose RGB through the wave's LDS so a 16-pixel row leaves as 12 x 16-byte stores
     const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
@@ -221,7 +223,7 @@ __device__ __forceinline__ void bwd_stage_pixels(BwdLds<WITH_ABS> &sm, int tx, i
         vx = v_output[3 * pix];
         vy = v_output[3 * pix + 1];
         vz = v_output[3 * pix + 2];
-        fi = __int_as_float(final_idx[pix]);
+        fi = __int_as_float(final_idx ? final_idx[pix] : 0x7fffffff);
     }
     float *row = reinterpret_cast<float *>(&sm.pix[ly * (GI2D_TILE + 1)]) + (lx >> 1) * 8 + (lx & 1);
     row[0] = vx;
@@ -242,7 +244,10 @@ __device__ __forceinline__ void bwd_stage_entry(BwdLds<WITH_ABS> &sm, int k, con
 // gradient partial of gaussian `tid` for this tile:
 //   acc = (v_x, v_y, v_conic[3], v_rgb[3], v_opacity [, sum|v_x|, sum|v_y|]).
 // `list_base` + k is the entry's position in the sorted list (compared with final_idx, backward.cu:903).
-template <bool WITH_ABS>
+// USE_FIDX=false (fast path): the forward that produced the lists evaluates every pair with the same
+// instructions, so "idx <= final_idx" is implied by the alpha test and is not re-checked (pixels outside the
+// image still carry v_out = 0 and contribute nothing).
+template <bool WITH_ABS, bool USE_FIDX = true>
 __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsigned mask, int list_base,
                                              float tx0, float ty0, float (&acc)[BwdLds<WITH_ABS>::PSTR]) {
     constexpr int PSTR = BwdLds<WITH_ABS>::PSTR;
@@ -316,8 +321,8 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
                     const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
                     const v2f t = opac2 * vis;
                     // backward.cu:903 (idx <= final_idx) and :925 (alpha = min(1,t) < 1/255 <=> t < 1/255)
-                    const bool ok0 = (idx <= __float_as_int(P1.z)) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
-                    const bool ok1 = (idx <= __float_as_int(P1.w)) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
+                    const bool ok0 = (!USE_FIDX || idx <= __float_as_int(P1.z)) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
+                    const bool ok1 = (!USE_FIDX || idx <= __float_as_int(P1.w)) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
                     const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
                     const v2f am = {fminf(1.f, tz.x), fminf(1.f, tz.y)};
                     // backward.cu:940-946

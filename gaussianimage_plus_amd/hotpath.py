@@ -75,9 +75,9 @@ class HotPath:
                         p(self.status)])
         self._f_fwd = (L.gi2d_fast_rasterize_forward, "fast rasterize forward",
                        [n, tx, ty, w, h, p(self.xys), p(self.radii), p(self.conics), p(self.colors), p(self.opac),
-                        None, ws, wsb, p(self.status), None, p(self.final_idx), p(self.out_img)])
+                        None, ws, wsb, p(self.status), None, None, p(self.out_img)])
         self._f_tiles = (L.gi2d_fast_rasterize_backward_tiles, "fast rasterize backward tiles",
-                         [n, tx, ty, w, h, p(self.final_idx), p(self.v_out), 0, ws, wsb])
+                         [n, tx, ty, w, h, None, p(self.v_out), 0, ws, wsb])
         self._f_red = (L.gi2d_fast_reduce_project_backward, "fast reduce+project backward",
                        [k, n, p(self.params), None, h, w, p(self.xys), p(self.radii), p(self.conics), tx, ty,
                         self.radius_clip, ws, wsb, p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,

@@ -246,7 +246,9 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
  *   - gi2d_fast_rasterize_forward: final_Ts may be NULL (it is the constant 1); `background`
  *     non-NULL adds the "no intersection at all -> image = background" rule of
  *     rasterize_sum_plus.py:110-118 (one extra tiny launch); NULL leaves such an image at 0.
- *   - final_idx holds positions in the workspace's strided list (tile*512 + rank).
+ *   - final_idx (positions in the workspace's strided list, tile*512 + rank) is optional in both
+ *     directions: the fused backward does not need it (its forward evaluated every pair with the
+ *     same instructions, so "idx <= final_idx" is implied by the alpha test); pass NULL to skip it.
  */
 size_t gi2d_fast_workspace_bytes(int num_points, int tiles_x, int tiles_y);
 int gi2d_fast_tile_capacity(void);
