@@ -29,6 +29,8 @@ namespace gi2d {
 #define GI2D_FAST_C (GI2D_FAST_SUB * GI2D_FAST_CSUB) /* list slots per tile */
 #define GI2D_FAST_S 16                               /* gaussian-major partial rows per gaussian */
 #define GI2D_BIG_TILES_F 32
+#define GI2D_FAST_ROW 4 /* float4 per partial row: 48 bytes of data padded to one 64-byte line */
+#define GI2D_CURSOR_STRIDE 16 /* ints between cursors: one 64-byte line each, so atomics on different cursors never share a line */
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FastWs {
@@ -37,8 +39,8 @@ struct FastWs {
     int32_t *gids_sorted;  // [T * C]            ascending ids per tile (stride C)
     int32_t *tile_bins;    // [T * 2]            [t*C, t*C + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
-    float4 *partial_g;     // [N * S * 3]        gaussian-major partial rows
-    float4 *partial_big;   // [T * 256 * 3]      partial rows of gaussians on > S tiles, by (tile, rank)
+    float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
+    float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
     size_t bytes;
 };
 static FastWs carve_fast(void *base, int n, int num_tiles) {
@@ -47,7 +49,7 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     size_t off = 0;
     const size_t t = (size_t)(num_tiles > 0 ? num_tiles : 1), nn = (size_t)(n > 0 ? n : 1);
     w.cursors = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_SUB * sizeof(int32_t));
+    off += align_up(t * GI2D_FAST_SUB * GI2D_CURSOR_STRIDE * sizeof(int32_t));
     w.buckets = (int32_t *)(b + off);
     off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
     w.gids_sorted = (int32_t *)(b + off);
@@ -57,9 +59,9 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     w.packed = (GaussRec *)(b + off);
     off += align_up(t * GI2D_TILE_LIST_CAP * sizeof(GaussRec));
     w.partial_g = (float4 *)(b + off);
-    off += align_up(nn * GI2D_FAST_S * 3 * sizeof(float4));
+    off += align_up(nn * GI2D_FAST_S * GI2D_FAST_ROW * sizeof(float4));
     w.partial_big = (float4 *)(b + off);
-    off += align_up(t * GI2D_TILE_LIST_CAP * 3 * sizeof(float4));
+    off += align_up(t * GI2D_TILE_LIST_CAP * GI2D_FAST_ROW * sizeof(float4));
     w.bytes = off;
     return w;
 }
@@ -68,10 +70,27 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
 __device__ __forceinline__ void fill_one(int g, int mnx, int mny, int mxx, int mxy, int tiles_x,
                                          int32_t *__restrict__ cursors, int32_t *__restrict__ buckets) {
     const int sub = g & (GI2D_FAST_SUB - 1);
+    const int w = mxx - mnx, h = mxy - mny;
+    if (w <= 2 && h <= 2) {
+        // the common case (<= 4 tiles): issue all returning atomics back to back, then the stores, so the
+        // lane pays one L2 round trip instead of one per tile
+        int c[4], p[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dj = q & 1, di = q >> 1;
+            c[q] = (dj < w && di < h) ? ((mny + di) * tiles_x + mnx + dj) * GI2D_FAST_SUB + sub : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[q] = c[q] >= 0 ? atomicAdd(&cursors[c[q] * GI2D_CURSOR_STRIDE], 1) : GI2D_FAST_CSUB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (p[q] < GI2D_FAST_CSUB) buckets[c[q] * GI2D_FAST_CSUB + p[q]] = g;
+        return;
+    }
     for (int i = mny; i < mxy; ++i)
         for (int j = mnx; j < mxx; ++j) {
             const int c = (i * tiles_x + j) * GI2D_FAST_SUB + sub;
-            const int p = atomicAdd(&cursors[c], 1);
+            const int p = atomicAdd(&cursors[c * GI2D_CURSOR_STRIDE], 1);
             if (p < GI2D_FAST_CSUB) buckets[c * GI2D_FAST_CSUB + p] = g;
         }
 }
@@ -145,6 +164,7 @@ struct FastFwdLds {
     FwdLds f;
     int ids[GI2D_FAST_C];
     int cnt[GI2D_FAST_SUB];
+    float soa[4 * 9 * 64];  // per-wave SoA copy of 64 list entries for the packed pixel loop
 };
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
@@ -160,8 +180,8 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
     if (tid < GI2D_FAST_SUB) {
-        const int c = cursors[tile * GI2D_FAST_SUB + tid];
-        cursors[tile * GI2D_FAST_SUB + tid] = 0;  // ready for the next call
+        const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
+        cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
         if (c > GI2D_FAST_CSUB) atomicOr(&status[1], 1);
         sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
     }
@@ -206,9 +226,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         } else if (slot >= 0) {
             // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            partial_g[3 * (size_t)slot] = z;
-            partial_g[3 * (size_t)slot + 1] = z;
-            partial_g[3 * (size_t)slot + 2] = z;
+            partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
+            partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
+            partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
         }
     }
     __syncthreads();
@@ -222,7 +242,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
                                    final_Ts, final_idx, out_img);
     else
         fwd_rasterize_staged<false>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
-                                    final_Ts, final_idx, out_img);
+                                    final_Ts, final_idx, out_img, sm.soa);
     if (tid == 0 && L > 0) status[0] = 1;
 }
 
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     if (len > 0 && acc[0] != 12345.f) return;  // + items and compute, no stores
 #endif
     if (tid < len) {
-        float4 *dst = slot >= 0 ? partial_g + 3 * (size_t)slot : partial_big + 3 * (size_t)(-slot - 1);
+        float4 *dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
         store_partial_row(dst, acc);
     }
 }
@@ -316,14 +336,14 @@ __device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restric
     }
     const int ntiles = mapped ? (mxx - mnx) * (mxy - mny) : 0;
     if (mapped && ntiles <= GI2D_FAST_S) {
-        for (int k = 0; k < ntiles; ++k) add_partial(acc, partial_g, (size_t)g * GI2D_FAST_S + k);
+        for (int k = 0; k < ntiles; ++k) add_partial<GI2D_FAST_ROW>(acc, partial_g, (size_t)g * GI2D_FAST_S + k);
     } else if (mapped && ntiles <= GI2D_BIG_TILES_F) {
         for (int i = mny; i < mxy; ++i)
             for (int j = mnx; j < mxx; ++j) {
                 const int tile = i * tiles_x + j;
                 const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, g);
                 if (pos >= 0)
-                    add_partial(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
+                    add_partial<GI2D_FAST_ROW>(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
             }
     }
     unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F);
@@ -340,7 +360,7 @@ __device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restric
             const int tile = (by0 + t / bw) * tiles_x + bx0 + t % bw;
             const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, bg);
             if (pos >= 0)
-                add_partial(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
+                add_partial<GI2D_FAST_ROW>(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
         }
 #pragma unroll
         for (int q = 0; q < 11; ++q) {
@@ -424,7 +444,7 @@ int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int 
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const size_t t = (size_t)tiles_x * tiles_y;
     if (t == 0) return GI2D_OK;
-    hipError_t e = hipMemsetAsync(w.cursors, 0, t * GI2D_FAST_SUB * sizeof(int32_t), (hipStream_t)st);
+    hipError_t e = hipMemsetAsync(w.cursors, 0, t * GI2D_FAST_SUB * GI2D_CURSOR_STRIDE * sizeof(int32_t), (hipStream_t)st);
     if (e != hipSuccess) {
         set_error(hipGetErrorString(e));
         return (int)e;

@@ -88,7 +88,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
                                                      const float *__restrict__ background,
                                                      float *__restrict__ final_Ts,
                                                      int32_t *__restrict__ final_idx,
-                                                     float *__restrict__ out_img) {
+                                                     float *__restrict__ out_img, float *soa = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
@@ -107,39 +107,108 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
     if (lane < 4) mylist[cnt + lane] = (unsigned short)GI2D_FWD_DUMMY;
     __builtin_amdgcn_wave_barrier();  // wave-private list: DS ops of one wave complete in order
 
-    // phase 3: one pixel per lane, four list entries per trip (indices are wave-uniform -> scalar)
+    // phase 3: one pixel per lane.  Entries 2p and 2p+1 of the wave's list feed two separate accumulator
+    // sets (summed at the end) in both loop forms below, so they give bitwise identical pixels.
     const float px = (float)j, py = (float)i;
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    float o0, o1, o2;
     int last_k = -1;
+    if (!NEED_FIDX && soa != nullptr) {
+        // packed form: the wave copies its list 64 entries at a time into a private SoA buffer so that two
+        // consecutive entries sit in one 64-bit LDS word pair, and evaluates them with v_pk_* instructions
+        float *mysoa = soa + wv * (9 * 64);
+        v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+        const v2f px2 = {px, px}, py2 = {py, py};
 #ifdef GI2D_ABLATE_FWD_COMPUTE
-    if (len < 0)  // timing experiment: skip the pixel loop
+        if (len < 0)  // timing experiment: skip the pixel loop
 #endif
-    for (int t = 0; t < cnt; t += 4) {
-        const uint2 packed = *reinterpret_cast<const uint2 *>(mylist + t);
-        const unsigned p0 = __builtin_amdgcn_readfirstlane(packed.x);
-        const unsigned p1 = __builtin_amdgcn_readfirstlane(packed.y);
-        const int ks[4] = {(int)(p0 & 0xffffu), (int)(p0 >> 16), (int)(p1 & 0xffffu), (int)(p1 >> 16)};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = ks[u];
-            const float4 A = sm.AB[2 * k];
-            const float4 B = sm.AB[2 * k + 1];
-            const float cb = sm.C[k];
-            ConicS s;
-            s.ha = A.z;
-            s.hb = A.w;
-            s.hc = B.x;
-            const float dx = A.x - px, dy = A.y - py;
-            const float sig = pair_sigma(s, dx, row_term_b(s, dy), row_term_c(s, dy));
-            const float vis = pair_vis(sig);
-            const float alpha = fminf(1.f, B.y * vis);
-            const bool ok = !(sig < 0.f || alpha < GI2D_ALPHA_MIN);  // forward.cu:541
-            const float am = ok ? alpha : 0.f;
-            o0 = __builtin_fmaf(B.z, am, o0);
-            o1 = __builtin_fmaf(B.w, am, o1);
-            o2 = __builtin_fmaf(cb, am, o2);
-            if (NEED_FIDX) last_k = ok ? k : last_k;
+        for (int c0 = 0; c0 < cnt; c0 += 64) {
+            {
+                const int e = c0 + lane;
+                const int k = e < cnt ? (int)mylist[e] : GI2D_FWD_DUMMY;
+                const float4 A = sm.AB[2 * k], B = sm.AB[2 * k + 1];
+                const float cb = sm.C[k];
+                mysoa[0 * 64 + lane] = A.x;
+                mysoa[1 * 64 + lane] = A.y;
+                mysoa[2 * 64 + lane] = A.z;
+                mysoa[3 * 64 + lane] = A.w;
+                mysoa[4 * 64 + lane] = B.x;
+                mysoa[5 * 64 + lane] = B.y;
+                mysoa[6 * 64 + lane] = B.z;
+                mysoa[7 * 64 + lane] = B.w;
+                mysoa[8 * 64 + lane] = cb;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int m = min(64, cnt - c0);
+            for (int t = 0; t < m; t += 2) {
+                const v2f gx = *reinterpret_cast<const v2f *>(mysoa + 0 * 64 + t);
+                const v2f gy = *reinterpret_cast<const v2f *>(mysoa + 1 * 64 + t);
+                const v2f ha = *reinterpret_cast<const v2f *>(mysoa + 2 * 64 + t);
+                const v2f hb = *reinterpret_cast<const v2f *>(mysoa + 3 * 64 + t);
+                const v2f hc = *reinterpret_cast<const v2f *>(mysoa + 4 * 64 + t);
+                const v2f op = *reinterpret_cast<const v2f *>(mysoa + 5 * 64 + t);
+                const v2f cr = *reinterpret_cast<const v2f *>(mysoa + 6 * 64 + t);
+                const v2f cg = *reinterpret_cast<const v2f *>(mysoa + 7 * 64 + t);
+                const v2f cb = *reinterpret_cast<const v2f *>(mysoa + 8 * 64 + t);
+                const v2f dx = gx - px2, dy = gy - py2;
+                const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
+                const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
+                const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+                const v2f tt = op * vis;
+                const v2f alpha = {fminf(1.f, tt.x), fminf(1.f, tt.y)};
+                const bool ok0 = !(sig.x < 0.f || alpha.x < GI2D_ALPHA_MIN);
+                const bool ok1 = !(sig.y < 0.f || alpha.y < GI2D_ALPHA_MIN);
+                const v2f am = {ok0 ? alpha.x : 0.f, ok1 ? alpha.y : 0.f};
+                a0 = __builtin_elementwise_fma(cr, am, a0);
+                a1 = __builtin_elementwise_fma(cg, am, a1);
+                a2 = __builtin_elementwise_fma(cb, am, a2);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        o0 = a0.x + a0.y;
+        o1 = a1.x + a1.y;
+        o2 = a2.x + a2.y;
+    } else {
+        // scalar form: four list entries per trip (indices are wave-uniform -> scalar)
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#ifdef GI2D_ABLATE_FWD_COMPUTE
+        if (len < 0)  // timing experiment: skip the pixel loop
+#endif
+        for (int t = 0; t < cnt; t += 4) {
+            const uint2 packed = *reinterpret_cast<const uint2 *>(mylist + t);
+            const unsigned p0 = __builtin_amdgcn_readfirstlane(packed.x);
+            const unsigned p1 = __builtin_amdgcn_readfirstlane(packed.y);
+            const int ks[4] = {(int)(p0 & 0xffffu), (int)(p0 >> 16), (int)(p1 & 0xffffu), (int)(p1 >> 16)};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = ks[u];
+                const float4 A = sm.AB[2 * k];
+                const float4 B = sm.AB[2 * k + 1];
+                const float cb = sm.C[k];
+                ConicS s;
+                s.ha = A.z;
+                s.hb = A.w;
+                s.hc = B.x;
+                const float dx = A.x - px, dy = A.y - py;
+                const float sig = pair_sigma(s, dx, row_term_b(s, dy), row_term_c(s, dy));
+                const float vis = pair_vis(sig);
+                const float alpha = fminf(1.f, B.y * vis);
+                const bool ok = !(sig < 0.f || alpha < GI2D_ALPHA_MIN);  // forward.cu:541
+                const float am = ok ? alpha : 0.f;
+                if (u & 1) {
+                    d0 = __builtin_fmaf(B.z, am, d0);
+                    d1 = __builtin_fmaf(B.w, am, d1);
+                    d2 = __builtin_fmaf(cb, am, d2);
+                } else {
+                    e0 = __builtin_fmaf(B.z, am, e0);
+                    e1 = __builtin_fmaf(B.w, am, e1);
+                    e2 = __builtin_fmaf(cb, am, e2);
+                }
+                if (NEED_FIDX) last_k = ok ? k : last_k;
+            }
+        }
+        o0 = e0 + d0;
+        o1 = e1 + d1;
+        o2 = e2 + d2;
     }
     int cur_idx = last_k < 0 ? 0 : list_base + last_k;  // forward.cu:497,550: 0 when nothing landed
     if (background_fill) {
@@ -387,8 +456,10 @@ __device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, cons
     dst[2] = make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, 0.f);
 }
 
+// STRIDE = float4 per row: 3 (packed 48-byte rows) or 4 (rows padded to one 64-byte line each)
+template <int STRIDE = 3>
 __device__ __forceinline__ void add_partial(float acc[11], const float4 *__restrict__ partials, size_t row) {
-    const float4 p0 = partials[3 * row], p1 = partials[3 * row + 1], p2 = partials[3 * row + 2];
+    const float4 p0 = partials[STRIDE * row], p1 = partials[STRIDE * row + 1], p2 = partials[STRIDE * row + 2];
     acc[0] += p0.x;
     acc[1] += p0.y;
     acc[2] += p0.z;
