@@ -131,12 +131,30 @@ def main():
             },
             "rasterize_pair": hp.pair_stats(ev, pair_bytes),
         }
+        line["train_step"] = train_step_rate(gt, n, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(xyz, L, col, op, h, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_step_rate(gt, n, dev, iters=400):
+    """Extra information, not `value`: the whole training iteration (hot path + L2 loss gradient + Adam update,
+    gi2d_train_step = 4 launches, no host sync) on the same image size / gaussian count, measured after the
+    timed region."""
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    fit = NativeFitter(gt.contiguous(), n, kind="cholesky", lr=1e-3, seed=3047)
+    fit.train(40)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    fit.train(iters)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    fit.check_status()
+    return {"iters_per_s": iters / dt, "us_per_iter": dt / iters * 1e6, "num_intersects": int(fit.nth.sum().item()),
+            "what": "full training iteration incl. activations, L2 loss gradient and Adam (gi2d_train_step)"}
 
 
 def cpu_baseline(xyz, L, col, op, h, w, budget_s):

@@ -49,6 +49,9 @@ SIGNATURES.update({
     "gi2d_fast_reduce_project_backward": [_i, _i, _p, _p, _u, _u, _p, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p,
                                           _p, _p, _p, _p, _p],
     "gi2d_fast_tile_capacity": [],
+    # struct gi2d_train_state* (gaussianimage_plus_amd/trainer.py::_TrainState)
+    "gi2d_train_render": [_p, _p],
+    "gi2d_train_step": [_p, _p, _f, _f, _f, _i, _p],
 })
 SIZE_FUNCS = {
     "gi2d_fast_workspace_bytes": [_i, _i, _i],

@@ -19,82 +19,11 @@
 //
 // Capacity contract: at most GI2D_FAST_CSUB ids per (tile, sub-bucket).  A fuller bucket sets
 // status[1] and the caller must fall back to the exact path (gi2d_bin_gaussians + plain ops).
-#include "gi2d_project_core.h"
-#include "gi2d_raster_core.h"
+#include "gi2d_fast_internal.h"
 
 namespace gi2d {
 
-#define GI2D_FAST_SUB 4
-#define GI2D_FAST_CSUB 128
-#define GI2D_FAST_C (GI2D_FAST_SUB * GI2D_FAST_CSUB) /* list slots per tile */
-#define GI2D_FAST_S 16                               /* gaussian-major partial rows per gaussian */
-#define GI2D_BIG_TILES_F 32
-#define GI2D_FAST_ROW 4 /* float4 per partial row: 48 bytes of data padded to one 64-byte line */
-#define GI2D_CURSOR_STRIDE 16 /* ints between cursors: one 64-byte line each, so atomics on different cursors never share a line */
-
-static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
-struct FastWs {
-    int32_t *cursors;      // [T * SUB]          zero between calls
-    int32_t *buckets;      // [T * C]            unsorted ids per (tile, sub)
-    int32_t *gids_sorted;  // [T * C]            ascending ids per tile (stride C)
-    int32_t *tile_bins;    // [T * 2]            [t*C, t*C + len)
-    GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
-    float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
-    float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
-    size_t bytes;
-};
-static FastWs carve_fast(void *base, int n, int num_tiles) {
-    FastWs w;
-    char *b = (char *)base;
-    size_t off = 0;
-    const size_t t = (size_t)(num_tiles > 0 ? num_tiles : 1), nn = (size_t)(n > 0 ? n : 1);
-    w.cursors = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_SUB * GI2D_CURSOR_STRIDE * sizeof(int32_t));
-    w.buckets = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
-    w.gids_sorted = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
-    w.tile_bins = (int32_t *)(b + off);
-    off += align_up(t * 2 * sizeof(int32_t));
-    w.packed = (GaussRec *)(b + off);
-    off += align_up(t * GI2D_TILE_LIST_CAP * sizeof(GaussRec));
-    w.partial_g = (float4 *)(b + off);
-    off += align_up(nn * GI2D_FAST_S * GI2D_FAST_ROW * sizeof(float4));
-    w.partial_big = (float4 *)(b + off);
-    off += align_up(t * GI2D_TILE_LIST_CAP * GI2D_FAST_ROW * sizeof(float4));
-    w.bytes = off;
-    return w;
-}
-
 // ----------------------------------------------------------------------------------------- fill
-__device__ __forceinline__ void fill_one(int g, int mnx, int mny, int mxx, int mxy, int tiles_x,
-                                         int32_t *__restrict__ cursors, int32_t *__restrict__ buckets) {
-    const int sub = g & (GI2D_FAST_SUB - 1);
-    const int w = mxx - mnx, h = mxy - mny;
-    if (w <= 2 && h <= 2) {
-        // the common case (<= 4 tiles): issue all returning atomics back to back, then the stores, so the
-        // lane pays one L2 round trip instead of one per tile
-        int c[4], p[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int dj = q & 1, di = q >> 1;
-            c[q] = (dj < w && di < h) ? ((mny + di) * tiles_x + mnx + dj) * GI2D_FAST_SUB + sub : -1;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = c[q] >= 0 ? atomicAdd(&cursors[c[q] * GI2D_CURSOR_STRIDE], 1) : GI2D_FAST_CSUB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (p[q] < GI2D_FAST_CSUB) buckets[c[q] * GI2D_FAST_CSUB + p[q]] = g;
-        return;
-    }
-    for (int i = mny; i < mxy; ++i)
-        for (int j = mnx; j < mxx; ++j) {
-            const int c = (i * tiles_x + j) * GI2D_FAST_SUB + sub;
-            const int p = atomicAdd(&cursors[c * GI2D_CURSOR_STRIDE], 1);
-            if (p < GI2D_FAST_CSUB) buckets[c * GI2D_FAST_CSUB + p] = g;
-        }
-}
-
 __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__restrict__ xys,
                                                         const int32_t *__restrict__ radii, int tiles_x,
                                                         int tiles_y, float radius_clip,
@@ -147,16 +76,6 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
         tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
         fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
     }
-}
-
-// partial-row code of gaussian g in tile (tx, ty): >= 0 gaussian-major row, < 0: -(big row) - 1
-__device__ __forceinline__ int partial_slot(int g, const float2 xy, int rad, int tiles_x, int tiles_y, int tx,
-                                            int ty, int big_row) {
-    int mnx, mny, mxx, mxy;
-    tile_bbox(xy.x, xy.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-    const int w = mxx - mnx, ntiles = w * (mxy - mny);
-    if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + (ty - mny) * w + (tx - mnx);
-    return -big_row - 1;
 }
 
 // -------------------------------------------------------------------------------------- forward
@@ -314,64 +233,6 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
 }
 
 // --------------------------------------------------------------------------------------- reduce
-// acc[11] <- ordered sum of gaussian g's partial rows.  Must be called by whole waves.
-__device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restrict__ xys,
-                                           const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
-                                           float radius_clip, const int32_t *__restrict__ gids_sorted,
-                                           const int2 *__restrict__ tile_bins, int num_tiles,
-                                           const float4 *__restrict__ partial_g,
-                                           const float4 *__restrict__ partial_big, float (&acc)[11]) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int q = 0; q < 11; ++q) acc[q] = 0.f;
-    int mnx = 0, mny = 0, mxx = 0, mxy = 0;
-    bool mapped = false;
-    if (g < n) {
-        const int rad = radii[g];
-        if (rad > 0 && !((float)rad < radius_clip)) {
-            const float2 c = xys[g];
-            tile_bbox(c.x, c.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-            mapped = mxx > mnx && mxy > mny;
-        }
-    }
-    const int ntiles = mapped ? (mxx - mnx) * (mxy - mny) : 0;
-    if (mapped && ntiles <= GI2D_FAST_S) {
-        for (int k = 0; k < ntiles; ++k) add_partial<GI2D_FAST_ROW>(acc, partial_g, (size_t)g * GI2D_FAST_S + k);
-    } else if (mapped && ntiles <= GI2D_BIG_TILES_F) {
-        for (int i = mny; i < mxy; ++i)
-            for (int j = mnx; j < mxx; ++j) {
-                const int tile = i * tiles_x + j;
-                const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, g);
-                if (pos >= 0)
-                    add_partial<GI2D_FAST_ROW>(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
-            }
-    }
-    unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F);
-    while (big) {  // a gaussian on > 32 tiles: the whole wave strides over its tiles
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const int bx0 = __shfl(mnx, src, 64), by0 = __shfl(mny, src, 64);
-        const int bw = __shfl(mxx, src, 64) - bx0, bn = __shfl(ntiles, src, 64);
-        const int bg = __shfl(g, src, 64);
-        float part[11];
-#pragma unroll
-        for (int q = 0; q < 11; ++q) part[q] = 0.f;
-        for (int t = lane; t < bn; t += 64) {
-            const int tile = (by0 + t / bw) * tiles_x + bx0 + t % bw;
-            const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, bg);
-            if (pos >= 0)
-                add_partial<GI2D_FAST_ROW>(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
-        }
-#pragma unroll
-        for (int q = 0; q < 11; ++q) {
-            float v = part[q];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane == src) acc[q] = v;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void fast_reduce_kernel(
     int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
     float radius_clip, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,

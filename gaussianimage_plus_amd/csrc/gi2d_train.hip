@@ -1,0 +1,333 @@
+// One whole fitting iteration of GaussianImage++ in four launches ("fused optimizer +
+// train-step glue"), for the Cholesky and covariance models with L2 loss and Adam:
+//
+//   train_project_fill   activations (tanh / +bound: models/gaussianimage_cholesky.py:137,150) + projection +
+//                        tile bucket fill
+//   fast_fwd_kernel      (gi2d_fast.hip, unchanged)                       -> out_img (pre-clamp)
+//   train_bwd_kernel     the backward tile kernel with the loss gradient formed while staging the pixels:
+//                        v_out = 2 (clamp(out,0,1) - gt) / (3 H W) inside the clamp range, 0 outside
+//                        (models/gaussianimage_cholesky.py:220,305 + models/utils.py:65 "L2"); per-tile sum of
+//                        squared errors for the PSNR (:308-309) without a host round trip
+//   train_reduce_update  per-gaussian sum of the gradient partials + projection backward + activation
+//                        backward + torch.optim.Adam's update (single-tensor form) on xyz / cholesky / colour
+//
+// The glue the reference runs as ~25 small PyTorch kernels plus two host syncs per iteration
+// (models/gaussianimage_cholesky.py:302-317) is folded into the kernels either side of the rasterizer.
+#include "gi2d_fast_internal.h"
+
+namespace gi2d {
+
+struct TrainParams {
+    // model state (updated in place)
+    float *xyz;       // [N,2] raw (pre-tanh) for kind 0, pixel coordinates for kind 1
+    float *chol;      // [N,3] raw cholesky (kind 0) / covariance (kind 1), before the additive bound
+    float *feat;      // [N,3] colours
+    const float *opacity;  // [N]   (a buffer of ones in the reference models; not optimised)
+    const float *bound;    // [3] or [N,3]: additive bound (cholesky_bound / cov bound)
+    int bound_stride;      // 0 or 3
+    // Adam state
+    float *m_xyz, *v_xyz, *m_chol, *v_chol, *m_feat, *v_feat;
+};
+
+template <int KIND>
+__device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &mean, float (&par)[3]) {
+    const float x = P.xyz[2 * g], y = P.xyz[2 * g + 1];
+    if (KIND == kCholesky)
+        mean = make_float2(tanhf(x), tanhf(y));  // get_xyz
+    else
+        mean = make_float2(x, y);
+    const float *bd = P.bound + (size_t)P.bound_stride * g;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) par[q] = P.chol[3 * g + q] + bd[q];  // get_cholesky_elements / get_cov2d_elements
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void train_project_fill_kernel(
+    int n, float clip_coe, TrainParams P, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
+    float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
+    int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors, int32_t *__restrict__ buckets,
+    int32_t *__restrict__ status) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        status[0] = 0;
+        status[1] = 0;
+        status[2] = 0;
+        status[3] = 0;
+    }
+    if (g >= n) return;
+    float2 mean;
+    float par[3];
+    activate<KIND>(P, g, mean, par);
+    const ProjOut o = project_one<KIND>(0, clip_coe, &mean, par, nullptr, img_w, img_h, tiles_x, tiles_y, radius_clip);
+    xys[g] = o.xy;
+    radii[g] = o.radius;
+    conics[3 * g] = o.k0;
+    conics[3 * g + 1] = o.k1;
+    conics[3 * g + 2] = o.k2;
+    num_tiles_hit[g] = o.tiles_hit;
+    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
+        int mnx, mny, mxx, mxy;
+        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
+    }
+}
+
+// Pixel staging of the backward with the L2 loss gradient formed on the fly; returns this lane's squared error.
+template <bool WITH_ABS>
+__device__ __forceinline__ float bwd_stage_pixels_l2(BwdLds<WITH_ABS> &sm, int tx, int ty, int img_w, int img_h,
+                                                     const float *__restrict__ out_img,
+                                                     const float *__restrict__ gt, float grad_scale) {
+    const int tid = threadIdx.x;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
+    float v[3] = {0.f, 0.f, 0.f};
+    float sse = 0.f;
+    if (i < img_h && j < img_w) {
+        const size_t pix = (size_t)i * img_w + j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = out_img[3 * pix + c];
+            const float oc = fminf(fmaxf(o, 0.f), 1.f);           // torch.clamp(out_img, 0, 1)
+            const float d = oc - gt[3 * pix + c];
+            sse += d * d;
+            v[c] = (o >= 0.f && o <= 1.f) ? grad_scale * d : 0.f;  // clamp passes the gradient on [0, 1]
+        }
+    }
+    float *row = reinterpret_cast<float *>(&sm.pix[ly * (GI2D_TILE + 1)]) + (lx >> 1) * 8 + (lx & 1);
+    row[0] = v[0];
+    row[2] = v[1];
+    row[4] = v[2];
+    row[6] = __int_as_float(0x7fffffff);
+    return sse;
+}
+
+__global__ __launch_bounds__(256, GI2D_BWD_OCC) void train_bwd_kernel(
+    int tiles_x, int tiles_y, int img_w, int img_h, const int2 *__restrict__ tile_bins,
+    const GaussRec *__restrict__ packed, const float *__restrict__ out_img, const float *__restrict__ gt,
+    float grad_scale, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
+    float *__restrict__ tile_sse) {
+    __shared__ BwdLds<false> sm;
+    __shared__ float sse_w[4];
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int2 range = tile_bins[tile];
+    const int full_len = range.y - range.x;
+    const int len = full_len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : (full_len < 0 ? 0 : full_len);
+    float sse = bwd_stage_pixels_l2(sm, tx, ty, img_w, img_h, out_img, gt, grad_scale);
+    // per-tile sum of squared errors, fixed reduction order (bitwise reproducible)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sse += __shfl_xor(sse, d, 64);
+    if (lane == 0) sse_w[wv] = sse;
+    unsigned mask = 0;
+    int slot = 0;
+    if (tid < len) {
+        const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + tid);
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+        sm.gA[tid] = q0;
+        sm.gB[tid] = q1;
+        sm.gCb[tid] = q2.x;
+        slot = __float_as_int(q2.y);
+        mask = (unsigned)__float_as_int(q2.w);
+    }
+    float acc[9];
+    bwd_run_tile<false, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), acc);
+    if (tid == 0) tile_sse[tile] = (sse_w[0] + sse_w[1]) + (sse_w[2] + sse_w[3]);  // after >= 1 barrier
+    if (tid < len) {
+        float4 *dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot
+                                : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
+        store_partial_row(dst, acc);
+    }
+}
+
+struct AdamStep {
+    float step_size;       // lr / (1 - beta1^t)
+    float bc2_sqrt;        // sqrt(1 - beta2^t)
+    float one_minus_b1, b2, one_minus_b2, eps;
+};
+// torch/optim/adam.py::_single_tensor_adam (non-capturable, no amsgrad, no weight decay)
+__device__ __forceinline__ float adam(float p, float g, float &m, float &v, const AdamStep &a) {
+    m = m + (g - m) * a.one_minus_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.b2 + a.one_minus_b2 * (g * g);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    return p - a.step_size * (m / denom);             // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void train_reduce_update_kernel(
+    int n, TrainParams P, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
+    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
+    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads) {
+#pragma clang fp contract(off)
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc[11];
+    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
+               partial_g, partial_big, acc);
+    if (g >= n) return;
+    float2 mean;
+    float par[3];
+    activate<KIND>(P, g, mean, par);
+    ProjGrad r;
+    r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
+    r.v_mean = make_float2(0.f, 0.f);
+    if (radii[g] > 0) {
+        const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
+        const float vc[3] = {acc[2], acc[3], acc[4]};
+        r = project_bwd_one<KIND>(0, par, nullptr, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
+    }
+    // activation backward: tanh' = 1 - tanh^2 (Cholesky model), identity otherwise; the bound is a constant
+    float gx = r.v_mean.x, gy = r.v_mean.y;
+    if (KIND == kCholesky) {
+        gx = gx * (1.f - mean.x * mean.x);
+        gy = gy * (1.f - mean.y * mean.y);
+    }
+    const float gp[3] = {r.o0, r.o1, r.o2};
+    const float gf[3] = {acc[5], acc[6], acc[7]};
+    if (dbg_grads) {  // [N,8]: gradients w.r.t. the raw parameters (tests)
+        float *d = dbg_grads + 8 * (size_t)g;
+        d[0] = gx;
+        d[1] = gy;
+        d[2] = gp[0];
+        d[3] = gp[1];
+        d[4] = gp[2];
+        d[5] = gf[0];
+        d[6] = gf[1];
+        d[7] = gf[2];
+    }
+    {
+        float m0 = P.m_xyz[2 * g], m1 = P.m_xyz[2 * g + 1], v0 = P.v_xyz[2 * g], v1 = P.v_xyz[2 * g + 1];
+        P.xyz[2 * g] = adam(P.xyz[2 * g], gx, m0, v0, a_xyz);
+        P.xyz[2 * g + 1] = adam(P.xyz[2 * g + 1], gy, m1, v1, a_xyz);
+        P.m_xyz[2 * g] = m0;
+        P.m_xyz[2 * g + 1] = m1;
+        P.v_xyz[2 * g] = v0;
+        P.v_xyz[2 * g + 1] = v1;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float m = P.m_chol[3 * g + q], v = P.v_chol[3 * g + q];
+        P.chol[3 * g + q] = adam(P.chol[3 * g + q], gp[q], m, v, a_chol);
+        P.m_chol[3 * g + q] = m;
+        P.v_chol[3 * g + q] = v;
+        float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q];
+        P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
+        P.m_feat[3 * g + q] = mf;
+        P.v_feat[3 * g + q] = vf;
+    }
+}
+
+}  // namespace gi2d
+
+using namespace gi2d;
+
+extern "C" {
+
+static TrainParams params_of(const gi2d_train_state *s) {
+    TrainParams P;
+    P.xyz = s->xyz;
+    P.chol = s->chol;
+    P.feat = s->feat;
+    P.opacity = s->opacity;
+    P.bound = s->bound;
+    P.bound_stride = s->bound_stride;
+    P.m_xyz = s->m_xyz;
+    P.v_xyz = s->v_xyz;
+    P.m_chol = s->m_chol;
+    P.v_chol = s->v_chol;
+    P.m_feat = s->m_feat;
+    P.v_feat = s->v_feat;
+    return P;
+}
+
+static int train_check(const gi2d_train_state *s, int &tx, int &ty) {
+    if (!s || s->kind < 0 || s->kind > 1 || s->num_points < 0 || s->img_height <= 0 || s->img_width <= 0) {
+        set_error("train: bad state");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    tx = (s->img_width + GI2D_TILE - 1) / GI2D_TILE;
+    ty = (s->img_height + GI2D_TILE - 1) / GI2D_TILE;
+    if (!s->xyz || !s->chol || !s->feat || !s->opacity || !s->bound || !s->m_xyz || !s->v_xyz || !s->m_chol ||
+        !s->v_chol || !s->m_feat || !s->v_feat || !s->gt || !s->xys || !s->conics || !s->radii ||
+        !s->num_tiles_hit || !s->out_img || !s->tile_sse || !s->status) {
+        set_error("train: null pointer in state");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (!s->workspace || s->workspace_bytes < gi2d_fast_workspace_bytes(s->num_points, tx, ty)) {
+        set_error("train: workspace too small");
+        return GI2D_ERR_WORKSPACE_TOO_SMALL;
+    }
+    return GI2D_OK;
+}
+
+// Forward only (render): activations + projection + fill + rasterize into state->out_img.
+int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
+    int tx, ty;
+    int rc = train_check(s, tx, ty);
+    if (rc != GI2D_OK) return rc;
+    hipStream_t st = (hipStream_t)st_;
+    const int n = s->num_points;
+    if (n == 0) return GI2D_OK;
+    FastWs w = carve_fast(s->workspace, n, tx * ty);
+    const TrainParams P = params_of(s);
+    const dim3 gg((n + 255) / 256), bb(256);
+    if (s->kind == 0)
+        hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
+                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
+                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+    else
+        hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
+                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
+                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+    return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys, s->radii,
+                                       s->conics, s->feat, s->opacity, nullptr, s->workspace, s->workspace_bytes,
+                                       s->status, nullptr, nullptr, s->out_img, st_);
+}
+
+// One full iteration: render, L2 loss gradient + backward, Adam update.  lr[3] / step are host values:
+// learning rates of the xyz / cholesky / colour groups for THIS step and the 1-based Adam step count.
+int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps, int step,
+                    gi2d_stream_t st_) {
+    int rc = gi2d_train_render(s, st_);
+    if (rc != GI2D_OK) return rc;
+    int tx, ty;
+    train_check(s, tx, ty);
+    hipStream_t st = (hipStream_t)st_;
+    const int n = s->num_points;
+    if (n == 0 || !lr || step < 1) {
+        if (n == 0) return GI2D_OK;
+        set_error("train step: bad lr/step");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(s->workspace, n, tx * ty);
+    const TrainParams P = params_of(s);
+    const float grad_scale = 2.f / (3.f * (float)s->img_height * (float)s->img_width);
+    hipLaunchKernelGGL(train_bwd_kernel, dim3((unsigned)(tx * ty)), dim3(256), 0, st, tx, ty, s->img_width,
+                       s->img_height, (const int2 *)w.tile_bins, w.packed, s->out_img, s->gt, grad_scale, w.partial_g,
+                       w.partial_big, s->tile_sse);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamStep a[3];
+    for (int q = 0; q < 3; ++q) {
+        a[q].step_size = (float)((double)lr[q] / bc1);
+        a[q].bc2_sqrt = (float)sqrt(bc2);
+        a[q].one_minus_b1 = (float)(1.0 - (double)beta1);
+        a[q].b2 = beta2;
+        a[q].one_minus_b2 = (float)(1.0 - (double)beta2);
+        a[q].eps = eps;
+    }
+    const dim3 gg((n + 255) / 256), bb(256);
+    if (s->kind == 0)
+        hipLaunchKernelGGL(train_reduce_update_kernel<kCholesky>, gg, bb, 0, st, n, P, (const float2 *)s->xys,
+                           s->radii, s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins,
+                           w.partial_g, w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2],
+                           s->dbg_grads);
+    else
+        hipLaunchKernelGGL(train_reduce_update_kernel<kCovariance>, gg, bb, 0, st, n, P, (const float2 *)s->xys,
+                           s->radii, s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins,
+                           w.partial_g, w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2],
+                           s->dbg_grads);
+    return check_launch("train step");
+}
+
+}  // extern "C"

@@ -60,10 +60,34 @@ def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, floa
 
 
 # ----------------------------------------------------------------------------------- per-image loop
+def fit_image_native(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float = 1e-3, seed: int = 3047,
+                     eval_renders: int = 10, kind: str = "cholesky") -> Dict[str, float]:
+    """The same loop on the fused training iteration (trainer.NativeFitter -> gi2d_train_step): one C-ABI call,
+    four kernel launches and no host synchronisation per iteration."""
+    from .trainer import NativeFitter
+
+    dev = gt_hwc.device
+    fit = NativeFitter(gt_hwc, num_points, kind=kind, lr=lr, seed=seed)
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    fit.train(iterations)
+    torch.cuda.synchronize(dev)
+    train_s = time.time() - t0
+    fit.check_status()
+    t0 = time.time()
+    for _ in range(eval_renders):
+        img = fit.render()
+    torch.cuda.synchronize(dev)
+    eval_s = (time.time() - t0) / max(eval_renders, 1)
+    mse = torch.nn.functional.mse_loss(img, fit.gt).item()
+    return {"psnr": 10 * math.log10(1.0 / max(mse, 1e-12)), "train_s": train_s, "eval_s": eval_s,
+            "num_gaussians": num_points, "mse": mse}
+
+
 def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float = 1e-3, seed: int = 3047,
               eval_renders: int = 10) -> Dict[str, float]:
     """Cholesky model, L2 loss, Adam (models/gaussianimage_cholesky.py:57-58,80-82,302-317 with
-    opt_type="adam").  gt_hwc: float32 [H, W, 3] in [0, 1] on the target GPU."""
+    opt_type="adam") through the autograd wrappers.  gt_hwc: float32 [H, W, 3] in [0, 1] on the target GPU."""
     from .gsplat.project_gaussians_2d import project_gaussians_2d
     from .gsplat.rasterize_sum_plus import rasterize_gaussians_plus
 
@@ -142,6 +166,8 @@ def main(argv=None):
     ap.add_argument("--iterations", type=int, default=2000)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=3047)
+    ap.add_argument("--loop", choices=["native", "autograd"], default="native",
+                    help="native: fused training iteration (gi2d_train_step); autograd: gsplat wrappers + torch Adam")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,7 +184,8 @@ def main(argv=None):
     images = load_images(args.dataset, args.synthetic, args.height, args.width)
 
     def fit_one(i, img):
-        r = fit_image(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed)
+        fit = fit_image_native if args.loop == "native" else fit_image
+        r = fit(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed)
         print(f"[rank {rank}] image {i}: {img.shape[0]}x{img.shape[1]}, PSNR:{r['psnr']:.4f}, "
               f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}", flush=True)
         return r

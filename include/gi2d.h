@@ -288,6 +288,45 @@ int gi2d_fast_reduce_project_backward(int kind, int num_points, const float *p0,
                                       float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
                                       gi2d_stream_t stream);
 
+/* ------------------------------------------------------------------ fused fitting iteration
+ * SURVEY 8f rank 2 (callers either side of the path): one whole training iteration of the
+ * Cholesky (kind 0) or covariance (kind 1) model with L2 loss and Adam --
+ * models/gaussianimage_cholesky.py:302-317 / models/gaussianimage_covariance.py:249-259 --
+ * in four launches: activations+projection+fill, rasterize forward, backward with the loss
+ * gradient formed while staging pixels, gradient reduce + projection backward + activation
+ * backward + torch.optim.Adam update.  All pointers are device pointers owned by the caller.
+ *   xyz   f32[N,2]  raw positions (kind 0: pre-tanh; kind 1: pixels)      updated in place
+ *   chol  f32[N,3]  raw Cholesky / covariance triple (bound is added)     updated in place
+ *   feat  f32[N,3]  colours                                              updated in place
+ *   opacity f32[N] (not optimised), bound f32[3] (bound_stride 0) or f32[N,3] (bound_stride 3)
+ *   m_*, v_*        Adam moments, same shapes as the parameters           updated in place
+ *   gt    f32[H,W,3] target image; out_img f32[H,W,3] last render (pre-clamp)
+ *   tile_sse f32[tiles] per-tile sum of squared errors of clamp(out_img) vs gt (for PSNR)
+ *   xys/conics/radii/num_tiles_hit: projection outputs of the last render
+ *   status i32[4], workspace: as for the fast path (gi2d_fast_workspace_bytes/_init)
+ *   dbg_grads f32[N,8] or NULL: gradients w.r.t. (xyz, chol, feat) of the last step (tests)
+ * gi2d_train_step(state, lr[3], beta1, beta2, eps, step): lr = learning rates of the
+ * (xyz, chol, feat) groups for this step, step = 1-based Adam step count. */
+typedef struct gi2d_train_state {
+    int kind, num_points, img_height, img_width;
+    float clip_coe, radius_clip;
+    float *xyz, *chol, *feat;
+    const float *opacity, *bound;
+    int bound_stride, pad0;
+    float *m_xyz, *v_xyz, *m_chol, *v_chol, *m_feat, *v_feat;
+    const float *gt;
+    float *xys, *conics;
+    int32_t *radii, *num_tiles_hit;
+    float *out_img, *tile_sse;
+    int32_t *status;
+    void *workspace;
+    size_t workspace_bytes;
+    float *dbg_grads;
+} gi2d_train_state;
+int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
+int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
+                    float eps, int step, gi2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
