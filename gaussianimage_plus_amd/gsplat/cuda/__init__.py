@@ -258,6 +258,57 @@ def rasterize_backward_fast(img_height, img_width, gaussian_ids_sorted, tile_bin
     return v_xy, v_conic, v_colors, v_opacity, v_abs
 
 
+# ------------------------------------------------------------------------------- fused fast path
+class FastWorkspace:
+    """A workspace of the fused fast path (include/gi2d.h "fused fast path"): allocated and initialised once,
+    then reused by every forward/backward pair of the same problem shape."""
+
+    def __init__(self, num_points, tile_bounds, like):
+        self.n, self.tx, self.ty = int(num_points), int(tile_bounds[0]), int(tile_bounds[1])
+        nbytes = _lib.load().gi2d_fast_workspace_bytes(self.n, self.tx, self.ty)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
+        self.status = torch.zeros(4, dtype=torch.int32, device=like.device)
+        with torch.cuda.device(like.device):
+            _lib.call("gi2d_fast_workspace_init", self.buf.data_ptr(), nbytes, self.n, self.tx, self.ty, _stream(like))
+
+
+def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_width, radius_clip):
+    """gi2d_fast_bin + gi2d_fast_rasterize_forward -> out_img[H,W,3]; ws.status = {any intersection, overflow}."""
+    for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (opacities, "opacities")):
+        _chk(t, nm, torch.float32)
+    _chk(radii, "radii", torch.int32)
+    h, w = int(img_height), int(img_width)
+    out_img = _f32(h, w, 3, like=xys)
+    with torch.cuda.device(xys.device):
+        st = _stream(xys)
+        _lib.call("gi2d_fast_bin", ws.n, xys.data_ptr(), radii.data_ptr(), ws.tx, ws.ty, float(radius_clip),
+                  ws.buf.data_ptr(), ws.buf.numel(), ws.status.data_ptr(), st)
+        _lib.call("gi2d_fast_rasterize_forward", ws.n, ws.tx, ws.ty, w, h, xys.data_ptr(), radii.data_ptr(),
+                  conics.data_ptr(), colors.data_ptr(), opacities.data_ptr(), None, ws.buf.data_ptr(), ws.buf.numel(),
+                  ws.status.data_ptr(), None, None, out_img.data_ptr(), st)
+    return out_img
+
+
+def fast_backward(ws, xys, radii, v_output, img_height, img_width, radius_clip, with_abs=False):
+    """gi2d_fast_rasterize_backward_tiles + _reduce on the workspace the forward filled.
+    -> (v_xy, v_conic, v_colors, v_opacity[N,1], v_abs_xys|None)"""
+    _chk(xys, "xys", torch.float32)
+    _chk(radii, "radii", torch.int32)
+    _chk(v_output, "v_output", torch.float32)
+    n = ws.n
+    v_xy, v_conic = _f32(n, 2, like=xys), _f32(n, 3, like=xys)
+    v_colors, v_opacity = _f32(n, 3, like=xys), _f32(n, 1, like=xys)
+    v_abs = _f32(n, 4, like=xys) if with_abs else None
+    with torch.cuda.device(xys.device):
+        st = _stream(xys)
+        _lib.call("gi2d_fast_rasterize_backward_tiles", n, ws.tx, ws.ty, int(img_width), int(img_height), None,
+                  v_output.data_ptr(), 1 if with_abs else 0, ws.buf.data_ptr(), ws.buf.numel(), st)
+        _lib.call("gi2d_fast_rasterize_backward_reduce", n, xys.data_ptr(), radii.data_ptr(), ws.tx, ws.ty,
+                  float(radius_clip), ws.buf.data_ptr(), ws.buf.numel(), v_xy.data_ptr(), v_conic.data_ptr(),
+                  v_colors.data_ptr(), v_opacity.data_ptr(), _ptr(v_abs), st)
+    return v_xy, v_conic, v_colors, v_opacity, v_abs
+
+
 # ------------------------------------------------------------------------------- rasterizer
 def _check_block(block):
     if int(block[0]) != _TILE or int(block[1]) != _TILE:

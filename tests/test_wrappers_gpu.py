@@ -129,3 +129,45 @@ def test_wrapper_errors(gs):
                                     None, 16, 16, background=torch.ones(4, device=DEV))
     with pytest.raises(NotImplementedError):
         gs.spherical_harmonics(3, None, None)
+
+
+def test_bucket_overflow_falls_back_to_the_capacity_free_ops(gs, oracle):
+    """700 gaussians in two tiles overflow the fast path's buckets; the wrapper must notice and redo the work on
+    the exact ops, forward and backward, with the reference's 256-entry cap semantics intact."""
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "case_chol_crowded.npz"))
+    h, w, npts = int(g["h"]), int(g["w"]), int(g["n"])
+    tb = oracle.tile_bounds(h, w)
+    x_t = torch.from_numpy(g["in_means"]).to(DEV).requires_grad_(True)
+    L_t = torch.from_numpy(g["in_L"]).to(DEV).requires_grad_(True)
+    c_t = torch.from_numpy(g["colors"]).to(DEV).requires_grad_(True)
+    o_t = torch.from_numpy(g["opacity"]).to(DEV)
+    xys, depths, radii, conics, nth = gs.project_gaussians_2d(x_t, L_t, h, w, tb)
+    img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, c_t, o_t, h, w, background=torch.ones(3, device=DEV))
+    ok = np.repeat((g["pix_ambig"] == 0)[..., None], 3, -1)
+    check_close("overflow out_img", img.detach().cpu().numpy(), g["out_img"], g["pix_abs"], mask=ok, rtol=3e-5)
+    (img * torch.from_numpy(g["v_out"]).to(DEV)).sum().backward()
+    okg = np.repeat((g["g_ambig"] == 0)[:, None], 3, 1)
+    check_close("overflow v_rgb", c_t.grad.cpu().numpy(), g["v_rgb"], g["g_abs9"][:, 5:8], mask=okg, rtol=3e-5, atol=1e-12)
+
+
+def test_no_grad_render_and_training_forward_can_interleave(gs, oracle):
+    """A no-grad render between a training forward and its backward must not disturb the saved workspace."""
+    npts, h, w = 1200, 64, 96
+    xyz, L, col, op = synth_cholesky(npts, h, w, 31)
+    tb = oracle.tile_bounds(h, w)
+    t = lambda a, g=False: torch.from_numpy(a).to(DEV).requires_grad_(g)
+    x_t, L_t, c_t, o_t = t(xyz), t(L), t(col, True), t(op)
+    bg = torch.ones(3, device=DEV)
+
+    def fwd(colors):
+        xys, depths, radii, conics, nth = gs.project_gaussians_2d(x_t, L_t, h, w, tb)
+        return gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, colors, o_t, h, w, background=bg)
+
+    img = fwd(c_t)
+    with torch.no_grad():
+        other = fwd(torch.rand_like(c_t))  # different colours: would corrupt the packed records if shared
+    img.sum().backward()
+    g1 = c_t.grad.clone()
+    c_t.grad = None
+    fwd(c_t).sum().backward()
+    assert torch.equal(g1, c_t.grad) and not torch.equal(other, img)
