@@ -25,13 +25,14 @@ _KINDS = {"cholesky": 0, "covariance": 1, "scale_rot": 2}
 _PROJ = {
     "cholesky": ("gi2d_project_gaussians_2d_forward", "gi2d_project_gaussians_2d_backward"),
     "covariance": ("gi2d_project_gaussians_2d_covariance_forward", "gi2d_project_gaussians_2d_covariance_backward"),
+    "scale_rot": ("gi2d_project_gaussians_2d_scale_rot_forward", "gi2d_project_gaussians_2d_scale_rot_backward"),
 }
 
 
 class HotPath:
     def __init__(self, num_points: int, height: int, width: int, device, kind: str = "cholesky",
                  mode: str = "fused", clip_coe: float = 3.0, radius_clip: float = 1.0):
-        assert kind in _PROJ, "HotPath drives the Cholesky and covariance models"
+        assert kind in _PROJ
         assert mode in ("fused", "exact")
         self.lib = _lib.load()
         self.n, self.h, self.w, self.kind, self.mode = int(num_points), int(height), int(width), kind, mode
@@ -42,7 +43,8 @@ class HotPath:
         n, h, w, dev = self.n, self.h, self.w, self.dev
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)
-        self.means, self.params = f32(n, 2), f32(n, 3)
+        self.means, self.params = f32(n, 2), f32(n, 2 if kind == "scale_rot" else 3)
+        self.rot, self.v_rot = f32(n, 1), f32(n, 1)  # scale_rot only
         self.colors, self.opac = f32(n, 3), f32(n, 1)
         self.background = torch.ones(3, dtype=torch.float32, device=dev)
         self.xys, self.depths, self.radii, self.conics, self.nth = f32(n, 2), f32(n), i32(n), f32(n, 3), i32(n)
@@ -50,7 +52,7 @@ class HotPath:
         self.out_img, self.final_idx = f32(h, w, 3), i32(h, w)
         self.v_out = f32(h, w, 3)
         self.v_xy, self.v_conic, self.v_rgb, self.v_opac = f32(n, 2), f32(n, 3), f32(n, 3), f32(n, 1)
-        self.v_cov2d, self.v_mean2d, self.v_params = f32(n, 3), f32(n, 2), f32(n, 3)
+        self.v_cov2d, self.v_mean2d, self.v_params = f32(n, 3), f32(n, 2), f32(n, 2 if kind == "scale_rot" else 3)
         # fused-path workspace (cursors zeroed once; every forward leaves them zero)
         nbytes = self.lib.gi2d_fast_workspace_bytes(n, self.tx, self.ty)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -69,8 +71,10 @@ class HotPath:
         n, h, w, tx, ty, k = self.n, self.h, self.w, self.tx, self.ty, _KINDS[self.kind]
         L = self.lib
         ws, wsb = p(self.ws), self.ws.numel()
+        rot = p(self.rot) if self.kind == "scale_rot" else None
+        v_rot = p(self.v_rot) if self.kind == "scale_rot" else None
         self._f_bin = (L.gi2d_fast_project_bin, "fast project+bin",
-                       [k, n, self.clip_coe, p(self.means), p(self.params), None, h, w, tx, ty, self.radius_clip,
+                       [k, n, self.clip_coe, p(self.means), p(self.params), rot, h, w, tx, ty, self.radius_clip,
                         p(self.xys), p(self.depths), p(self.radii), p(self.conics), p(self.nth), ws, wsb,
                         p(self.status)])
         self._f_fwd = (L.gi2d_fast_rasterize_forward, "fast rasterize forward",
@@ -79,9 +83,9 @@ class HotPath:
         self._f_tiles = (L.gi2d_fast_rasterize_backward_tiles, "fast rasterize backward tiles",
                          [n, tx, ty, w, h, None, p(self.v_out), 0, ws, wsb])
         self._f_red = (L.gi2d_fast_reduce_project_backward, "fast reduce+project backward",
-                       [k, n, p(self.params), None, h, w, p(self.xys), p(self.radii), p(self.conics), tx, ty,
+                       [k, n, p(self.params), rot, h, w, p(self.xys), p(self.radii), p(self.conics), tx, ty,
                         self.radius_clip, ws, wsb, p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,
-                        p(self.v_cov2d), p(self.v_mean2d), p(self.v_params), None])
+                        p(self.v_cov2d), p(self.v_mean2d), p(self.v_params), v_rot])
 
     def _build_exact_calls(self, capacity: int):
         p = lambda t: t.data_ptr()
@@ -95,10 +99,12 @@ class HotPath:
         self.final_Ts = torch.zeros(h, w, dtype=torch.float32, device=dev)
         self.ws_bin = torch.zeros(L.gi2d_bin_workspace_bytes(self.capacity, self.T), dtype=torch.uint8, device=dev)
         fwd_name, bwd_name = _PROJ[self.kind]
+        sr = self.kind == "scale_rot"
         self._e_fwd = [
             (getattr(L, fwd_name), "project forward",
-             [n, self.clip_coe, p(self.means), p(self.params), h, w, tx, ty, 0.01, self.radius_clip, p(self.xys),
-              p(self.depths), p(self.radii), p(self.conics), p(self.nth)]),
+             [n, self.clip_coe, p(self.means), p(self.params)] + ([p(self.rot)] if sr else []) +
+             [h, w, tx, ty, 0.01, self.radius_clip, p(self.xys), p(self.depths), p(self.radii), p(self.conics),
+              p(self.nth)]),
             (L.gi2d_bin_gaussians, "bin_gaussians",
              [n, self.capacity, p(self.xys), p(self.radii), tx, ty, self.radius_clip, p(self.gids_sorted),
               p(self.tile_bins), p(self.status), p(self.ws_bin), self.ws_bin.numel()]),
@@ -115,8 +121,9 @@ class HotPath:
              [n, p(self.xys), p(self.radii), tx, ty, self.radius_clip, p(self.gids_sorted), p(self.tile_bins),
               self.T, p(self.partials), p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None]),
             (getattr(L, bwd_name), "project backward",
-             [n, p(self.means), p(self.params), h, w, p(self.radii), p(self.conics), p(self.v_xy), None,
-              p(self.v_conic), p(self.v_cov2d), p(self.v_mean2d), p(self.v_params)]),
+             [n, p(self.means), p(self.params)] + ([p(self.rot)] if sr else []) +
+             [h, w, p(self.radii), p(self.conics), p(self.v_xy), None, p(self.v_conic), p(self.v_cov2d),
+              p(self.v_mean2d), p(self.v_params)] + ([p(self.v_rot)] if sr else [])),
         ]
         self._exact_ready = True
 
@@ -130,10 +137,14 @@ class HotPath:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     # ------------------------------------------------------------------ inputs
-    def set_inputs(self, means, params, colors, opac):
-        """means: tanh(xyz) in (-1,1) for "cholesky" / pixel coordinates for "covariance"; params: the
-        activated Cholesky (or covariance) triple; colors [N,3]; opacity [N,1]."""
-        for dst, src in ((self.means, means), (self.params, params), (self.colors, colors), (self.opac, opac)):
+    def set_inputs(self, means, params, colors, opac, rot=None):
+        """means: tanh(xyz) in (-1,1) for "cholesky" / pixel coordinates otherwise; params: the activated
+        Cholesky or covariance triple, or the [N,2] scales (+ rot [N,1]) for "scale_rot"; colors [N,3];
+        opacity [N,1]."""
+        pairs = [(self.means, means), (self.params, params), (self.colors, colors), (self.opac, opac)]
+        if rot is not None:
+            pairs.append((self.rot, rot))
+        for dst, src in pairs:
             dst.copy_(torch.as_tensor(np.ascontiguousarray(src) if isinstance(src, np.ndarray) else src).to(self.dev))
 
     def set_v_out(self, v_out: torch.Tensor):

@@ -149,3 +149,73 @@ def test_graph_replay_matches_eager():
     hp.check_status()
     for a, b in zip(want, (hp.out_img, hp.v_params, hp.v_mean2d, hp.v_rgb)):
         assert torch.equal(a, b)
+
+
+def test_scale_rot_kind_at_config5_size(oracle):
+    """BASELINE.json config 5 geometry: rotation-scale model, 30 000 gaussians, 768x512 (activations as in
+    models/gaussianimage_rs.py:167,172: scale = |s + 0.5|, rot = sigmoid(r) * 2 pi)."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n, h, w = 30000, 512, 768
+    rng = np.random.default_rng(30)
+    mean_px = (rng.random((n, 2)) * np.array([w, h])).astype(np.float32)
+    scales = np.abs(rng.random((n, 2)) + 0.5).astype(np.float32)
+    rot = (1 / (1 + np.exp(-rng.random((n, 1)))) * 2 * np.pi).astype(np.float32)
+    col = rng.random((n, 3)).astype(np.float32)
+    op = np.ones((n, 1), np.float32)
+    v = _v_out(h, w, 5)
+    res = []
+    for mode in ("fused", "exact"):
+        hp = HotPath(n, h, w, device=DEV, mode=mode, kind="scale_rot")
+        hp.set_inputs(mean_px, scales, col, op, rot=rot)
+        img = hp.forward().clone()
+        hp.set_v_out(v)
+        hp.backward()
+        hp.check_status()
+        res.append((img, hp.v_mean2d.clone(), hp.v_params.clone(), hp.v_rot.clone(), hp.v_rgb.clone(), hp.xys.clone(),
+                    hp.conics.clone(), hp.radii.clone(), hp.nth.clone(), hp.v_xy.clone(), hp.v_conic.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # against the oracle: projection, then rasterizer + projection backward on the device's projection
+    tb = oracle.tile_bounds(h, w)
+    po = oracle.project_gaussians_2d_scale_rot_forward(n, 3.0, mean_px, scales, rot, h, w, tb, 0.01, 1.0)
+    d_xys, d_conics, d_radii, d_nth = [t.cpu().numpy() for t in (res[0][5], res[0][6], res[0][7], res[0][8])]
+    same = (d_radii == po[2]) & (d_nth == po[4])
+    assert same.mean() > 0.999
+    cs = np.abs(po[3][same]).max(axis=-1, keepdims=True)
+    check_close("rs conics", d_conics[same], po[3][same], cs, rtol=4e-5)
+    m, cum = oracle.compute_cumulative_intersects(d_nth)
+    _, _, so, go, bins = oracle.bin_and_sort_gaussians(n, m, d_xys, np.zeros(n, np.float32), d_radii, cum, tb, 1.0)
+    out_o, fT, fidx, amb, absimg = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, d_xys, d_conics,
+                                                                col, op, with_aux=True)
+    check_close("rs out_img", res[0][0].cpu().numpy(), out_o, absimg, mask=np.repeat((amb == 0)[..., None], 3, -1))
+    pb = oracle.project_gaussians_2d_scale_rot_backward(n, mean_px, scales, rot, h, w, d_radii, d_conics,
+                                                        res[0][9].cpu().numpy(), None, res[0][10].cpu().numpy())
+    for got, want, nm in ((res[0][2], pb[2], "v_scale"), (res[0][3], pb[3], "v_rot"), (res[0][1], pb[1], "v_mean")):
+        sc = np.abs(want).max(axis=-1, keepdims=True) + 1e-30
+        check_close("rs " + nm, got.cpu().numpy().reshape(want.shape), want, sc, rtol=1e-4, max_bad_frac=1e-4)
+
+
+def test_2k_image_config4_size_properties():
+    """BASELINE.json config 4 geometry: 50 000 gaussians on a 2040x1356 image (10 880 tiles, ragged edges):
+    fused == exact bitwise, linear in colour, <v_out, out(c)> == <v_rgb, c>."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n, h, w = 50000, 1356, 2040
+    xyz, L, col, op = synth_cholesky(n, h, w, 44)
+    v = _v_out(h, w, 6)
+    res = []
+    for mode in ("fused", "exact"):
+        hp = HotPath(n, h, w, device=DEV, mode=mode)
+        hp.set_inputs(xyz, L, col, op)
+        img = hp.forward().clone()
+        hp.set_v_out(v)
+        hp.backward()
+        hp.check_status()
+        res.append((img, hp.v_rgb.clone(), hp.v_params.clone(), hp.v_mean2d.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    hp.set_inputs(xyz, L, 2 * col, op)
+    img2 = hp.forward()
+    assert torch.allclose(img2, 2 * res[0][0], rtol=1e-6, atol=1e-7)
+    lhs = float((v.double() * res[0][0].double()).sum())
+    rhs = float((res[0][1].double() * torch.from_numpy(col).to(DEV).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs)) + 1e-9
