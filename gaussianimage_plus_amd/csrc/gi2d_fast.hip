@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
         const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
         if (rank < GI2D_TILE_LIST_CAP) {
-            const unsigned mask = strip_mask(r, tx0, ty0, img_h);
-            fwd_stage_entry(sm.f, rank, r, mask);
+            const unsigned mask = cull_word(r, tx0, ty0, img_h);
+            fwd_stage_entry(sm.f, rank, r, mask & 15u);
             float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
             dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
             dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);

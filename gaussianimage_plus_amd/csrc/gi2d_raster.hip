@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     // dependent global loads), and records which 4-row strips each gaussian can reach
     if (tid < len) {
         const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
-        fwd_stage_entry(sm, tid, r, strip_mask(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h));
+        fwd_stage_entry(sm, tid, r, cull_word(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h) & 15u);
     }
     if (tid == 0) fwd_stage_dummy(sm);
     __syncthreads();
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void raster_bwd_k
     if (tid < len) {
         const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
         bwd_stage_entry(sm, tid, r);
-        mask = strip_mask(r, tx0, ty0, img_h);
+        mask = cull_word(r, tx0, ty0, img_h);
     }
     float acc[BwdLds<WITH_ABS>::PSTR];
     bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, tx0, ty0, acc);

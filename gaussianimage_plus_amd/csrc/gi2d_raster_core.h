@@ -40,18 +40,23 @@ __device__ __forceinline__ GaussRec load_gaussian(int g, const float2 *__restric
     return r;
 }
 
-// Which of the tile's four 4-row strips can the gaussian reach with alpha >= 1/255?
-__device__ __forceinline__ unsigned strip_mask(const GaussRec &r, float tx0, float ty0, int img_h) {
+// Where inside a tile can the gaussian reach alpha >= 1/255?  Packed "cull word":
+//   bits 0-3   the 4-row strips it reaches (forward: one wave per strip)
+//   bits 8-11  first row r0, bits 12-15 last row r1, bits 16-19 first pixel pair q0, bits 20-23 last pair q1
+//   (rows / pairs of the 16x16 tile, from the conservative box of gi2d_common.h::cull_box, clipped to the
+//   image height); 0 when it reaches nothing.  Evaluating more pixels than necessary never changes a
+//   result (they fail the alpha test); the box guarantees none that passes is left out.
+__device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, float ty0, int img_h) {
     CullBox box;
-    unsigned mask = 0;
-    if (cull_box(r.gx, r.gy, r.a, r.b, r.c, r.opac, box) && box.x1 >= tx0 && box.x0 <= tx0 + 15.f) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float y0 = ty0 + 4.f * s4;
-            mask |= (box.y1 >= y0 && box.y0 <= y0 + 3.f && y0 < (float)img_h) ? (1u << s4) : 0u;
-        }
-    }
-    return mask;
+    if (!cull_box(r.gx, r.gy, r.a, r.b, r.c, r.opac, box)) return 0u;
+    const float last_row = fminf(15.f, (float)(img_h - 1) - ty0);
+    const float r0f = fmaxf(ceilf(box.y0 - ty0), 0.f), r1f = fminf(floorf(box.y1 - ty0), last_row);
+    const float c0f = fmaxf(ceilf(box.x0 - tx0), 0.f), c1f = fminf(floorf(box.x1 - tx0), 15.f);
+    if (!(r1f >= r0f) || !(c1f >= c0f)) return 0u;
+    const unsigned r0 = (unsigned)r0f, r1 = (unsigned)r1f, q0 = (unsigned)c0f >> 1, q1 = (unsigned)c1f >> 1;
+    unsigned strips = 0;
+    for (unsigned s4 = r0 >> 2; s4 <= (r1 >> 2); ++s4) strips |= 1u << s4;
+    return strips | (r0 << 8) | (r1 << 12) | (q0 << 16) | (q1 << 20);
 }
 
 // =========================================================================================== forward
@@ -250,12 +255,13 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 }
 
 // ========================================================================================== backward
-// Work item = (gaussian k, 4-row strip s) for the strips the gaussian's alpha>=1/255 box reaches: one
-// lane walks the strip's 4 x 16 pixels two at a time with packed fp32 (v_pk_fma_f32 & co), keeping
-// every running sum in registers.  Per row the conic/xy gradients follow from three sums
+// Work item = (gaussian k, row pair p) for the pixel rows 2p, 2p+1 the gaussian's alpha>=1/255 box reaches:
+// one lane walks those rows over the box's pixel-pair range only (small gaussians touch ~8 of a row's 16
+// pixels) two pixels at a time with packed fp32 (v_pk_fma_f32 & co), keeping every running sum in
+// registers.  Per row the conic/xy gradients follow from three sums
 //   S0 = sum w, S1 = sum w dx, S2 = sum w dx^2,  w = opac*vis*v_alpha = -v_sigma  (backward.cu:948)
-// because dy is constant along a row.  A gaussian owns at most 4 items, so the hand-off to the lane
-// that owns the gaussian is at most 4 LDS rows.
+// because dy is constant along a row.  A gaussian owns at most 8 items; their partials are handed to the
+// lane that owns the gaussian through LDS and added in row order.
 #define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
 #ifndef GI2D_BWD_OCC
 #define GI2D_BWD_OCC 6 /* waves per SIMD the register allocator must leave room for (6 workgroups/CU) */
@@ -273,8 +279,9 @@ struct BwdLds {
     float4 gB[GI2D_TILE_LIST_CAP];  // c, opac, cr, cg
     float gCb[GI2D_TILE_LIST_CAP];  // cb
     unsigned short off[GI2D_TILE_LIST_CAP + 2];     // exclusive prefix of items per gaussian
-    unsigned short item[4 * GI2D_TILE_LIST_CAP];    // k | strip << 8
+    unsigned short item[8 * GI2D_TILE_LIST_CAP];    // k | row pair << 8
     float part[GI2D_BWD_ITEMS * PSTR];
+    unsigned short xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | q0 << 8 | q1 << 12 per gaussian
     int wsum[4];
 };
 
@@ -309,7 +316,7 @@ __device__ __forceinline__ void bwd_stage_entry(BwdLds<WITH_ABS> &sm, int k, con
 }
 
 // After pixels and the first `len` gaussians are staged (no barrier needed before the call): builds the
-// item list from each lane's strip mask, runs the items, and leaves in acc[] (lanes tid < len) the
+// item list from each lane's cull word (cull_word()), runs the items, and leaves in acc[] (lanes tid < len) the
 // gradient partial of gaussian `tid` for this tile:
 //   acc = (v_x, v_y, v_conic[3], v_rgb[3], v_opacity [, sum|v_x|, sum|v_y|]).
 // `list_base` + k is the entry's position in the sorted list (compared with final_idx, backward.cu:903).
@@ -317,12 +324,15 @@ __device__ __forceinline__ void bwd_stage_entry(BwdLds<WITH_ABS> &sm, int k, con
 // instructions, so "idx <= final_idx" is implied by the alpha test and is not re-checked (pixels outside the
 // image still carry v_out = 0 and contribute nothing).
 template <bool WITH_ABS, bool USE_FIDX = true>
-__device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsigned mask, int list_base,
+__device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsigned cull, int list_base,
                                              float tx0, float ty0, float (&acc)[BwdLds<WITH_ABS>::PSTR]) {
     constexpr int PSTR = BwdLds<WITH_ABS>::PSTR;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
-        const int nitems = __popc(mask);
+        // row pairs this gaussian reaches: p0..p1; its pixel-pair range rides along in sm.xr
+        const int p0 = (int)((cull >> 9) & 7u), p1 = (int)((cull >> 13) & 7u);
+        const int nitems = (cull & 15u) ? (p1 - p0 + 1) : 0;
+        if (tid < len) sm.xr[tid] = (cull >> 8) & 0xffffu;  // r0 | r1 << 4 | q0 << 8 | q1 << 12
         const int incl = wave_inclusive_scan(nitems);
         if (lane == 63) sm.wsum[wv] = incl;
         __syncthreads();
@@ -331,12 +341,7 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
         int excl = base + incl - nitems;
         if (tid < len) sm.off[tid] = (unsigned short)excl;
         if (tid == 255) sm.off[len] = (unsigned short)(excl + nitems);  // lanes >= len carry 0 items
-        unsigned m = mask;
-        while (m) {
-            const int s4 = __ffs(m) - 1;
-            m &= m - 1;
-            sm.item[excl++] = (unsigned short)(tid | (s4 << 8));
-        }
+        for (int p = 0; p < nitems; ++p) sm.item[excl++] = (unsigned short)(tid | ((p0 + p) << 8));
     }
     __syncthreads();
     const int n_items = sm.off[len];
@@ -354,7 +359,10 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
         const int it = round0 + tid;
         if (it < round1) {
             const unsigned code = sm.item[it];
-            const int k = code & 255, s4 = code >> 8;
+            const int k = code & 255, rp = code >> 8;
+            const unsigned xr = sm.xr[k];
+            const int row_lo = max(2 * rp, (int)(xr & 15u)), row_hi = min(2 * rp + 1, (int)((xr >> 4) & 15u));
+            const int q_lo = (int)((xr >> 8) & 15u), q_hi = (int)((xr >> 12) & 15u);
             const float4 A = sm.gA[k], B = sm.gB[k];
             const float cb = sm.gCb[k];
             const float gx = A.x, gy = A.y, a = A.z, b = A.w, c = B.x, opac = B.y;
@@ -365,22 +373,21 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
             float vx = 0.f, vy = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, gop = 0.f;
             v2f gr = {0.f, 0.f}, gg = {0.f, 0.f}, gb = {0.f, 0.f}, ax = {0.f, 0.f}, ay = {0.f, 0.f};
 #ifdef GI2D_ABLATE_BWD_COMPUTE
-            const int rows_to_do = (n_items < 0) ? 4 : 0;  // timing experiment: skip the pixel loop
+            const int row_end = (n_items < 0) ? row_hi : row_lo - 1;  // timing experiment: skip the pixel loop
 #else
-            const int rows_to_do = 4;
+            const int row_end = row_hi;
 #endif
 #pragma unroll 1
-            for (int r = 0; r < rows_to_do; ++r) {
-                const int row = 4 * s4 + r;
+            for (int row = row_lo; row <= row_end; ++row) {
                 const float dy = gy - (ty0 + (float)row);
                 const float bdy = row_term_b(s, dy), cdy2 = row_term_c(s, dy);
                 const v2f bdy2 = {bdy, bdy}, cdy22 = {cdy2, cdy2};
                 const float bdy_u = b * dy, cdy_u = c * dy;
                 v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
                 const float4 *prow = &sm.pix[row * (GI2D_TILE + 1)];
-                v2f px = px_first;
-#pragma unroll GI2D_BWD_UNROLL
-                for (int q = 0; q < 8; ++q) {
+                v2f px = px_first + (v2f){(float)(2 * q_lo), (float)(2 * q_lo)};
+#pragma unroll 1
+                for (int q = q_lo; q <= q_hi; ++q) {
                     const float4 P0 = prow[2 * q], P1 = prow[2 * q + 1];
                     const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
                     const v2f dx = gx2 - px;
@@ -438,7 +445,7 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
             }
         }
         __syncthreads();
-        // the lane that owns gaussian `tid` adds its (<= 4) strip partials of this round, in strip order
+        // the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row order
         const int lo = max(my_lo, round0), hi = min(my_hi, round1);
         for (int e = lo; e < hi; ++e) {
             const float *in = &sm.part[(e - round0) * PSTR];
