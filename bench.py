@@ -125,7 +125,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["name"], n, h, w),
                 "algorithmic_bytes_per_launch": dom["bytes"], "avg_kernel_us": dom["avg_us"],
                 "note": "VALU-bound by construction (each staged gaussian is reused by up to 256 pixels); see DESIGN.md",
             },
@@ -138,6 +138,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, n, h, w):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/traffic.json, built by
+    tools/make_profiles.py: 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md); null when no
+    counters were collected for this workload -- counters cannot be read from inside the timed process."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        c = t["config"]
+        if (c["num_points"], c["height"], c["width"]) != (n, h, w):
+            return None
+        for k, v in t["kernels"].items():
+            if k.replace(" ", "").endswith(kernel.replace(" ", "")):
+                return v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def train_step_rate(gt, n, dev, iters=400):

@@ -83,7 +83,7 @@ struct FastFwdLds {
     FwdLds f;
     int ids[GI2D_FAST_C];
     int cnt[GI2D_FAST_SUB];
-    float soa[4 * 9 * 64];  // per-wave SoA copy of 64 list entries for the packed pixel loop
+    float4 soa[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats: pair-interleaved copy of 64 list entries
 };
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
+#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 0
+    if (tiles_x > 0) return;  // timing experiment: launch floor
+#endif
     if (tid < GI2D_FAST_SUB) {
         const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
         cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     __syncthreads();
     const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
+#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 1
+    if (tiles_x > 0) return;  // + cursors
+#endif
     // my (up to two) bucket entries
     int my_id[2];
 #pragma unroll
@@ -122,6 +128,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         }
     }
     __syncthreads();
+#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 2
+    if (tiles_x > 0) { if (sm.ids[tid & 1] == 0x7ffffffe) status[3] = 1; return; }  // + bucket ids
+#endif
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -151,6 +160,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         }
     }
     __syncthreads();
+#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 3
+    if (tiles_x > 0) { if (sm.f.C[tid] == 12345.f) status[3] = 1; return; }  // + gather / rank / staging
+#endif
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     // "No intersection at all" (image = background) is a global property no single tile can decide: every
     // non-empty tile raises status[0] with a plain store as its LAST memory operation (no barrier waits on
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
                                    final_Ts, final_idx, out_img);
     else
         fwd_rasterize_staged<false>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
-                                    final_Ts, final_idx, out_img, sm.soa);
+                                    final_Ts, final_idx, out_img, reinterpret_cast<float *>(sm.soa));
     if (tid == 0 && L > 0) status[0] = 1;
 }
 

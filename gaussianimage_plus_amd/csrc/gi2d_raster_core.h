@@ -61,6 +61,7 @@ __device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, floa
 
 // =========================================================================================== forward
 #define GI2D_FWD_DUMMY GI2D_TILE_LIST_CAP /* index of a never-contributing entry used as list padding */
+#define GI2D_FWD_PAIRBUF (32 * 20)        /* floats per wave of the packed loop's pair-interleaved buffer */
 struct FwdLds {
     float4 AB[2 * (GI2D_TILE_LIST_CAP + 1)];  // [k]: (gx, gy, ha, hb), (hc, opac, cr, cg)
     float C[GI2D_TILE_LIST_CAP + 4];          // cb
@@ -118,9 +119,12 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
     float o0, o1, o2;
     int last_k = -1;
     if (!NEED_FIDX && soa != nullptr) {
-        // packed form: the wave copies its list 64 entries at a time into a private SoA buffer so that two
-        // consecutive entries sit in one 64-bit LDS word pair, and evaluates them with v_pk_* instructions
-        float *mysoa = soa + wv * (9 * 64);
+        // packed form: the wave copies its list 64 entries at a time into a private pair-interleaved buffer --
+        // entries 2p and 2p+1 side by side, 20 floats per pair: (gx gx' gy gy') (ha ha' hb hb') (hc hc' op op')
+        // (cr cr' cg cg') (cb cb' - -) -- so one pair costs four ds_read_b128 + one ds_read_b64 (18 LDS cycles;
+        // nine separate 64-bit words get merged into ds_read2_b64 at half the LDS rate, which bound this loop),
+        // and evaluates both entries with v_pk_* instructions
+        float *mysoa = soa + wv * GI2D_FWD_PAIRBUF;
         v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
         const v2f px2 = {px, px}, py2 = {py, py};
 #ifdef GI2D_ABLATE_FWD_COMPUTE
@@ -132,28 +136,25 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
                 const int k = e < cnt ? (int)mylist[e] : GI2D_FWD_DUMMY;
                 const float4 A = sm.AB[2 * k], B = sm.AB[2 * k + 1];
                 const float cb = sm.C[k];
-                mysoa[0 * 64 + lane] = A.x;
-                mysoa[1 * 64 + lane] = A.y;
-                mysoa[2 * 64 + lane] = A.z;
-                mysoa[3 * 64 + lane] = A.w;
-                mysoa[4 * 64 + lane] = B.x;
-                mysoa[5 * 64 + lane] = B.y;
-                mysoa[6 * 64 + lane] = B.z;
-                mysoa[7 * 64 + lane] = B.w;
-                mysoa[8 * 64 + lane] = cb;
+                float *w = mysoa + (lane >> 1) * 20 + (lane & 1);
+                w[0] = A.x;
+                w[2] = A.y;
+                w[4] = A.z;
+                w[6] = A.w;
+                w[8] = B.x;
+                w[10] = B.y;
+                w[12] = B.z;
+                w[14] = B.w;
+                w[16] = cb;
             }
             __builtin_amdgcn_wave_barrier();
             const int m = min(64, cnt - c0);
             for (int t = 0; t < m; t += 2) {
-                const v2f gx = *reinterpret_cast<const v2f *>(mysoa + 0 * 64 + t);
-                const v2f gy = *reinterpret_cast<const v2f *>(mysoa + 1 * 64 + t);
-                const v2f ha = *reinterpret_cast<const v2f *>(mysoa + 2 * 64 + t);
-                const v2f hb = *reinterpret_cast<const v2f *>(mysoa + 3 * 64 + t);
-                const v2f hc = *reinterpret_cast<const v2f *>(mysoa + 4 * 64 + t);
-                const v2f op = *reinterpret_cast<const v2f *>(mysoa + 5 * 64 + t);
-                const v2f cr = *reinterpret_cast<const v2f *>(mysoa + 6 * 64 + t);
-                const v2f cg = *reinterpret_cast<const v2f *>(mysoa + 7 * 64 + t);
-                const v2f cb = *reinterpret_cast<const v2f *>(mysoa + 8 * 64 + t);
+                const float4 *q = reinterpret_cast<const float4 *>(mysoa + t * 10);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
+                const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
+                const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
                 const v2f dx = gx - px2, dy = gy - py2;
                 const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
                 const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);

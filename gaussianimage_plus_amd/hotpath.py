@@ -256,11 +256,17 @@ class HotPath:
         return float(np.mean(ts)), float(np.min(ts))
 
     def dominant_kernel_stats(self, ev):
-        """The backward tile kernel dominates; its algorithmic bytes: 40*M + 16*H*W + 36*N."""
+        """The longer of the two rasterizer kernels (HIP-event spans of this run) with its algorithmic bytes per
+        launch: forward 40*M + 20*H*W, backward tiles 40*M + 16*H*W + 36*N."""
         m = self.num_intersects()
-        avg, mn = self._avg_us(ev, "bwd0", "bwd1")
-        name = "gi2d::fast_bwd_kernel" if self.mode == "fused" else "gi2d::raster_bwd_kernel"
-        return {"name": name, "avg_us": avg, "min_us": mn, "bytes": 40 * m + 16 * self.h * self.w + 36 * self.n}
+        f_avg, f_min = self._avg_us(ev, "fwd0", "fwd1")
+        b_avg, b_min = self._avg_us(ev, "bwd0", "bwd1")
+        fused = self.mode == "fused"
+        if f_avg >= b_avg:
+            return {"name": "gi2d::fast_fwd_kernel" if fused else "gi2d::raster_fwd_kernel", "avg_us": f_avg,
+                    "min_us": f_min, "bytes": 40 * m + 20 * self.h * self.w}
+        return {"name": "gi2d::fast_bwd_kernel<false>" if fused else "gi2d::raster_bwd_kernel<false>", "avg_us": b_avg,
+                "min_us": b_min, "bytes": 40 * m + 16 * self.h * self.w + 36 * self.n}
 
     def pair_stats(self, ev, pair_bytes):
         f_avg, _ = self._avg_us(ev, "fwd0", "fwd1")
