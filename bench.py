@@ -3,10 +3,11 @@
 
 One STEP = one pass of the hot path over one image's gaussians, everything resident in HBM:
     project_gaussians_2d (fwd) -> tile binning -> rasterize_sum forward
-    -> rasterize_sum backward (gradient image given) -> project_gaussians_2d (bwd)
+    -> L2-loss gradient of the rendered image -> rasterize_sum backward -> project_gaussians_2d (bwd)
 i.e. the work one training iteration of models/gaussianimage_cholesky.py:302-317 hands to the `gsplat`
-operator surface.  Model-side glue (tanh, +bound, clamp, MSE, optimizer) is not part of the metric
-(BASELINE.json: "training iters/sec (fwd+bwd rasterize)"); the gradient image v_out is fixed.
+operator surface, with the gradient image derived from the step's own render exactly as loss.backward() does
+(clamp + MSE against a fixed synthetic target).  tanh / +bound / the optimizer are not part of the metric
+(BASELINE.json: "training iters/sec (fwd+bwd rasterize)"); they are in the separate `train_step` figure.
 
 N GPUs: one process per GPU, one independent image per rank (images shard embarrassingly,
 no data-path collective) -> weak scaling; value = ranks * K / max-over-ranks time.
@@ -63,10 +64,10 @@ def main():
     xyz, L, col, op = synth_cholesky(n, h, w, 3047 + rank)  # reference default seed (train.py:225) + rank
     hp = HotPath(n, h, w, device=dev)
     hp.set_inputs(xyz, L, col, op)
-    # gradient image from the first render against a seeded smooth target
-    out = hp.forward()
+    # every step renders, forms the L2 gradient against a seeded smooth target and back-propagates it
     gt = torch.from_numpy(synth_gt(h, w, 1 + rank)).to(dev)
-    hp.set_v_out((2 * (out.clamp(0, 1) - gt) / (3 * h * w)).contiguous())
+    hp.set_target(gt)
+    hp.forward()
     m = hp.num_intersects()
 
     def barrier():
@@ -77,7 +78,7 @@ def main():
     for _ in range(args.warmup):
         hp.step()
     barrier()
-    # HIP events around the two rasterizer kernels on the launch stream, on every EVENT_STRIDE-th step of the
+    # HIP events around the rasterizer tile pass on the launch stream, on every EVENT_STRIDE-th step of the
     # timed region (each record costs ~3 us of launch-queue time, so timing every step would slow the loop)
     n_timed = max(1, args.steps // EVENT_STRIDE)
     ev = hp.kernel_timers(n_timed)
@@ -118,7 +119,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"Cholesky model, N={n} Gaussians, {w}x{h}, one image per GPU: project fwd + tile binning + "
-                            f"rasterize_sum fwd + bwd + project bwd per step (fixed gradient image)",
+                            f"rasterize_sum fwd + L2 gradient of the render + rasterize_sum bwd + project bwd per step",
                 "num_points": n, "height": h, "width": w, "num_intersects_rank0": m,
                 "num_intersects_mean": float(ms.item()) / world, "seed": 3047,
                 "host_path": hp.describe(),

@@ -19,7 +19,7 @@
 //
 // Capacity contract: at most GI2D_FAST_CSUB ids per (tile, sub-bucket).  A fuller bucket sets
 // status[1] and the caller must fall back to the exact path (gi2d_bin_gaussians + plain ops).
-#include "gi2d_fast_internal.h"
+#include "gi2d_fused_core.h"
 
 namespace gi2d {
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     int tiles_x, int tiles_y, int img_w, int img_h, const int2 *__restrict__ tile_bins,
     const GaussRec *__restrict__ packed, const int32_t *__restrict__ final_idx,
     const float *__restrict__ v_output, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big) {
-    __shared__ BwdLds<WITH_ABS> sm;
+    __shared__ BwdLds<WITH_ABS, false> sm;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
@@ -229,19 +229,29 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
 #if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 3
     if (len > 0) {  // + gaussian staging
         __syncthreads();
-        if (sm.gCb[tid & 63] == 12345.f && mask == 77u) partial_big[0] = sm.pix[tid];
+        if (sm.gCb[tid & 63] == 12345.f && mask == 77u) partial_big[0] = sm.pixA[tid & 127];
         return;
     }
 #endif
-    float acc[BwdLds<WITH_ABS>::PSTR];
-    bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), acc);
-#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 4
-    if (len > 0 && acc[0] != 12345.f) return;  // + items and compute, no stores
-#endif
-    if (tid < len) {
-        float4 *dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
-        store_partial_row(dst, acc);
-    }
+    float4 *dst = nullptr;
+    if (tid < len)
+        dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
+    bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
+}
+
+// ----------------------------------------------------------------- forward + backward in one pass
+template <int MODE>
+__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
+    int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacities, int32_t *__restrict__ cursors, const int32_t *__restrict__ buckets,
+    int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g,
+    float4 *__restrict__ partial_big, int32_t *__restrict__ status, float *__restrict__ out_img,
+    const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
+    __shared__ FusedLds sm;
+    fused_tile<MODE>(sm, blockIdx.x, tiles_x, tiles_y, img_w, img_h, xys, radii, conics, colors, opacities, cursors,
+                     buckets, gids_sorted, tile_bins, partial_g, partial_big, status, out_img, vsrc, grad_scale,
+                     tile_sse);
 }
 
 // --------------------------------------------------------------------------------------- reduce
@@ -393,6 +403,41 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);
     return check_launch("fast rasterize forward");
+}
+
+int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *xys,
+                                         const int32_t *radii, const float *conics, const float *colors,
+                                         const float *opac, const float *background, const float *v_output,
+                                         const float *target, float grad_scale, float *tile_sse, void *ws,
+                                         size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st) {
+    int rc = check_ws("fast rasterize forward+backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
+    if (rc != GI2D_OK) return rc;
+    const long long t = (long long)tiles_x * tiles_y;
+    if (t == 0 || w_ == 0 || h == 0) return GI2D_OK;
+    if ((unsigned)tiles_x * GI2D_TILE < w_ || (unsigned)tiles_y * GI2D_TILE < h) {
+        set_error("fast rasterize forward+backward: tile grid does not cover the image");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (!status || !out_img || (n > 0 && (!xys || !radii || !conics || !colors || !opac)) ||
+        ((v_output != nullptr) == (target != nullptr)) || (target && !tile_sse)) {
+        set_error("fast rasterize forward+backward: bad argument (exactly one of v_output / target; tile_sse with target)");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    FastWs w = carve_fast(ws, n, (int)t);
+    if (v_output)
+        hipLaunchKernelGGL(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
+                           (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors, w.buckets,
+                           w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big, status, out_img, v_output,
+                           0.f, nullptr);
+    else
+        hipLaunchKernelGGL(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
+                           (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors, w.buckets,
+                           w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big, status, out_img, target,
+                           grad_scale, tile_sse);
+    if (background)
+        hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
+                           status, background, out_img);
+    return check_launch("fast rasterize forward+backward");
 }
 
 int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h,

@@ -1,0 +1,256 @@
+// One workgroup = one 16x16 tile, forward AND backward of the additive rasterizer in a single pass.
+//
+// The fused fast path's backward does not consume anything the forward computes except the tile's ordered
+// gaussian list (it re-evaluates every pair with the same instructions), and the gradient of a pixel depends on
+// that pixel alone -- either it is given (a gradient image), or it is the L2-loss gradient of the pixel the
+// forward has just produced.  So the tile's gaussians are ranked, gathered and staged in LDS ONCE, the forward
+// runs on them, each lane turns its pixel into its gradient, and the backward items run on the same staged
+// records: no second launch, no packed-list round trip through HBM, no second cursor / list / record load chain.
+//
+// LDS: records (raw conic), cull words and partial-row codes by list position are shared by both phases; the
+// sort buffer, the forward's lists + pair buffers and the backward's pixel / item / hand-off buffers overlay
+// each other (they are live in disjoint phases, separated by workgroup barriers).
+#pragma once
+#include "gi2d_fast_internal.h"
+
+namespace gi2d {
+
+#ifndef GI2D_FUSED_OCC
+#define GI2D_FUSED_OCC 5 /* workgroups per CU the register allocator leaves room for (LDS: 29 KB -> 5) */
+#endif
+
+struct FusedLds {
+    static constexpr int PSTR = 9;
+    static constexpr bool HAS_FIDX = false;
+    typedef float2 PixB;
+    float4 gA[GI2D_TILE_LIST_CAP + 1];  // gx, gy, a, b        (entry CAP: the forward's never-contributing padding)
+    float4 gB[GI2D_TILE_LIST_CAP + 1];  // c, opac, cr, cg
+    float gCb[GI2D_TILE_LIST_CAP + 4];  // cb
+    unsigned cullw[GI2D_TILE_LIST_CAP]; // cull_word() of the entry
+    int slot[GI2D_TILE_LIST_CAP];       // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big)
+    int cnt[GI2D_FAST_SUB];
+    float sse_w[4];
+    union {
+        struct {
+            int ids[GI2D_FAST_C];
+        };
+        struct {  // forward phase
+            unsigned short list[4][GI2D_TILE_LIST_CAP + 8];
+            float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats; re-used as the RGB transpose stage
+        };
+        struct {  // backward phase (member names as BwdLds: bwd_run_tile is shared)
+            float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];
+            float2 pixB[GI2D_TILE * GI2D_BWD_PIXROW];
+            unsigned short off[GI2D_TILE_LIST_CAP + 4];
+            unsigned char item[8 * GI2D_TILE_LIST_CAP];
+            float part[GI2D_BWD_ITEMS * PSTR];
+            unsigned short xr[GI2D_TILE_LIST_CAP];
+            int wsum[4];
+        };
+    };
+};
+
+// MODE 0: `vsrc` is the gradient image v_output[H,W,3].
+// MODE 1: `vsrc` is the target image gt[H,W,3]; the pixel gradient is that of mean((clamp(out,0,1) - gt)^2):
+//         grad_scale * (clamp(out) - gt) where the clamp passes gradient (models/gaussianimage_cholesky.py:307-310
+//         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
+template <int MODE>
+__device__ __forceinline__ void fused_tile(
+    FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacities, int32_t *__restrict__ cursors, const int32_t *__restrict__ buckets,
+    int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g,
+    float4 *__restrict__ partial_big, int32_t *__restrict__ status, float *__restrict__ out_img,
+    const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lx = tid & 15, ly = tid >> 4;  // == (lane & 15, wv * 4 + (lane >> 4)): wave wv owns pixel rows 4wv..4wv+3
+    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
+    const bool inside = (i < img_h) && (j < img_w);
+    const size_t pix = (size_t)i * img_w + j;
+
+    // this lane's pixel of the gradient / target image: issued first, consumed after the forward
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (inside) {
+        p0 = vsrc[3 * pix];
+        p1 = vsrc[3 * pix + 1];
+        p2 = vsrc[3 * pix + 2];
+    }
+
+    // ---- bucket -> ordered, staged list (as fast_fwd_kernel)
+    if (tid < GI2D_FAST_SUB) {
+        const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
+        cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
+        if (c > GI2D_FAST_CSUB) atomicOr(&status[1], 1);
+        sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
+    }
+    if (tid == 0) {
+        sm.gA[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sm.gB[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
+        sm.gCb[GI2D_TILE_LIST_CAP] = 0.f;
+    }
+    __syncthreads();
+    const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
+    if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
+    int my_id[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        my_id[u] = -1;
+        if (e < L) {
+            const int sub = (e >= c0) + (e >= c1) + (e >= c2);
+            const int off = e - (sub == 0 ? 0 : (sub == 1 ? c0 : (sub == 2 ? c1 : c2)));
+            my_id[u] = buckets[(tile * GI2D_FAST_SUB + sub) * GI2D_FAST_CSUB + off];
+            sm.ids[e] = my_id[u];
+        }
+    }
+    __syncthreads();
+    const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (my_id[u] < 0) continue;
+        const int g = my_id[u];
+        const GaussRec r = load_gaussian(g, xys, conics, colors, opacities);  // gathers in flight under the rank loop
+        const int rad = radii[g];
+        int rank = 0;
+        for (int q = 0; q < L; ++q) rank += (sm.ids[q] < g) ? 1 : 0;
+        gids_sorted[tile * GI2D_FAST_C + rank] = g;
+        const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
+        const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
+        if (rank < GI2D_TILE_LIST_CAP) {
+            sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
+            sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
+            sm.gCb[rank] = r.cb;
+            sm.cullw[rank] = cull_word(r, tx0, ty0, img_h);
+            sm.slot[rank] = slot;
+        } else if (slot >= 0) {
+            // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
+            partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
+            partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
+        }
+    }
+    __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
+    const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
+
+    // ---- forward: per-wave list of the entries that reach this wave's 4-row strip, then the packed pair loop
+    // (same arithmetic, same order as fwd_rasterize_staged's packed form: bitwise identical pixels)
+    unsigned short *mylist = sm.list[wv];
+    int cnt = 0;
+    for (int base = 0; base < len; base += 64) {
+        const int k = base + lane;
+        const bool take = (k < len) && ((sm.cullw[k] >> wv) & 1u);
+        const unsigned long long m = __ballot(take);
+        if (take) mylist[cnt + __popcll(m & lanemask_lt())] = (unsigned short)k;
+        cnt += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF;
+    const float px = (float)j, py = (float)i;
+    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+    const v2f px2 = {px, px}, py2 = {py, py};
+    for (int e0 = 0; e0 < cnt; e0 += 64) {
+        {
+            const int e = e0 + lane;
+            const int k = e < cnt ? (int)mylist[e] : GI2D_TILE_LIST_CAP;
+            const float4 A = sm.gA[k], B = sm.gB[k];
+            const float cb = sm.gCb[k];
+            const ConicS s = scale_conic(A.z, A.w, B.x);
+            float *w = mybuf + (lane >> 1) * 20 + (lane & 1);
+            w[0] = A.x;
+            w[2] = A.y;
+            w[4] = s.ha;
+            w[6] = s.hb;
+            w[8] = s.hc;
+            w[10] = B.y;
+            w[12] = B.z;
+            w[14] = B.w;
+            w[16] = cb;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int m = min(64, cnt - e0);
+        for (int t = 0; t < m; t += 2) {
+            const float4 *q = reinterpret_cast<const float4 *>(mybuf + t * 10);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
+            const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
+            const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
+            const v2f dx = gx - px2, dy = gy - py2;
+            const v2f bdy = hb * dy, cdy2 = hc * dy * dy;
+            const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
+            const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+            const v2f tt = op * vis;
+            const v2f alpha = {fminf(1.f, tt.x), fminf(1.f, tt.y)};
+            const bool ok0 = !(sig.x < 0.f || alpha.x < GI2D_ALPHA_MIN);
+            const bool ok1 = !(sig.y < 0.f || alpha.y < GI2D_ALPHA_MIN);
+            const v2f am = {ok0 ? alpha.x : 0.f, ok1 ? alpha.y : 0.f};
+            a0 = __builtin_elementwise_fma(cr, am, a0);
+            a1 = __builtin_elementwise_fma(cg, am, a1);
+            a2 = __builtin_elementwise_fma(cb, am, a2);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float o0 = a0.x + a0.y, o1 = a1.x + a1.y, o2 = a2.x + a2.y;
+
+    // image out: transpose RGB through the wave's (now idle) pair buffer, 12 x 16-byte stores per pixel row
+    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
+    if (full_tile) {
+        const int r = lane >> 4;
+        mybuf[r * 48 + lx * 3 + 0] = o0;
+        mybuf[r * 48 + lx * 3 + 1] = o1;
+        mybuf[r * 48 + lx * 3 + 2] = o2;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 48) {
+            const int rr = lane / 12, q = lane % 12;
+            const int ii = ty * GI2D_TILE + wv * 4 + rr;
+            if (ii < img_h) {
+                const float4 v = reinterpret_cast<const float4 *>(mybuf)[rr * 12 + q];
+                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
+                dst[q] = v;
+            }
+        }
+    } else if (inside) {
+        out_img[3 * pix + 0] = o0;
+        out_img[3 * pix + 1] = o1;
+        out_img[3 * pix + 2] = o2;
+    }
+
+    // ---- this pixel's gradient
+    float v0 = p0, v1 = p1, v2 = p2, sse = 0.f;
+    if (MODE == 1) {
+        v0 = v1 = v2 = 0.f;
+        if (inside) {
+            const float o[3] = {o0, o1, o2}, gtv[3] = {p0, p1, p2};
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float oc = fminf(fmaxf(o[c], 0.f), 1.f);  // torch.clamp(out_img, 0, 1)
+                const float d = oc - gtv[c];
+                sse += d * d;
+                v[c] = (o[c] >= 0.f && o[c] <= 1.f) ? grad_scale * d : 0.f;  // clamp passes the gradient on [0, 1]
+            }
+            v0 = v[0], v1 = v[1], v2 = v[2];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sse += __shfl_xor(sse, d, 64);
+        if (lane == 0) sm.sse_w[wv] = sse;
+    }
+    __syncthreads();  // every wave is done with its list / pair buffer: the overlay becomes the backward's buffers
+
+    // ---- backward on the same staged records
+    bwd_publish_pixel(sm, lx, ly, v0, v1, v2, 0.f);
+    unsigned cull = 0u;
+    float4 *dst = nullptr;
+    if (tid < len) {
+        cull = sm.cullw[tid];
+        const int slot = sm.slot[tid];
+        dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
+    }
+    bwd_run_tile<false, false>(sm, len, cull, 0, tx0, ty0, dst);
+    if (MODE == 1 && tid == 0) tile_sse[tile] = (sm.sse_w[0] + sm.sse_w[1]) + (sm.sse_w[2] + sm.sse_w[3]);
+    // "No intersection at all" is a global property: see fast_fwd_kernel
+    if (tid == 0 && L > 0) status[0] = 1;
+}
+
+}  // namespace gi2d

@@ -90,9 +90,8 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void raster_bwd_k
         bwd_stage_entry(sm, tid, r);
         mask = cull_word(r, tx0, ty0, img_h);
     }
-    float acc[BwdLds<WITH_ABS>::PSTR];
-    bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, tx0, ty0, acc);
-    if (tid < len) store_partial_row(partials + 3 * (size_t)(range.x + tid), acc);
+    bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, tx0, ty0,
+                           tid < len ? partials + 3 * (size_t)(range.x + tid) : nullptr);
 }
 
 // Plan form: gaussian g owns input positions [cum[g-1], cum[g]) (ascending tile id);

@@ -265,30 +265,56 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 // lane that owns the gaussian through LDS and added in row order.
 #define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
 #ifndef GI2D_BWD_OCC
-#define GI2D_BWD_OCC 6 /* waves per SIMD the register allocator must leave room for (6 workgroups/CU) */
+#define GI2D_BWD_OCC 5 /* waves per SIMD the register allocator must leave room for; measured: 5 (96 VGPRs) beats 6 (80) */
 #endif
 #ifndef GI2D_BWD_UNROLL
 #define GI2D_BWD_UNROLL 1 /* pixel pairs per trip; 2 needs > 80 VGPRs and costs the sixth workgroup */
 #endif
 
-template <bool WITH_ABS>
+template <int PSTR>
+__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR]);
+
+template <bool FIDX>
+struct BwdPixB;  // second word of a pixel pair: (voz0, voz1) and, where final_idx is consulted, (fidx0, fidx1)
+template <>
+struct BwdPixB<true> {
+    typedef float4 type;
+};
+template <>
+struct BwdPixB<false> {
+    typedef float2 type;
+};
+#define GI2D_BWD_PIXROW 9 /* 8 pixel pairs + one element of padding per row (rows of different items: no conflicts) */
+
+template <bool WITH_ABS, bool FIDX = true>
 struct BwdLds {
     static constexpr int PSTR = WITH_ABS ? 11 : 9;  // odd: conflict-free hand-off rows
-    // per pixel row: 8 pairs x {(vox0,vox1,voy0,voy1), (voz0,voz1,fidx0,fidx1)} + one float4 of padding
-    float4 pix[GI2D_TILE * (GI2D_TILE + 1)];
+    static constexpr bool HAS_FIDX = FIDX;
+    typedef typename BwdPixB<FIDX>::type PixB;
+    float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];  // per pixel row: 8 pairs of (vox0, vox1, voy0, voy1)
+    PixB pixB[GI2D_TILE * GI2D_BWD_PIXROW];    //                8 pairs of (voz0, voz1 [, fidx0, fidx1])
     float4 gA[GI2D_TILE_LIST_CAP];  // gx, gy, a, b
     float4 gB[GI2D_TILE_LIST_CAP];  // c, opac, cr, cg
     float gCb[GI2D_TILE_LIST_CAP];  // cb
     unsigned short off[GI2D_TILE_LIST_CAP + 2];     // exclusive prefix of items per gaussian
-    unsigned short item[8 * GI2D_TILE_LIST_CAP];    // k | row pair << 8
+    unsigned char item[8 * GI2D_TILE_LIST_CAP];     // k: the item's gaussian (its row pair follows from off[k])
     float part[GI2D_BWD_ITEMS * PSTR];
     unsigned short xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | q0 << 8 | q1 << 12 per gaussian
     int wsum[4];
 };
 
 // lane (lx, ly) publishes pixel (v_out, final_idx) in pair-major order; -1 outside the image
-template <bool WITH_ABS>
-__device__ __forceinline__ void bwd_stage_pixels(BwdLds<WITH_ABS> &sm, int tx, int ty, int img_w, int img_h,
+template <class Lds>
+__device__ __forceinline__ void bwd_publish_pixel(Lds &sm, int lx, int ly, float vx, float vy, float vz, float fi) {
+    float *ra = reinterpret_cast<float *>(&sm.pixA[ly * GI2D_BWD_PIXROW]) + (lx >> 1) * 4 + (lx & 1);
+    ra[0] = vx;
+    ra[2] = vy;
+    float *rb = reinterpret_cast<float *>(&sm.pixB[ly * GI2D_BWD_PIXROW]) + (lx >> 1) * (Lds::HAS_FIDX ? 4 : 2) + (lx & 1);
+    rb[0] = vz;
+    if (Lds::HAS_FIDX) rb[2] = fi;
+}
+template <class Lds>
+__device__ __forceinline__ void bwd_stage_pixels(Lds &sm, int tx, int ty, int img_w, int img_h,
                                                  const int32_t *__restrict__ final_idx,
                                                  const float *__restrict__ v_output) {
     const int tid = threadIdx.x;
@@ -300,34 +326,43 @@ __device__ __forceinline__ void bwd_stage_pixels(BwdLds<WITH_ABS> &sm, int tx, i
         vx = v_output[3 * pix];
         vy = v_output[3 * pix + 1];
         vz = v_output[3 * pix + 2];
-        fi = __int_as_float(final_idx ? final_idx[pix] : 0x7fffffff);
+        if (Lds::HAS_FIDX) fi = __int_as_float(final_idx ? final_idx[pix] : 0x7fffffff);
     }
-    float *row = reinterpret_cast<float *>(&sm.pix[ly * (GI2D_TILE + 1)]) + (lx >> 1) * 8 + (lx & 1);
-    row[0] = vx;
-    row[2] = vy;
-    row[4] = vz;
-    row[6] = fi;
+    bwd_publish_pixel(sm, lx, ly, vx, vy, vz, fi);
 }
 
-template <bool WITH_ABS>
-__device__ __forceinline__ void bwd_stage_entry(BwdLds<WITH_ABS> &sm, int k, const GaussRec &r) {
+template <class Lds>
+__device__ __forceinline__ void bwd_stage_entry(Lds &sm, int k, const GaussRec &r) {
     sm.gA[k] = make_float4(r.gx, r.gy, r.a, r.b);
     sm.gB[k] = make_float4(r.c, r.opac, r.cr, r.cg);
     sm.gCb[k] = r.cb;
 }
 
 // After pixels and the first `len` gaussians are staged (no barrier needed before the call): builds the
-// item list from each lane's cull word (cull_word()), runs the items, and leaves in acc[] (lanes tid < len) the
-// gradient partial of gaussian `tid` for this tile:
-//   acc = (v_x, v_y, v_conic[3], v_rgb[3], v_opacity [, sum|v_x|, sum|v_y|]).
+// item list from each lane's cull word (cull_word()), runs the items, and stores to `dst` (lanes tid < len; three
+// float4) the gradient partial of gaussian `tid` for this tile:
+//   (v_x, v_y, v_conic[3], v_rgb[3], v_opacity [, sum|v_x|, sum|v_y|]).
+// Items are processed 256 per round; nearly every tile needs one round, so the running sums are NOT kept in
+// registers across rounds (that costs the register budget of the sixth workgroup per CU): a gaussian whose items
+// straddle two rounds re-reads its own row from `dst` in the later round.
 // `list_base` + k is the entry's position in the sorted list (compared with final_idx, backward.cu:903).
 // USE_FIDX=false (fast path): the forward that produced the lists evaluates every pair with the same
 // instructions, so "idx <= final_idx" is implied by the alpha test and is not re-checked (pixels outside the
 // image still carry v_out = 0 and contribute nothing).
-template <bool WITH_ABS, bool USE_FIDX = true>
-__device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsigned cull, int list_base,
-                                             float tx0, float ty0, float (&acc)[BwdLds<WITH_ABS>::PSTR]) {
-    constexpr int PSTR = BwdLds<WITH_ABS>::PSTR;
+template <bool USE_FIDX>
+__device__ __forceinline__ bool fidx_admits(int idx, const float4 &p1, int half) {
+    return !USE_FIDX || idx <= __float_as_int(half ? p1.w : p1.z);
+}
+template <bool USE_FIDX>
+__device__ __forceinline__ bool fidx_admits(int, const float2 &, int) {
+    static_assert(!USE_FIDX, "final_idx is not staged in this LDS layout");
+    return true;
+}
+
+template <bool WITH_ABS, bool USE_FIDX = true, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
+__device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, int list_base, float tx0, float ty0,
+                                             float4 *__restrict__ dst) {
+    constexpr int PSTR = Lds::PSTR;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         // row pairs this gaussian reaches: p0..p1; its pixel-pair range rides along in sm.xr
@@ -342,26 +377,23 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
         int excl = base + incl - nitems;
         if (tid < len) sm.off[tid] = (unsigned short)excl;
         if (tid == 255) sm.off[len] = (unsigned short)(excl + nitems);  // lanes >= len carry 0 items
-        for (int p = 0; p < nitems; ++p) sm.item[excl++] = (unsigned short)(tid | ((p0 + p) << 8));
+        for (int p = 0; p < nitems; ++p) sm.item[excl++] = (unsigned char)tid;
     }
     __syncthreads();
     const int n_items = sm.off[len];
-    const int my_lo = tid < len ? sm.off[tid] : 0;
-    const int my_hi = tid < len ? sm.off[tid + 1] : 0;
-#pragma unroll
-    for (int q = 0; q < PSTR; ++q) acc[q] = 0.f;
 
     // pixel x coordinates of a row's first pair, exactly as the forward forms them: (float)j
     // (small integers: stepping by 2.0 stays exact)
     const v2f px_first = {tx0, tx0 + 1.f};
 
-    for (int round0 = 0; round0 < n_items; round0 += GI2D_BWD_ITEMS) {
+    int round0 = 0;
+    do {
         const int round1 = min(n_items, round0 + GI2D_BWD_ITEMS);
         const int it = round0 + tid;
         if (it < round1) {
-            const unsigned code = sm.item[it];
-            const int k = code & 255, rp = code >> 8;
+            const int k = sm.item[it];
             const unsigned xr = sm.xr[k];
+            const int rp = (int)((xr & 15u) >> 1) + (it - (int)sm.off[k]);  // items of k: its row pairs in order
             const int row_lo = max(2 * rp, (int)(xr & 15u)), row_hi = min(2 * rp + 1, (int)((xr >> 4) & 15u));
             const int q_lo = (int)((xr >> 8) & 15u), q_hi = (int)((xr >> 12) & 15u);
             const float4 A = sm.gA[k], B = sm.gB[k];
@@ -385,11 +417,13 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
                 const v2f bdy2 = {bdy, bdy}, cdy22 = {cdy2, cdy2};
                 const float bdy_u = b * dy, cdy_u = c * dy;
                 v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
-                const float4 *prow = &sm.pix[row * (GI2D_TILE + 1)];
+                const float4 *pa = &sm.pixA[row * GI2D_BWD_PIXROW];
+                const typename Lds::PixB *pb = &sm.pixB[row * GI2D_BWD_PIXROW];
                 v2f px = px_first + (v2f){(float)(2 * q_lo), (float)(2 * q_lo)};
 #pragma unroll 1
                 for (int q = q_lo; q <= q_hi; ++q) {
-                    const float4 P0 = prow[2 * q], P1 = prow[2 * q + 1];
+                    const float4 P0 = pa[q];
+                    const typename Lds::PixB P1 = pb[q];
                     const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
                     const v2f dx = gx2 - px;
                     px += (v2f){2.f, 2.f};
@@ -398,8 +432,8 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
                     const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
                     const v2f t = opac2 * vis;
                     // backward.cu:903 (idx <= final_idx) and :925 (alpha = min(1,t) < 1/255 <=> t < 1/255)
-                    const bool ok0 = (!USE_FIDX || idx <= __float_as_int(P1.z)) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
-                    const bool ok1 = (!USE_FIDX || idx <= __float_as_int(P1.w)) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
+                    const bool ok0 = fidx_admits<USE_FIDX>(idx, P1, 0) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
+                    const bool ok1 = fidx_admits<USE_FIDX>(idx, P1, 1) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
                     const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
                     const v2f am = {fminf(1.f, tz.x), fminf(1.f, tz.y)};
                     // backward.cu:940-946
@@ -447,14 +481,31 @@ __device__ __forceinline__ void bwd_run_tile(BwdLds<WITH_ABS> &sm, int len, unsi
         }
         __syncthreads();
         // the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row order
-        const int lo = max(my_lo, round0), hi = min(my_hi, round1);
-        for (int e = lo; e < hi; ++e) {
-            const float *in = &sm.part[(e - round0) * PSTR];
+        if (dst != nullptr) {
+            const int my_lo = sm.off[tid], my_hi = sm.off[tid + 1];
+            const int lo = max(my_lo, round0), hi = min(my_hi, round1);
+            if (hi > lo || (round0 == 0 && my_hi == my_lo)) {  // a gaussian without items still owes a zero row
+                float acc[PSTR];
 #pragma unroll
-            for (int q = 0; q < PSTR; ++q) acc[q] += in[q];
+                for (int q = 0; q < PSTR; ++q) acc[q] = 0.f;
+                if (my_lo < round0) {  // earlier round(s) already stored part of this row
+                    const float4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
+                    acc[0] = d0.x, acc[1] = d0.y, acc[2] = d0.z, acc[3] = d0.w;
+                    acc[4] = d1.x, acc[5] = d1.y, acc[6] = d1.z, acc[7] = d1.w;
+                    acc[8] = d2.x;
+                    if (PSTR > 9) acc[PSTR - 2] = d2.y, acc[PSTR - 1] = d2.z;
+                }
+                for (int e = lo; e < hi; ++e) {
+                    const float *in = &sm.part[(e - round0) * PSTR];
+#pragma unroll
+                    for (int q = 0; q < PSTR; ++q) acc[q] += in[q];
+                }
+                store_partial_row<PSTR>(dst, acc);
+            }
         }
         __syncthreads();
-    }
+        round0 += GI2D_BWD_ITEMS;
+    } while (round0 < n_items);
 }
 
 template <int PSTR>

@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
 }
 
 // Pixel staging of the backward with the L2 loss gradient formed on the fly; returns this lane's squared error.
-template <bool WITH_ABS>
-__device__ __forceinline__ float bwd_stage_pixels_l2(BwdLds<WITH_ABS> &sm, int tx, int ty, int img_w, int img_h,
+template <class Lds>
+__device__ __forceinline__ float bwd_stage_pixels_l2(Lds &sm, int tx, int ty, int img_w, int img_h,
                                                      const float *__restrict__ out_img,
                                                      const float *__restrict__ gt, float grad_scale) {
     const int tid = threadIdx.x;
@@ -93,11 +93,7 @@ __device__ __forceinline__ float bwd_stage_pixels_l2(BwdLds<WITH_ABS> &sm, int t
             v[c] = (o >= 0.f && o <= 1.f) ? grad_scale * d : 0.f;  // clamp passes the gradient on [0, 1]
         }
     }
-    float *row = reinterpret_cast<float *>(&sm.pix[ly * (GI2D_TILE + 1)]) + (lx >> 1) * 8 + (lx & 1);
-    row[0] = v[0];
-    row[2] = v[1];
-    row[4] = v[2];
-    row[6] = __int_as_float(0x7fffffff);
+    bwd_publish_pixel(sm, lx, ly, v[0], v[1], v[2], 0.f);
     return sse;
 }
 
@@ -106,7 +102,7 @@ __global__ __launch_bounds__(256, GI2D_BWD_OCC) void train_bwd_kernel(
     const GaussRec *__restrict__ packed, const float *__restrict__ out_img, const float *__restrict__ gt,
     float grad_scale, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
     float *__restrict__ tile_sse) {
-    __shared__ BwdLds<false> sm;
+    __shared__ BwdLds<false, false> sm;
     __shared__ float sse_w[4];
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -130,14 +126,11 @@ __global__ __launch_bounds__(256, GI2D_BWD_OCC) void train_bwd_kernel(
         slot = __float_as_int(q2.y);
         mask = (unsigned)__float_as_int(q2.w);
     }
-    float acc[9];
-    bwd_run_tile<false, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), acc);
+    float4 *dst = nullptr;
+    if (tid < len)
+        dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
+    bwd_run_tile<false, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
     if (tid == 0) tile_sse[tile] = (sse_w[0] + sse_w[1]) + (sse_w[2] + sse_w[3]);  // after >= 1 barrier
-    if (tid < len) {
-        float4 *dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot
-                                : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
-        store_partial_row(dst, acc);
-    }
 }
 
 struct AdamStep {
@@ -261,6 +254,20 @@ static int train_check(const gi2d_train_state *s, int &tx, int &ty) {
     return GI2D_OK;
 }
 
+static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w, const TrainParams &P, int tx,
+                                      int ty, hipStream_t st) {
+    const int n = s->num_points;
+    const dim3 gg((n + 255) / 256), bb(256);
+    if (s->kind == 0)
+        hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
+                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
+                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+    else
+        hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
+                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
+                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+}
+
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
 int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
     int tx, ty;
@@ -271,15 +278,7 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
     if (n == 0) return GI2D_OK;
     FastWs w = carve_fast(s->workspace, n, tx * ty);
     const TrainParams P = params_of(s);
-    const dim3 gg((n + 255) / 256), bb(256);
-    if (s->kind == 0)
-        hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
-                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
-    else
-        hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
-                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+    train_launch_project_fill(s, w, P, tx, ty, st);
     return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys, s->radii,
                                        s->conics, s->feat, s->opacity, nullptr, s->workspace, s->workspace_bytes,
                                        s->status, nullptr, nullptr, s->out_img, st_);
@@ -289,10 +288,9 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
 // learning rates of the xyz / cholesky / colour groups for THIS step and the 1-based Adam step count.
 int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps, int step,
                     gi2d_stream_t st_) {
-    int rc = gi2d_train_render(s, st_);
-    if (rc != GI2D_OK) return rc;
     int tx, ty;
-    train_check(s, tx, ty);
+    int rc = train_check(s, tx, ty);
+    if (rc != GI2D_OK) return rc;
     hipStream_t st = (hipStream_t)st_;
     const int n = s->num_points;
     if (n == 0 || !lr || step < 1) {
@@ -303,9 +301,12 @@ int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, flo
     FastWs w = carve_fast(s->workspace, n, tx * ty);
     const TrainParams P = params_of(s);
     const float grad_scale = 2.f / (3.f * (float)s->img_height * (float)s->img_width);
-    hipLaunchKernelGGL(train_bwd_kernel, dim3((unsigned)(tx * ty)), dim3(256), 0, st, tx, ty, s->img_width,
-                       s->img_height, (const int2 *)w.tile_bins, w.packed, s->out_img, s->gt, grad_scale, w.partial_g,
-                       w.partial_big, s->tile_sse);
+    train_launch_project_fill(s, w, P, tx, ty, st);
+    rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
+                                              s->radii, s->conics, s->feat, s->opacity, nullptr, nullptr, s->gt,
+                                              grad_scale, s->tile_sse, s->workspace, s->workspace_bytes, s->status,
+                                              s->out_img, st_);
+    if (rc != GI2D_OK) return rc;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     AdamStep a[3];
     for (int q = 0; q < 3; ++q) {

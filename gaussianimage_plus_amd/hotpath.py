@@ -5,14 +5,20 @@ issues the C-ABI calls with pre-built argument lists, so one step costs four nat
 nothing else: no allocation, no host read-back, nothing but kernel launches on the current HIP stream
 (so a step can be captured into a hipGraph: `capture_graph()`).
 
-  mode "fused" (default) -- the 4-launch fast path (csrc/gi2d_fast.hip)
-      gi2d_fast_project_bin -> gi2d_fast_rasterize_forward
-      -> gi2d_fast_rasterize_backward_tiles -> gi2d_fast_reduce_project_backward
+  mode "fused" (default) -- the fast path (csrc/gi2d_fast.hip), 3 launches per step():
+      gi2d_fast_project_bin -> gi2d_fast_rasterize_forward_backward (one tile pass for both directions)
+      -> gi2d_fast_reduce_project_backward
+    (forward() / backward() called separately use gi2d_fast_rasterize_forward / _backward_tiles)
   mode "exact" -- the capacity-free ops (any tile population):
       gi2d_project_*_forward -> gi2d_bin_gaussians -> gi2d_rasterize_sum_forward
       -> gi2d_rasterize_backward_tiles -> gi2d_rasterize_backward_reduce -> gi2d_project_*_backward
 `check_status()` raises if a fused step overflowed a tile bucket; `step_safe()` re-runs such a step in
 "exact" mode.  Both modes produce the same numbers (tests/test_hotpath_gpu.py).
+
+The gradient image of a step is either given (`set_v_out`) or -- `set_target(gt)` -- the L2-loss gradient of the
+image the step itself renders, 2/(3HW) * (clamp(out,0,1) - gt) as in the reference's training loop
+(models/gaussianimage_cholesky.py:302-317 with loss_type "L2"); the fused tile pass forms it per pixel in
+registers, the exact mode with torch ops between its forward and backward calls.
 """
 from __future__ import annotations
 
@@ -51,6 +57,9 @@ class HotPath:
         self.status = i32(4)
         self.out_img, self.final_idx = f32(h, w, 3), i32(h, w)
         self.v_out = f32(h, w, 3)
+        self.target = None            # set_target(): L2 loss against this image instead of a given v_out
+        self.tile_sse = f32(self.T)
+        self.grad_scale = 2.0 / (3.0 * h * w)
         self.v_xy, self.v_conic, self.v_rgb, self.v_opac = f32(n, 2), f32(n, 3), f32(n, 3), f32(n, 1)
         self.v_cov2d, self.v_mean2d, self.v_params = f32(n, 3), f32(n, 2), f32(n, 2 if kind == "scale_rot" else 3)
         # fused-path workspace (cursors zeroed once; every forward leaves them zero)
@@ -80,6 +89,11 @@ class HotPath:
         self._f_fwd = (L.gi2d_fast_rasterize_forward, "fast rasterize forward",
                        [n, tx, ty, w, h, p(self.xys), p(self.radii), p(self.conics), p(self.colors), p(self.opac),
                         None, ws, wsb, p(self.status), None, None, p(self.out_img)])
+        tgt = p(self.target) if self.target is not None else None
+        self._f_both = (L.gi2d_fast_rasterize_forward_backward, "fast rasterize forward+backward",
+                        [n, tx, ty, w, h, p(self.xys), p(self.radii), p(self.conics), p(self.colors), p(self.opac),
+                         None, None if tgt else p(self.v_out), tgt, self.grad_scale, p(self.tile_sse), ws, wsb,
+                         p(self.status), p(self.out_img)])
         self._f_tiles = (L.gi2d_fast_rasterize_backward_tiles, "fast rasterize backward tiles",
                          [n, tx, ty, w, h, None, p(self.v_out), 0, ws, wsb])
         self._f_red = (L.gi2d_fast_reduce_project_backward, "fast reduce+project backward",
@@ -148,7 +162,26 @@ class HotPath:
             dst.copy_(torch.as_tensor(np.ascontiguousarray(src) if isinstance(src, np.ndarray) else src).to(self.dev))
 
     def set_v_out(self, v_out: torch.Tensor):
+        """Use a fixed gradient image dL/d(out_img) [H,W,3]."""
         self.v_out.copy_(v_out)
+        if self.target is not None:
+            self.target = None
+            self._build_fused_calls()
+
+    def set_target(self, gt: torch.Tensor):
+        """Use the L2 loss mean((clamp(out,0,1) - gt)^2) of each step's own render: gt [H,W,3] in [0,1]."""
+        self.target = gt.to(self.dev, torch.float32).contiguous().clone()
+        self._build_fused_calls()
+
+    def _l2_grad_from_render(self):
+        """v_out <- d mean((clamp(out,0,1)-gt)^2) / d out, tile_sse-equivalent loss in self.loss_value (torch ops)."""
+        o = self.out_img
+        d = o.clamp(0, 1) - self.target
+        self.v_out.copy_(torch.where((o >= 0) & (o <= 1), self.grad_scale * d, torch.zeros_like(d)))
+
+    def loss(self) -> float:
+        """L2 loss of the last fused step with a target (sum of the per-tile squared errors / (3HW))."""
+        return float(self.tile_sse.double().sum().item()) / (3.0 * self.h * self.w)
 
     # ------------------------------------------------------------------ the path
     def forward(self) -> torch.Tensor:
@@ -175,6 +208,8 @@ class HotPath:
     def backward(self, timer=None, index: int = 0):
         st = self._stream()
         with torch.cuda.device(self.dev):
+            if self.target is not None:
+                self._l2_grad_from_render()
             if timer is not None:
                 timer["bwd0"][index].record()
             self._run(self._f_tiles if self.mode == "fused" else self._e_tiles, st)
@@ -192,10 +227,12 @@ class HotPath:
             if self.mode == "fused":
                 self._run(self._f_bin, st)
                 if timer is not None:
-                    timer["fwd0"][index].record()
-                self._run(self._f_fwd, st)
+                    timer["rast0"][index].record()
+                self._run(self._f_both, st)
                 if timer is not None:
-                    timer["fwd1"][index].record()
+                    timer["rast1"][index].record()
+                self._run(self._f_red, st)
+                return
             else:
                 if not self._exact_ready:
                     self._exact_forward(st)
@@ -249,6 +286,8 @@ class HotPath:
 
     def kernel_timers(self, steps: int):
         mk = lambda: [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        if self.mode == "fused":
+            return {"rast0": mk(), "rast1": mk()}
         return {"fwd0": mk(), "fwd1": mk(), "bwd0": mk(), "bwd1": mk()}
 
     def _avg_us(self, ev, a, b):
@@ -256,29 +295,38 @@ class HotPath:
         return float(np.mean(ts)), float(np.min(ts))
 
     def dominant_kernel_stats(self, ev):
-        """The longer of the two rasterizer kernels (HIP-event spans of this run) with its algorithmic bytes per
-        launch: forward 40*M + 20*H*W, backward tiles 40*M + 16*H*W + 36*N."""
+        """The dominant kernel of a step (HIP-event spans of this run) with its algorithmic bytes per launch
+        (SURVEY 8d): forward 40*M + 20*H*W, backward tiles 40*M + 16*H*W + 36*N; the fused tile pass does both."""
         m = self.num_intersects()
+        if self.mode == "fused":
+            avg, mn = self._avg_us(ev, "rast0", "rast1")
+            return {"name": "gi2d::fast_fwdbwd_kernel<%d>" % (1 if self.target is not None else 0), "avg_us": avg,
+                    "min_us": mn, "bytes": 80 * m + 36 * self.h * self.w + 36 * self.n}
         f_avg, f_min = self._avg_us(ev, "fwd0", "fwd1")
         b_avg, b_min = self._avg_us(ev, "bwd0", "bwd1")
-        fused = self.mode == "fused"
         if f_avg >= b_avg:
-            return {"name": "gi2d::fast_fwd_kernel" if fused else "gi2d::raster_fwd_kernel", "avg_us": f_avg,
-                    "min_us": f_min, "bytes": 40 * m + 20 * self.h * self.w}
-        return {"name": "gi2d::fast_bwd_kernel<false>" if fused else "gi2d::raster_bwd_kernel<false>", "avg_us": b_avg,
-                "min_us": b_min, "bytes": 40 * m + 16 * self.h * self.w + 36 * self.n}
+            return {"name": "gi2d::raster_fwd_kernel", "avg_us": f_avg, "min_us": f_min,
+                    "bytes": 40 * m + 20 * self.h * self.w}
+        return {"name": "gi2d::raster_bwd_kernel<false>", "avg_us": b_avg, "min_us": b_min,
+                "bytes": 40 * m + 16 * self.h * self.w + 36 * self.n}
 
     def pair_stats(self, ev, pair_bytes):
-        f_avg, _ = self._avg_us(ev, "fwd0", "fwd1")
-        b_avg, _ = self._avg_us(ev, "bwd0", "bwd1")
         m = self.num_intersects()
-        return {"fwd_kernel_us": f_avg, "bwd_tile_kernel_us": b_avg, "algorithmic_bytes": pair_bytes,
-                "achieved_GBps": pair_bytes / ((f_avg + b_avg) * 1e-6) / 1e9,
-                "pixel_gaussian_pairs_per_s": 2 * 256.0 * m / ((f_avg + b_avg) * 1e-6),
-                "note": "HIP-event spans of the two rasterizer kernels inside the timed loop"}
+        if self.mode == "fused":
+            t_avg, _ = self._avg_us(ev, "rast0", "rast1")
+            extra = {"fwdbwd_kernel_us": t_avg}
+        else:
+            f_avg, _ = self._avg_us(ev, "fwd0", "fwd1")
+            b_avg, _ = self._avg_us(ev, "bwd0", "bwd1")
+            t_avg = f_avg + b_avg
+            extra = {"fwd_kernel_us": f_avg, "bwd_tile_kernel_us": b_avg}
+        extra.update({"algorithmic_bytes": pair_bytes, "achieved_GBps": pair_bytes / (t_avg * 1e-6) / 1e9,
+                      "pixel_gaussian_pairs_per_s": 2 * 256.0 * m / (t_avg * 1e-6),
+                      "note": "HIP-event span of the rasterizer kernel(s) inside the timed loop"})
+        return extra
 
     def describe(self) -> str:
         if self.mode == "fused":
-            return ("HotPath[fused]: 4 C-ABI calls/step (project+bin, rasterize fwd, bwd tiles, reduce+project bwd) on "
+            return ("HotPath[fused]: 3 C-ABI calls/step (project+bin, rasterize fwd+bwd tile pass, reduce+project bwd) on "
                     "persistent HBM buffers, eager launches on the current HIP stream")
         return f"HotPath[exact]: 6 C-ABI calls/step, intersection capacity {self.capacity}"

@@ -270,6 +270,23 @@ int gi2d_fast_rasterize_forward(int num_points, int tiles_x, int tiles_y, unsign
                                 const float *background, void *workspace, size_t workspace_bytes,
                                 int32_t *status, float *final_Ts, int32_t *final_idx,
                                 float *out_img, gi2d_stream_t stream);
+/* Forward AND backward tiles in ONE launch (one workgroup per tile ranks / gathers / stages its
+ * gaussians once and runs both passes on them).  Exactly one of:
+ *   v_output f32[H,W,3]  the gradient image is given (it cannot depend on this call's out_img);
+ *   target   f32[H,W,3]  the gradient is the L2-loss gradient formed per pixel from the pixel the
+ *                        forward has just produced: grad_scale * (clamp(out,0,1) - target), zero
+ *                        where out is outside [0,1] (models/gaussianimage_cholesky.py:307-310,
+ *                        loss_type "L2": grad_scale = 2/(3*H*W)); tile_sse f32[tiles] receives the
+ *                        per-tile sum of squared errors (loss = sum(tile_sse)/(3*H*W)).
+ * Leaves the workspace exactly as gi2d_fast_rasterize_forward + _backward_tiles(with_abs=0) would
+ * for the reduce calls below, except that the packed record list is not written. */
+int gi2d_fast_rasterize_forward_backward(int num_points, int tiles_x, int tiles_y, unsigned img_width,
+                                         unsigned img_height, const float *xys, const int32_t *radii,
+                                         const float *conics, const float *colors,
+                                         const float *opacities, const float *background,
+                                         const float *v_output, const float *target, float grad_scale,
+                                         float *tile_sse, void *workspace, size_t workspace_bytes,
+                                         int32_t *status, float *out_img, gi2d_stream_t stream);
 int gi2d_fast_rasterize_backward_tiles(int num_points, int tiles_x, int tiles_y, unsigned img_width,
                                        unsigned img_height, const int32_t *final_idx,
                                        const float *v_output, int with_abs, void *workspace,

@@ -219,3 +219,52 @@ def test_2k_image_config4_size_properties():
     lhs = float((v.double() * res[0][0].double()).sum())
     rhs = float((res[0][1].double() * torch.from_numpy(col).to(DEV).double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs)) + 1e-9
+
+
+@pytest.mark.parametrize("n,h,w", [(6000, 256, 384), (900, 70, 100), (50000, 512, 768), (380, 16, 16)])
+def test_single_pass_step_equals_separate_forward_backward(n, h, w):
+    """step() runs forward and backward of a tile in ONE kernel (gi2d_fast_rasterize_forward_backward); the result
+    must equal forward() + backward() (two kernels) and the capacity-free ops bit for bit."""
+    one, _ = _mk("fused", n, h, w, seed=21)
+    two, _ = _mk("fused", n, h, w, seed=21)
+    exact, _ = _mk("exact", n, h, w, seed=21)
+    v = _v_out(h, w, 6)
+    for hp in (one, two, exact):
+        hp.set_v_out(v)
+    one.step()
+    one.step()  # twice: the bucket cursors must come back clean
+    one.check_status()
+    two.forward()
+    two.backward()
+    exact.step()
+    for name in ("out_img", "v_xy", "v_conic", "v_rgb", "v_opac", "v_mean2d", "v_params"):
+        a, b, c = getattr(one, name), getattr(two, name), getattr(exact, name)
+        assert torch.equal(a, b), name
+        assert torch.equal(a, c), name
+
+
+@pytest.mark.parametrize("n,h,w", [(6000, 256, 384), (900, 70, 100)])
+def test_single_pass_l2_target_matches_torch_loss_gradient(n, h, w):
+    """set_target(): the tile pass forms the L2-loss gradient from its own pixel; exact mode does the same with
+    torch ops between its forward and backward calls (same fp32 operations -> same bits)."""
+    fused, _ = _mk("fused", n, h, w, seed=22)
+    exact, _ = _mk("exact", n, h, w, seed=22)
+    gt = torch.from_numpy(synth_gt(h, w, 5)).to(DEV)
+    # push some pixels outside [0,1] so the clamp's zero-gradient branch is exercised
+    fused.colors.mul_(1.8)
+    exact.colors.mul_(1.8)
+    for hp in (fused, exact):
+        hp.set_target(gt)
+        hp.step()
+        hp.check_status()
+    assert float((fused.out_img > 1).float().mean()) > 0.001
+    for name in ("out_img", "v_xy", "v_conic", "v_rgb", "v_opac", "v_mean2d", "v_params"):
+        assert torch.equal(getattr(fused, name), getattr(exact, name)), name
+    want = torch.nn.functional.mse_loss(fused.out_img.clamp(0, 1), gt).item()
+    assert abs(fused.loss() - want) <= 1e-5 * want
+    # and autograd agrees with the hand-written gradient image
+    o = fused.out_img.clone().requires_grad_(True)
+    torch.nn.functional.mse_loss(o.clamp(0, 1), gt).backward()
+    exact._l2_grad_from_render()
+    inner = (fused.out_img > 0) & (fused.out_img < 1)
+    assert torch.allclose(exact.v_out[inner], o.grad[inner], rtol=1e-6, atol=0)
