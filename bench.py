@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--width", type=int, default=768)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--train-step", action="store_true",
+                   help="also time the whole training iteration (gi2d_train_step) after the timed region")
     return p.parse_args()
 
 
@@ -78,8 +80,8 @@ def main():
     for _ in range(args.warmup):
         hp.step()
     barrier()
-    # HIP events around the rasterizer tile pass on the launch stream, on every EVENT_STRIDE-th step of the
-    # timed region (each record costs ~3 us of launch-queue time, so timing every step would slow the loop)
+    # HIP start/stop events attached to the rasterizer tile-pass dispatch (gi2d_timer_*: the kernel's own begin/end
+    # timestamps on the launch stream), on every EVENT_STRIDE-th step of the timed region
     n_timed = max(1, args.steps // EVENT_STRIDE)
     ev = hp.kernel_timers(n_timed)
     t0 = time.perf_counter()
@@ -132,7 +134,8 @@ def main():
             },
             "rasterize_pair": hp.pair_stats(ev, pair_bytes),
         }
-        line["train_step"] = train_step_rate(gt, n, dev)
+        if args.train_step:
+            line["train_step"] = train_step_rate(gt, n, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(xyz, L, col, op, h, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)
@@ -160,7 +163,7 @@ def pmc_traffic(kernel, n, h, w):
 
 def train_step_rate(gt, n, dev, iters=400):
     """Extra information, not `value`: the whole training iteration (hot path + L2 loss gradient + Adam update,
-    gi2d_train_step = 4 launches, no host sync) on the same image size / gaussian count, measured after the
+    gi2d_train_step = 3 launches, no host sync) on the same image size / gaussian count, measured after the
     timed region."""
     from gaussianimage_plus_amd.trainer import NativeFitter
     fit = NativeFitter(gt.contiguous(), n, kind="cholesky", lr=1e-3, seed=3047)

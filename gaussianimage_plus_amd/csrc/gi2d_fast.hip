@@ -19,6 +19,8 @@
 //
 // Capacity contract: at most GI2D_FAST_CSUB ids per (tile, sub-bucket).  A fuller bucket sets
 // status[1] and the caller must fall back to the exact path (gi2d_bin_gaussians + plain ops).
+#include <hip/hip_ext.h>
+
 #include "gi2d_fused_core.h"
 
 namespace gi2d {
@@ -81,9 +83,12 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
 // -------------------------------------------------------------------------------------- forward
 struct FastFwdLds {
     FwdLds f;
-    int ids[GI2D_FAST_C];
     int cnt[GI2D_FAST_SUB];
-    float4 soa[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats: pair-interleaved copy of 64 list entries
+    union {  // the id sort buffer is dead once the records are staged
+        int ids[GI2D_FAST_C];
+        float4 soa[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats: pair-interleaved copy of 64 list entries,
+                                       // afterwards the RGB transpose stage
+    };
 };
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
@@ -170,10 +175,11 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     // fix-up kernel for that corner case.
     if (final_idx)
         fwd_rasterize_staged<true>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
-                                   final_Ts, final_idx, out_img);
+                                   final_Ts, final_idx, out_img, reinterpret_cast<float *>(sm.soa));
     else
         fwd_rasterize_staged<false>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
-                                    final_Ts, final_idx, out_img, reinterpret_cast<float *>(sm.soa));
+                                    final_Ts, final_idx, out_img, reinterpret_cast<float *>(sm.soa),
+                                    reinterpret_cast<float *>(sm.soa));
     if (tid == 0 && L > 0) status[0] = 1;
 }
 
@@ -314,7 +320,65 @@ static int check_ws(const char *what, void *ws, size_t ws_bytes, int n, int tile
 
 using namespace gi2d;
 
+// Kernel timer (bench.py): start/stop events attached to ONE dispatch with hipExtLaunchKernelGGL read the
+// kernel's own begin/end timestamps -- what rocprofv3's kernel trace reports -- instead of the span between
+// two stream markers, which also contains marker processing and dispatch latency.
+struct KernelTimer {
+    hipEvent_t begin, end;
+};
+static thread_local KernelTimer *g_armed_timer = nullptr;
+#define GI2D_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                                        \
+    do {                                                                                                           \
+        if (g_armed_timer) {                                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_armed_timer->begin, g_armed_timer->end, 0,     \
+                                  __VA_ARGS__);                                                                    \
+            g_armed_timer = nullptr;                                                                               \
+        } else {                                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                       \
+        }                                                                                                          \
+    } while (0)
+
 extern "C" {
+
+int gi2d_timer_create(void **timer) {
+    if (!timer) return GI2D_ERR_INVALID_ARGUMENT;
+    KernelTimer *t = new KernelTimer;
+    hipError_t e = hipEventCreate(&t->begin);
+    if (e == hipSuccess) e = hipEventCreate(&t->end);
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        delete t;
+        return (int)e;
+    }
+    *timer = t;
+    return GI2D_OK;
+}
+int gi2d_timer_destroy(void *timer) {
+    KernelTimer *t = (KernelTimer *)timer;
+    if (!t) return GI2D_OK;
+    if (g_armed_timer == t) g_armed_timer = nullptr;
+    hipEventDestroy(t->begin);
+    hipEventDestroy(t->end);
+    delete t;
+    return GI2D_OK;
+}
+int gi2d_timer_arm(void *timer) {
+    g_armed_timer = (KernelTimer *)timer;
+    return GI2D_OK;
+}
+int gi2d_timer_elapsed_us(void *timer, float *us) {
+    KernelTimer *t = (KernelTimer *)timer;
+    if (!t || !us) return GI2D_ERR_INVALID_ARGUMENT;
+    hipError_t e = hipEventSynchronize(t->end);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, t->begin, t->end);
+    if (e != hipSuccess) {
+        set_error(hipGetErrorString(e));
+        return (int)e;
+    }
+    *us = ms * 1e3f;
+    return GI2D_OK;
+}
 
 size_t gi2d_fast_workspace_bytes(int n, int tiles_x, int tiles_y) {
     return carve_fast(nullptr, n, tiles_x * tiles_y).bytes;
@@ -424,16 +488,17 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
+    float *no_sse = nullptr;
     if (v_output)
-        hipLaunchKernelGGL(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
-                           (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors, w.buckets,
-                           w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big, status, out_img, v_output,
-                           0.f, nullptr);
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
+                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors,
+                          (const int32_t *)w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big,
+                          status, out_img, v_output, 0.f, no_sse);
     else
-        hipLaunchKernelGGL(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
-                           (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors, w.buckets,
-                           w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big, status, out_img, target,
-                           grad_scale, tile_sse);
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
+                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors,
+                          (const int32_t *)w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big,
+                          status, out_img, target, grad_scale, tile_sse);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);
@@ -511,6 +576,12 @@ int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const fl
 #undef GI2D_LAUNCH_RP
     return check_launch("fast reduce+project backward");
 }
+
+#ifdef GI2D_FUSED_TRACE
+int gi2d_debug_set_trace(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_trace), &buf, sizeof(buf));
+}
+#endif
 
 // Views into the workspace for callers that want the binning result itself (tests, debugging).
 int gi2d_fast_workspace_views(void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y,

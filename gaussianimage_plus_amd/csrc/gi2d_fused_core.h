@@ -16,12 +16,29 @@
 namespace gi2d {
 
 #ifndef GI2D_FUSED_OCC
-#define GI2D_FUSED_OCC 5 /* workgroups per CU the register allocator leaves room for (LDS: 29 KB -> 5) */
+#define GI2D_FUSED_OCC 6 /* workgroups per CU the register allocator leaves room for: 1536 tiles of a 768x512 image
+                            are then resident at once (measured: a 27 KB workgroup still gets only 5 per CU and a
+                            second, 256-workgroup round; 23.7 KB gets 6) */
+#endif
+
+// Development aid (-DGI2D_FUSED_TRACE): thread 0 of every workgroup stamps the 100 MHz wall clock at the phase
+// boundaries into a buffer set with gi2d_debug_set_trace (tools/trace_fused.py).
+#ifdef GI2D_FUSED_TRACE
+__device__ unsigned long long *g_fused_trace = nullptr;  // [tiles][8]
+#define GI2D_TRACE(i)                                                                  \
+    do {                                                                               \
+        if (threadIdx.x == 0 && g_fused_trace) g_fused_trace[tile * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define GI2D_TRACE(i) \
+    do {              \
+    } while (0)
 #endif
 
 struct FusedLds {
     static constexpr int PSTR = 9;
     static constexpr bool HAS_FIDX = false;
+    static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
     typedef float2 PixB;
     float4 gA[GI2D_TILE_LIST_CAP + 1];  // gx, gy, a, b        (entry CAP: the forward's never-contributing padding)
     float4 gB[GI2D_TILE_LIST_CAP + 1];  // c, opac, cr, cg
@@ -43,7 +60,7 @@ struct FusedLds {
             float2 pixB[GI2D_TILE * GI2D_BWD_PIXROW];
             unsigned short off[GI2D_TILE_LIST_CAP + 4];
             unsigned char item[8 * GI2D_TILE_LIST_CAP];
-            float part[GI2D_BWD_ITEMS * PSTR];
+            float part[GI2D_BWD_PART_ROWS * PSTR];
             unsigned short xr[GI2D_TILE_LIST_CAP];
             int wsum[4];
         };
@@ -69,6 +86,7 @@ __device__ __forceinline__ void fused_tile(
     const bool inside = (i < img_h) && (j < img_w);
     const size_t pix = (size_t)i * img_w + j;
 
+    GI2D_TRACE(0);
     // this lane's pixel of the gradient / target image: issued first, consumed after the forward
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     if (inside) {
@@ -90,6 +108,7 @@ __device__ __forceinline__ void fused_tile(
         sm.gCb[GI2D_TILE_LIST_CAP] = 0.f;
     }
     __syncthreads();
+    GI2D_TRACE(1);
     const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
     int my_id[2];
@@ -105,6 +124,7 @@ __device__ __forceinline__ void fused_tile(
         }
     }
     __syncthreads();
+    GI2D_TRACE(2);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -133,6 +153,7 @@ __device__ __forceinline__ void fused_tile(
     }
     __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
+    GI2D_TRACE(3);
 
     // ---- forward: per-wave list of the entries that reach this wave's 4-row strip, then the packed pair loop
     // (same arithmetic, same order as fwd_rasterize_staged's packed form: bitwise identical pixels)
@@ -146,6 +167,7 @@ __device__ __forceinline__ void fused_tile(
         cnt += __popcll(m);
     }
     __builtin_amdgcn_wave_barrier();
+    GI2D_TRACE(4);
     float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF;
     const float px = (float)j, py = (float)i;
     v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
@@ -192,6 +214,7 @@ __device__ __forceinline__ void fused_tile(
         __builtin_amdgcn_wave_barrier();
     }
     const float o0 = a0.x + a0.y, o1 = a1.x + a1.y, o2 = a2.x + a2.y;
+    GI2D_TRACE(5);
 
     // image out: transpose RGB through the wave's (now idle) pair buffer, 12 x 16-byte stores per pixel row
     const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
@@ -238,6 +261,7 @@ __device__ __forceinline__ void fused_tile(
     }
     __syncthreads();  // every wave is done with its list / pair buffer: the overlay becomes the backward's buffers
 
+    GI2D_TRACE(6);
     // ---- backward on the same staged records
     bwd_publish_pixel(sm, lx, ly, v0, v1, v2, 0.f);
     unsigned cull = 0u;
@@ -248,6 +272,7 @@ __device__ __forceinline__ void fused_tile(
         dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
     }
     bwd_run_tile<false, false>(sm, len, cull, 0, tx0, ty0, dst);
+    GI2D_TRACE(7);
     if (MODE == 1 && tid == 0) tile_sse[tile] = (sm.sse_w[0] + sm.sse_w[1]) + (sm.sse_w[2] + sm.sse_w[3]);
     // "No intersection at all" is a global property: see fast_fwd_kernel
     if (tid == 0 && L > 0) status[0] = 1;

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     const int32_t *__restrict__ num_intersects_dev, float *__restrict__ final_Ts,
     int32_t *__restrict__ final_idx, float *__restrict__ out_img) {
     __shared__ FwdLds sm;
+    __shared__ float stage[4 * GI2D_FWD_STAGE];
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     if (tid == 0) fwd_stage_dummy(sm);
     __syncthreads();
     const bool bg = (num_intersects_dev != nullptr) && (*num_intersects_dev < 1);
-    fwd_rasterize_staged(sm, len, range.x, tx, ty, img_w, img_h, bg, background, final_Ts, final_idx, out_img);
+    fwd_rasterize_staged(sm, len, range.x, tx, ty, img_w, img_h, bg, background, final_Ts, final_idx, out_img, stage);
 }
 
 // ----------------------------------------------------------------------------------- backward

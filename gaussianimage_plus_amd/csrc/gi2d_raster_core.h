@@ -67,8 +67,8 @@ struct FwdLds {
     float C[GI2D_TILE_LIST_CAP + 4];          // cb
     unsigned char strips[GI2D_TILE_LIST_CAP]; // bit w: the gaussian can reach pixel rows 4w..4w+3
     unsigned short list[4][GI2D_TILE_LIST_CAP + 8];  // per-wave ascending indices, padded to x4
-    float stage[4][4 * 48];                   // per-wave RGB transpose buffer
 };
+#define GI2D_FWD_STAGE (4 * 48) /* floats per wave of the RGB transpose buffer the caller provides */
 
 // phase 1 helper: lane `k` publishes its gaussian (list position k of the tile)
 __device__ __forceinline__ void fwd_stage_entry(FwdLds &sm, int k, const GaussRec &r, unsigned mask) {
@@ -86,7 +86,8 @@ __device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
 }
 
 // phases 2-4 of the forward for one tile whose `len` (<= 256) entries are staged in ascending order.
-// Must be called by all 256 lanes after a __syncthreads() that follows the staging.
+// Must be called by all 256 lanes after a __syncthreads() that follows the staging.  `stage_base`: 4 x
+// GI2D_FWD_STAGE floats of LDS; `soa`: 4 x GI2D_FWD_PAIRBUF floats of LDS or nullptr (scalar loop form).
 // NEED_FIDX=false (fast path: nobody consumes final_idx) drops the per-pair index tracking and the store.
 template <bool NEED_FIDX = true>
 __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int list_base, int tx, int ty,
@@ -94,7 +95,8 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
                                                      const float *__restrict__ background,
                                                      float *__restrict__ final_Ts,
                                                      int32_t *__restrict__ final_idx,
-                                                     float *__restrict__ out_img, float *soa = nullptr) {
+                                                     float *__restrict__ out_img, float *stage_base,
+                                                     float *soa = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
@@ -233,7 +235,8 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
     // phase 4: transpose RGB through the wave's LDS so a 16-pixel row leaves as 12 x 16-byte stores
     const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
     if (full_tile) {
-        float *stage = sm.stage[wv];  // 4 rows x 48 floats, wave-private
+        // 4 rows x 48 floats, wave-private: the wave's own (now idle) pair buffer, or the caller's stage buffer
+        float *stage = (!NEED_FIDX && soa != nullptr) ? soa + wv * GI2D_FWD_PAIRBUF : stage_base + wv * GI2D_FWD_STAGE;
         const int r = lane >> 4;
         stage[r * 48 + lx * 3 + 0] = o0;
         stage[r * 48 + lx * 3 + 1] = o1;
@@ -264,6 +267,9 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 // because dy is constant along a row.  A gaussian owns at most 8 items; their partials are handed to the
 // lane that owns the gaussian through LDS and added in row order.
 #define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
+#ifndef GI2D_BWD_PART_ROWS
+#define GI2D_BWD_PART_ROWS 128 /* item rows of the LDS hand-off buffer (256: one pass per round, +4.5 KB LDS) */
+#endif
 #ifndef GI2D_BWD_OCC
 #define GI2D_BWD_OCC 5 /* waves per SIMD the register allocator must leave room for; measured: 5 (96 VGPRs) beats 6 (80) */
 #endif
@@ -298,7 +304,8 @@ struct BwdLds {
     float gCb[GI2D_TILE_LIST_CAP];  // cb
     unsigned short off[GI2D_TILE_LIST_CAP + 2];     // exclusive prefix of items per gaussian
     unsigned char item[8 * GI2D_TILE_LIST_CAP];     // k: the item's gaussian (its row pair follows from off[k])
-    float part[GI2D_BWD_ITEMS * PSTR];
+    static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
+    float part[PART_ROWS * PSTR];
     unsigned short xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | q0 << 8 | q1 << 12 per gaussian
     int wsum[4];
 };
@@ -390,6 +397,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
     do {
         const int round1 = min(n_items, round0 + GI2D_BWD_ITEMS);
         const int it = round0 + tid;
+        float res[PSTR];
         if (it < round1) {
             const int k = sm.item[it];
             const unsigned xr = sm.xr[k];
@@ -464,46 +472,58 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                 c2 -= 0.5f * dy * dys0;                  // sum 0.5 v_sigma dy dy
                 gop += s0;                               // sum opac*vis*v_alpha
             }
-            float *out = &sm.part[tid * PSTR];
-            out[0] = vx;
-            out[1] = vy;
-            out[2] = c0;
-            out[3] = c1;
-            out[4] = c2;
-            out[5] = gr.x + gr.y;
-            out[6] = gg.x + gg.y;
-            out[7] = gb.x + gb.y;
-            out[8] = (gop != 0.f) ? gop / opac : 0.f;  // v_opacity = sum vis*v_alpha (backward.cu:961)
+            res[0] = vx;
+            res[1] = vy;
+            res[2] = c0;
+            res[3] = c1;
+            res[4] = c2;
+            res[5] = gr.x + gr.y;
+            res[6] = gg.x + gg.y;
+            res[7] = gb.x + gb.y;
+            res[8] = (gop != 0.f) ? gop / opac : 0.f;  // v_opacity = sum vis*v_alpha (backward.cu:961)
             if (WITH_ABS) {
-                out[9] = ax.x + ax.y;
-                out[10] = ay.x + ay.y;
+                res[PSTR - 2] = ax.x + ax.y;
+                res[PSTR - 1] = ay.x + ay.y;
             }
         }
-        __syncthreads();
-        // the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row order
-        if (dst != nullptr) {
-            const int my_lo = sm.off[tid], my_hi = sm.off[tid + 1];
-            const int lo = max(my_lo, round0), hi = min(my_hi, round1);
-            if (hi > lo || (round0 == 0 && my_hi == my_lo)) {  // a gaussian without items still owes a zero row
-                float acc[PSTR];
+        // hand-off: the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row
+        // order.  The LDS exchange buffer holds PART_ROWS item rows, so a round is handed over in
+        // GI2D_BWD_ITEMS / PART_ROWS passes (half the buffer = two more barriers, 4.5 KB less LDS per workgroup).
+        constexpr int PROWS = Lds::PART_ROWS;
+        int my_lo = 0, my_hi = 0;
+        if (dst != nullptr) my_lo = sm.off[tid], my_hi = sm.off[tid + 1];
+        const int lo = max(my_lo, round0), hi = min(my_hi, round1);
+        // a gaussian without items still owes a zero row
+        const bool owner = dst != nullptr && (hi > lo || (round0 == 0 && my_hi == my_lo));
+        float acc[PSTR];
 #pragma unroll
-                for (int q = 0; q < PSTR; ++q) acc[q] = 0.f;
-                if (my_lo < round0) {  // earlier round(s) already stored part of this row
-                    const float4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
-                    acc[0] = d0.x, acc[1] = d0.y, acc[2] = d0.z, acc[3] = d0.w;
-                    acc[4] = d1.x, acc[5] = d1.y, acc[6] = d1.z, acc[7] = d1.w;
-                    acc[8] = d2.x;
-                    if (PSTR > 9) acc[PSTR - 2] = d2.y, acc[PSTR - 1] = d2.z;
-                }
-                for (int e = lo; e < hi; ++e) {
-                    const float *in = &sm.part[(e - round0) * PSTR];
+        for (int q = 0; q < PSTR; ++q) acc[q] = 0.f;
+        if (owner && my_lo < round0) {  // earlier round(s) already stored part of this row
+            const float4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
+            acc[0] = d0.x, acc[1] = d0.y, acc[2] = d0.z, acc[3] = d0.w;
+            acc[4] = d1.x, acc[5] = d1.y, acc[6] = d1.z, acc[7] = d1.w;
+            acc[8] = d2.x;
+            if (PSTR > 9) acc[PSTR - 2] = d2.y, acc[PSTR - 1] = d2.z;
+        }
+#pragma unroll
+        for (int h0 = 0; h0 < GI2D_BWD_ITEMS; h0 += PROWS) {
+            if (it < round1 && tid >= h0 && tid < h0 + PROWS) {
+                float *out = &sm.part[(tid - h0) * PSTR];
+#pragma unroll
+                for (int q = 0; q < PSTR; ++q) out[q] = res[q];
+            }
+            __syncthreads();
+            if (owner) {
+                const int e0 = max(lo, round0 + h0), e1 = min(hi, round0 + h0 + PROWS);
+                for (int e = e0; e < e1; ++e) {
+                    const float *in = &sm.part[(e - round0 - h0) * PSTR];
 #pragma unroll
                     for (int q = 0; q < PSTR; ++q) acc[q] += in[q];
                 }
-                store_partial_row<PSTR>(dst, acc);
             }
+            __syncthreads();
         }
-        __syncthreads();
+        if (owner) store_partial_row<PSTR>(dst, acc);
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);
 }

@@ -231,8 +231,9 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
                                    gi2d_stream_t stream);
 
 /* ------------------------------------------------------------------ fused fast path
- * The whole per-iteration path in 4 launches (project+fill, forward, backward tiles,
- * reduce+project backward) on one caller-owned workspace.  Results equal the ops above
+ * The whole per-iteration path in 3 launches (project+fill, forward+backward tile pass,
+ * reduce+project backward; 4 when forward and backward tiles are issued separately) on one
+ * caller-owned workspace.  Results equal the ops above
  * (bit-identical index work; the same per-pair arithmetic).  Contract:
  *   - workspace: gi2d_fast_workspace_bytes(N, tiles_x, tiles_y) bytes, initialised ONCE with
  *     gi2d_fast_workspace_init (zeroes the bucket cursors; every forward leaves them zero again).
@@ -305,12 +306,21 @@ int gi2d_fast_reduce_project_backward(int kind, int num_points, const float *p0,
                                       float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
                                       gi2d_stream_t stream);
 
+/* Kernel timer for measurement code: an armed timer attaches start/stop events to the NEXT
+ * gi2d_fast_rasterize_forward_backward launch issued by the calling thread (hipExtLaunchKernelGGL), so
+ * gi2d_timer_elapsed_us returns that kernel's own execution time -- the figure rocprofv3's kernel
+ * trace reports -- rather than a span between stream markers.  elapsed_us waits for the kernel. */
+int gi2d_timer_create(void **timer);
+int gi2d_timer_destroy(void *timer);
+int gi2d_timer_arm(void *timer);
+int gi2d_timer_elapsed_us(void *timer, float *microseconds);
+
 /* ------------------------------------------------------------------ fused fitting iteration
  * SURVEY 8f rank 2 (callers either side of the path): one whole training iteration of the
  * Cholesky (kind 0) or covariance (kind 1) model with L2 loss and Adam --
  * models/gaussianimage_cholesky.py:302-317 / models/gaussianimage_covariance.py:249-259 --
- * in four launches: activations+projection+fill, rasterize forward, backward with the loss
- * gradient formed while staging pixels, gradient reduce + projection backward + activation
+ * in three launches: activations+projection+fill, one tile pass (rasterize forward, loss
+ * gradient formed per pixel in registers, backward), gradient reduce + projection backward + activation
  * backward + torch.optim.Adam update.  All pointers are device pointers owned by the caller.
  *   xyz   f32[N,2]  raw positions (kind 0: pre-tanh; kind 1: pixels)      updated in place
  *   chol  f32[N,3]  raw Cholesky / covariance triple (bound is added)     updated in place

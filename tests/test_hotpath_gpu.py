@@ -1,4 +1,5 @@
-"""GPU: the fused 4-launch fast path (gi2d_fast_*) against the capacity-free ops and the oracle."""
+"""GPU: the fused fast path (gi2d_fast_*; two-kernel and single-pass tile forms) against the capacity-free ops and
+the oracle."""
 import numpy as np
 import pytest
 import torch
