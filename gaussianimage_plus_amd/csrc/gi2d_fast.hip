@@ -17,7 +17,8 @@
 //   reduce   is a single level of coalesced loads per gaussian (fixed ascending-tile order: bitwise
 //            reproducible); optionally fused with the projection backward (reduce_project).
 //
-// Capacity contract: at most GI2D_FAST_CSUB ids per (tile, sub-bucket).  A fuller bucket sets
+// Capacity contract: at most GI2D_FAST_CSUB (256) ids per (tile, sub-bucket), i.e. up to 1024 candidates per tile
+// of which the 256 lowest ids are rasterized (forward.cu:553).  A fuller bucket sets
 // status[1] and the caller must fall back to the exact path (gi2d_bin_gaussians + plain ops).
 #include <hip/hip_ext.h>
 
@@ -36,8 +37,7 @@ __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__r
     if (g == 0) {
         status[0] = 0;
         status[1] = 0;
-        status[2] = 0;
-        status[3] = 0;
+        status[3] = 0;  // status[2] is sticky (any overflow since the caller last cleared it)
     }
     if (g >= n) return;
     const int rad = radii[g];
@@ -59,8 +59,7 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
     if (g == 0) {
         status[0] = 0;
         status[1] = 0;
-        status[2] = 0;
-        status[3] = 0;
+        status[3] = 0;  // status[2] is sticky (any overflow since the caller last cleared it)
     }
     if (g >= n) return;
     const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
@@ -109,7 +108,10 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     if (tid < GI2D_FAST_SUB) {
         const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
         cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
-        if (c > GI2D_FAST_CSUB) atomicOr(&status[1], 1);
+        if (c > GI2D_FAST_CSUB) {
+            atomicOr(&status[1], 1);
+            atomicOr(&status[2], 1);
+        }
         sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
     }
     if (tid == 0) fwd_stage_dummy(sm.f);
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
 #if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 1
     if (tiles_x > 0) return;  // + cursors
 #endif
-    // my (up to two) bucket entries
-    int my_id[2];
+    // my (up to GI2D_FAST_EPT) bucket entries
+    int my_id[GI2D_FAST_EPT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
         const int e = tid + 256 * u;
         my_id[u] = -1;
         if (e < L) {
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
 #endif
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
         if (my_id[u] < 0) continue;
         const int g = my_id[u];
         // issue the gathers first; the rank loop below runs under their latency

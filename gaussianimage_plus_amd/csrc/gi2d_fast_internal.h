@@ -8,8 +8,9 @@ namespace gi2d {
 
 
 #define GI2D_FAST_SUB 4
-#define GI2D_FAST_CSUB 128
+#define GI2D_FAST_CSUB 256
 #define GI2D_FAST_C (GI2D_FAST_SUB * GI2D_FAST_CSUB) /* list slots per tile */
+#define GI2D_FAST_EPT (GI2D_FAST_C / 256)            /* bucket entries per lane of the 256-lane tile workgroup */
 #define GI2D_FAST_S 16                               /* gaussian-major partial rows per gaussian */
 #define GI2D_BIG_TILES_F 32
 #define GI2D_FAST_ROW 4 /* float4 per partial row: 48 bytes of data padded to one 64-byte line */

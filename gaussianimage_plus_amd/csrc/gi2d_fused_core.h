@@ -99,7 +99,10 @@ __device__ __forceinline__ void fused_tile(
     if (tid < GI2D_FAST_SUB) {
         const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
         cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
-        if (c > GI2D_FAST_CSUB) atomicOr(&status[1], 1);
+        if (c > GI2D_FAST_CSUB) {
+            atomicOr(&status[1], 1);
+            atomicOr(&status[2], 1);
+        }
         sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
     }
     if (tid == 0) {
@@ -111,9 +114,9 @@ __device__ __forceinline__ void fused_tile(
     GI2D_TRACE(1);
     const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
-    int my_id[2];
+    int my_id[GI2D_FAST_EPT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
         const int e = tid + 256 * u;
         my_id[u] = -1;
         if (e < L) {
@@ -127,7 +130,7 @@ __device__ __forceinline__ void fused_tile(
     GI2D_TRACE(2);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
         if (my_id[u] < 0) continue;
         const int g = my_id[u];
         const GaussRec r = load_gaussian(g, xys, conics, colors, opacities);  // gathers in flight under the rank loop

@@ -29,6 +29,16 @@ struct TrainParams {
     float *m_xyz, *v_xyz, *m_chol, *v_chol, *m_feat, *v_feat;
 };
 
+// Best-model snapshot kept on the device (train.py:133-139 deep-copies the state dict on the host whenever the
+// PSNR improves): best_sse[2] ping-pongs between steps so every workgroup of a launch reads the same value.
+struct BestSnap {
+    float *xyz, *chol, *feat, *bound;  // [N,2], [N,3], [N,3], [N,3] or null (bound_stride 0)
+    float *sse;                        // [2]
+    int32_t *info;                     // [2]: num_points, step of the snapshot
+    const float *tile_sse;
+    int num_tiles, step;
+};
+
 template <int KIND>
 __device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &mean, float (&par)[3]) {
     const float x = P.xyz[2 * g], y = P.xyz[2 * g + 1];
@@ -51,8 +61,7 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     if (g == 0) {
         status[0] = 0;
         status[1] = 0;
-        status[2] = 0;
-        status[3] = 0;
+        status[3] = 0;  // status[2] is sticky (any overflow since the caller last cleared it)
     }
     if (g >= n) return;
     float2 mean;
@@ -70,67 +79,6 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
         tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
         fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
     }
-}
-
-// Pixel staging of the backward with the L2 loss gradient formed on the fly; returns this lane's squared error.
-template <class Lds>
-__device__ __forceinline__ float bwd_stage_pixels_l2(Lds &sm, int tx, int ty, int img_w, int img_h,
-                                                     const float *__restrict__ out_img,
-                                                     const float *__restrict__ gt, float grad_scale) {
-    const int tid = threadIdx.x;
-    const int lx = tid & 15, ly = tid >> 4;
-    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
-    float v[3] = {0.f, 0.f, 0.f};
-    float sse = 0.f;
-    if (i < img_h && j < img_w) {
-        const size_t pix = (size_t)i * img_w + j;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float o = out_img[3 * pix + c];
-            const float oc = fminf(fmaxf(o, 0.f), 1.f);           // torch.clamp(out_img, 0, 1)
-            const float d = oc - gt[3 * pix + c];
-            sse += d * d;
-            v[c] = (o >= 0.f && o <= 1.f) ? grad_scale * d : 0.f;  // clamp passes the gradient on [0, 1]
-        }
-    }
-    bwd_publish_pixel(sm, lx, ly, v[0], v[1], v[2], 0.f);
-    return sse;
-}
-
-__global__ __launch_bounds__(256, GI2D_BWD_OCC) void train_bwd_kernel(
-    int tiles_x, int tiles_y, int img_w, int img_h, const int2 *__restrict__ tile_bins,
-    const GaussRec *__restrict__ packed, const float *__restrict__ out_img, const float *__restrict__ gt,
-    float grad_scale, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
-    float *__restrict__ tile_sse) {
-    __shared__ BwdLds<false, false> sm;
-    __shared__ float sse_w[4];
-    const int tile = blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int2 range = tile_bins[tile];
-    const int full_len = range.y - range.x;
-    const int len = full_len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : (full_len < 0 ? 0 : full_len);
-    float sse = bwd_stage_pixels_l2(sm, tx, ty, img_w, img_h, out_img, gt, grad_scale);
-    // per-tile sum of squared errors, fixed reduction order (bitwise reproducible)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sse += __shfl_xor(sse, d, 64);
-    if (lane == 0) sse_w[wv] = sse;
-    unsigned mask = 0;
-    int slot = 0;
-    if (tid < len) {
-        const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + tid);
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-        sm.gA[tid] = q0;
-        sm.gB[tid] = q1;
-        sm.gCb[tid] = q2.x;
-        slot = __float_as_int(q2.y);
-        mask = (unsigned)__float_as_int(q2.w);
-    }
-    float4 *dst = nullptr;
-    if (tid < len)
-        dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
-    bwd_run_tile<false, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
-    if (tid == 0) tile_sse[tile] = (sse_w[0] + sse_w[1]) + (sse_w[2] + sse_w[3]);  // after >= 1 barrier
 }
 
 struct AdamStep {
@@ -152,9 +100,32 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
-    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads) {
+    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
 #pragma clang fp contract(off)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    // Is the render of THIS step (made with the pre-update parameters) the best so far?  Every workgroup sums
+    // the per-tile squared errors in the same fixed order, so all take the same decision without a host round trip.
+    bool snapshot = false;
+    if (best.sse != nullptr) {
+        __shared__ float red[256];
+        float part = 0.f;
+        for (int t = threadIdx.x; t < best.num_tiles; t += 256) part += best.tile_sse[t];
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+            __syncthreads();
+        }
+        const float total = red[0], prev = best.sse[best.step & 1];
+        snapshot = total < prev;  // train.py:134 `best_psnr < psnr`
+        if (g == 0) {
+            best.sse[(best.step + 1) & 1] = snapshot ? total : prev;
+            if (snapshot) {
+                best.info[0] = n;
+                best.info[1] = best.step;
+            }
+        }
+    }
     float acc[11];
     reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
                partial_g, partial_big, acc);
@@ -208,6 +179,16 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
         P.m_feat[3 * g + q] = mf;
         P.v_feat[3 * g + q] = vf;
+    }
+    if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned)
+        best.xyz[2 * g] = P.xyz[2 * g];
+        best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            best.chol[3 * g + q] = P.chol[3 * g + q];
+            best.feat[3 * g + q] = P.feat[3 * g + q];
+            if (best.bound) best.bound[3 * g + q] = P.bound[(size_t)P.bound_stride * g + q];
+        }
     }
 }
 
@@ -317,17 +298,31 @@ int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, flo
         a[q].one_minus_b2 = (float)(1.0 - (double)beta2);
         a[q].eps = eps;
     }
+    BestSnap best;
+    best.xyz = s->best_xyz;
+    best.chol = s->best_chol;
+    best.feat = s->best_feat;
+    best.bound = s->bound_stride ? s->best_bound : nullptr;
+    best.sse = s->best_sse;
+    best.info = s->best_info;
+    best.tile_sse = s->tile_sse;
+    best.num_tiles = tx * ty;
+    best.step = step;
+    if (best.sse && (!best.xyz || !best.chol || !best.feat || !best.info || (s->bound_stride && !s->best_bound))) {
+        set_error("train step: best_sse given without the snapshot buffers");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
     const dim3 gg((n + 255) / 256), bb(256);
     if (s->kind == 0)
         hipLaunchKernelGGL(train_reduce_update_kernel<kCholesky>, gg, bb, 0, st, n, P, (const float2 *)s->xys,
                            s->radii, s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins,
                            w.partial_g, w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2],
-                           s->dbg_grads);
+                           s->dbg_grads, best);
     else
         hipLaunchKernelGGL(train_reduce_update_kernel<kCovariance>, gg, bb, 0, st, n, P, (const float2 *)s->xys,
                            s->radii, s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins,
                            w.partial_g, w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2],
-                           s->dbg_grads);
+                           s->dbg_grads, best);
     return check_launch("train step");
 }
 

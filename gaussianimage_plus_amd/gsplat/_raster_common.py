@@ -7,7 +7,7 @@ on a pooled workspace of the fused fast path (csrc/gi2d_fast.hip):
 and one backward is gi2d_fast_rasterize_backward_tiles + _reduce on the same workspace: no float atomics,
 bitwise reproducible.  Eight bytes of status are read back AFTER everything is enqueued (the GPU never
 waits for the host): "no intersection at all" gives the background image (rasterize_sum_plus.py:110-118),
-and a tile bucket overflow (more than 128 gaussians of one id-mod-4 class in a tile) re-runs the forward on
+and a tile bucket overflow (more than 256 gaussians of one id-mod-4 class in a tile) re-runs the forward on
 the capacity-free ops (gi2d_bin_gaussians + plain rasterizer), so results are always exact."""
 from __future__ import annotations
 

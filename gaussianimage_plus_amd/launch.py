@@ -61,19 +61,30 @@ def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, floa
 
 # ----------------------------------------------------------------------------------- per-image loop
 def fit_image_native(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float = 1e-3, seed: int = 3047,
-                     eval_renders: int = 10, kind: str = "cholesky") -> Dict[str, float]:
+                     eval_renders: int = 10, kind: str = "cholesky", max_points: int = 0, prune_iter: int = 100,
+                     grow_iter: int = 5000, eps: float = 1e-8) -> Dict[str, float]:
     """The same loop on the fused training iteration (trainer.NativeFitter -> gi2d_train_step): one C-ABI call,
-    four kernel launches and no host synchronisation per iteration."""
+    three kernel launches and no host synchronisation per iteration.  With `max_points` > `num_points` (covariance
+    model) it is the adaptive loop of train.py:120-160: prune every `prune_iter`, grow every `grow_iter`, keep the
+    best model on the device and evaluate that one."""
     from .trainer import NativeFitter
 
     dev = gt_hwc.device
-    fit = NativeFitter(gt_hwc, num_points, kind=kind, lr=lr, seed=seed)
+    adaptive = kind == "covariance" and max_points > num_points
+    fit = NativeFitter(gt_hwc, num_points, kind=kind, lr=lr, seed=seed, eps=eps,
+                       max_points=max_points if adaptive else None, track_best=adaptive)
     torch.cuda.synchronize(dev)
     t0 = time.time()
-    fit.train(iterations)
+    if adaptive:
+        fit.fit(iterations, prune_iter=prune_iter, grow_iter=grow_iter, max_points=max_points)
+        fit.check_status()
+        fit.load_best()
+    else:
+        fit.train(iterations)
     torch.cuda.synchronize(dev)
     train_s = time.time() - t0
-    fit.check_status()
+    if not adaptive:
+        fit.check_status()
     t0 = time.time()
     for _ in range(eval_renders):
         img = fit.render()
@@ -81,7 +92,7 @@ def fit_image_native(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr:
     eval_s = (time.time() - t0) / max(eval_renders, 1)
     mse = torch.nn.functional.mse_loss(img, fit.gt).item()
     return {"psnr": 10 * math.log10(1.0 / max(mse, 1e-12)), "train_s": train_s, "eval_s": eval_s,
-            "num_gaussians": num_points, "mse": mse}
+            "num_gaussians": fit.n, "mse": mse}
 
 
 def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float = 1e-3, seed: int = 3047,
@@ -166,6 +177,12 @@ def main(argv=None):
     ap.add_argument("--iterations", type=int, default=2000)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--seed", type=int, default=3047)
+    ap.add_argument("--model", choices=["cholesky", "covariance"], default="cholesky",
+                    help="covariance = train.py's default model (pixel coordinates, lr 0.018, Adam eps 1e-15)")
+    ap.add_argument("--max_num_points", type=int, default=0,
+                    help="> num_points: adaptive growth/pruning as in train.py (covariance model, native loop)")
+    ap.add_argument("--prune_iter", type=int, default=100)
+    ap.add_argument("--grow_iter", type=int, default=5000)
     ap.add_argument("--loop", choices=["native", "autograd"], default="native",
                     help="native: fused training iteration (gi2d_train_step); autograd: gsplat wrappers + torch Adam")
     args = ap.parse_args(argv)
@@ -184,10 +201,16 @@ def main(argv=None):
     images = load_images(args.dataset, args.synthetic, args.height, args.width)
 
     def fit_one(i, img):
-        fit = fit_image_native if args.loop == "native" else fit_image
-        r = fit(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed)
+        if args.loop == "native":
+            cov = args.model == "covariance"
+            r = fit_image_native(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed,
+                                 kind=args.model, max_points=args.max_num_points, prune_iter=args.prune_iter,
+                                 grow_iter=args.grow_iter, eps=1e-15 if cov else 1e-8)
+        else:
+            r = fit_image(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed)
         print(f"[rank {rank}] image {i}: {img.shape[0]}x{img.shape[1]}, PSNR:{r['psnr']:.4f}, "
-              f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}", flush=True)
+              f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}, "
+              f"gaussians:{int(r['num_gaussians'])}", flush=True)
         return r
 
     t0 = time.time()

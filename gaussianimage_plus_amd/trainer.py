@@ -1,15 +1,28 @@
-"""Native fitting loop: one GaussianImage++ training iteration = one C-ABI call (`gi2d_train_step`, four kernel
+"""Native fitting loop: one GaussianImage++ training iteration = one C-ABI call (`gi2d_train_step`, three kernel
 launches; csrc/gi2d_train.hip).  Mirrors `GaussianImage_Cholesky.train_iter` / `GaussianImage_Covariance.train_iter`
 with L2 loss and torch.optim.Adam + StepLR (models/gaussianimage_cholesky.py:123-130,302-317;
 models/gaussianimage_covariance.py:234-259), without the ~25 small PyTorch kernels and the two host syncs per
-iteration of the reference loop.  Parameters live in ordinary torch tensors (`xyz`, `chol`, `feat`), so checkpoints,
-densification or any other host logic can read and modify them between calls.
+iteration of the reference loop.
+
+On top of the iteration, the per-image driver of train.py:120-160 -- SURVEY section 8f ranks 2 and 3:
+  * best-model snapshot on the device (train.py:133-139 deep-copies the state dict on the host every time the PSNR
+    improves, which needs `.item()` every iteration): the update kernel compares the step's squared error with the
+    best so far and copies the parameters itself; the host reads two ints at the end (`load_best`);
+  * non-positive-definite pruning every `prune_iter` iterations (models/gaussianimage_covariance.py:352-382): one
+    4-byte read-back per check, in-place compaction of parameters + Adam moments + bounds only when something is
+    pruned;
+  * error-driven growth every `grow_iter` iterations (train.py:85-118, densification_postfix :317-350): top-k of
+    the per-pixel absolute error of the last render, new gaussians appended in place inside buffers allocated once
+    at `max_points` (no reallocation, no optimizer-state surgery on the host: Adam moments of the new rows are
+    zeroed, everything else stays where it is).
+Parameters live in ordinary torch tensors (`xyz`, `chol`, `feat` are views of the first `n` rows), so checkpoints or
+any other host logic can read and modify them between calls.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 
@@ -35,57 +48,108 @@ class _TrainState(C.Structure):
         ("status", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dbg_grads", C.c_void_p),
+        ("best_xyz", C.c_void_p), ("best_chol", C.c_void_p), ("best_feat", C.c_void_p), ("best_bound", C.c_void_p),
+        ("best_sse", C.c_void_p), ("best_info", C.c_void_p),
     ]
+
+
+# ------------------------------------------------------------------ host-side pieces of densify / prune (any device)
+def positive_definite_mask(cov2d: torch.Tensor) -> torch.Tensor:
+    """models/gaussianimage_covariance.py:372-379: det > 0 and both diagonal entries > 0 (singular ones excluded)."""
+    return (cov2d[:, 0] * cov2d[:, 2] - cov2d[:, 1] ** 2 > 0) & (cov2d[:, 0] > 0) & (cov2d[:, 2] > 0)
+
+
+def growth_budget(iteration: int, iterations: int, grow_iter: int, cur_points: int, max_points: int,
+                  base_num_samples: int = 1000) -> int:
+    """train.py:91-99: 1000 new samples per growth step, everything that is left at the last one."""
+    if iteration == iterations - grow_iter:
+        return max(0, max_points - cur_points)
+    return max(0, min(base_num_samples, max_points - cur_points))
+
+
+def select_new_points(render_hwc: torch.Tensor, gt_hwc: torch.Tensor, count: int, rand3: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """train.py:85-118 on [H,W,3] images: the `count` pixels with the largest summed absolute error become the centres
+    of new gaussians (pixel coordinates), colour 0, covariance rand + (0.5, 0, 0.5); non-PD draws are dropped
+    (densification_postfix, models/gaussianimage_covariance.py:317-320).  `rand3`: [count,3] uniform numbers."""
+    w = render_hwc.shape[1]
+    errors = torch.abs(render_hwc - gt_hwc).sum(dim=2)
+    p_flat = (errors / torch.sum(errors)).reshape(-1)
+    _, idx = torch.topk(p_flat, count)
+    xyz = torch.stack([idx % w, idx // w], dim=1).float()
+    cov = rand3.to(render_hwc.device, torch.float32) + torch.tensor([0.5, 0.0, 0.5], device=render_hwc.device)
+    keep = positive_definite_mask(cov)
+    return {"xyz": xyz[keep], "cov2d": cov[keep], "feat": torch.zeros(int(keep.sum()), 3, device=render_hwc.device),
+            "dropped": int(count - int(keep.sum()))}
 
 
 class NativeFitter:
     def __init__(self, gt_hwc: torch.Tensor, num_points: int, kind: str = "cholesky", lr: float = 1e-3,
                  betas=(0.9, 0.999), eps: float = 1e-8, lr_step: int = 20000, lr_gamma: float = 0.5,
                  seed: int = 3047, clip_coe: float = 3.0, radius_clip: float = 1.0,
-                 init: Optional[dict] = None, debug_grads: bool = False):
+                 init: Optional[dict] = None, debug_grads: bool = False, max_points: Optional[int] = None,
+                 track_best: bool = False):
         assert kind in _KINDS and gt_hwc.is_cuda and gt_hwc.dim() == 3 and gt_hwc.size(2) == 3
         self.lib = _lib.load()
         self.kind, self.dev = kind, gt_hwc.device
         self.h, self.w, self.n = int(gt_hwc.shape[0]), int(gt_hwc.shape[1]), int(num_points)
+        self.cap = max(int(max_points or 0), self.n)
         self.tx, self.ty = (self.w + 15) // 16, (self.h + 15) // 16
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.lr_step, self.lr_gamma = int(lr_step), float(lr_gamma)
         self.iteration = 0
-        n, h, w, dev = self.n, self.h, self.w, self.dev
+        self.rng = torch.Generator(device="cpu").manual_seed(seed)
+        n, cap, h, w, dev = self.n, self.cap, self.h, self.w, self.dev
         self.gt = gt_hwc.contiguous().float()
         if init is None:  # models/gaussianimage_cholesky.py:57-58,99 / gaussianimage_covariance.py:52-57
-            g = torch.Generator(device="cpu").manual_seed(seed)
             if kind == "cholesky":
-                xyz = torch.atanh(2 * (torch.rand(n, 2, generator=g) - 0.5))
+                xyz = torch.atanh(2 * (torch.rand(n, 2, generator=self.rng) - 0.5))
             else:
-                xyz = torch.rand(n, 2, generator=g) * torch.tensor([float(w), float(h)])
-            init = {"xyz": xyz, "chol": torch.rand(n, 3, generator=g), "feat": torch.zeros(n, 3)}
-        self.xyz = init["xyz"].detach().to(dev, torch.float32).contiguous().clone()
-        self.chol = init["chol"].detach().to(dev, torch.float32).contiguous().clone()
-        self.feat = init["feat"].detach().to(dev, torch.float32).contiguous().clone()
-        self.opacity = init.get("opacity", torch.ones(n, 1)).detach().to(dev, torch.float32).contiguous().clone()
-        low_pass = min(h * w / (9 * math.pi * n), 300)  # SLV bound, models/gaussianimage_cholesky.py:80-82
-        self.bound = init.get("bound", torch.tensor([low_pass, 0.0, low_pass])).detach().to(dev, torch.float32).contiguous()
+                xyz = torch.rand(n, 2, generator=self.rng) * torch.tensor([float(w), float(h)])
+            init = {"xyz": xyz, "chol": torch.rand(n, 3, generator=self.rng), "feat": torch.zeros(n, 3)}
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)
-        self.m_xyz, self.v_xyz = f32(n, 2), f32(n, 2)
-        self.m_chol, self.v_chol = f32(n, 3), f32(n, 3)
-        self.m_feat, self.v_feat = f32(n, 3), f32(n, 3)
-        self.xys, self.conics, self.radii, self.nth = f32(n, 2), f32(n, 3), i32(n), i32(n)
+        self._xyz, self._chol, self._feat = f32(cap, 2), f32(cap, 3), f32(cap, 3)
+        self._xyz[:n] = init["xyz"].detach().to(dev, torch.float32)
+        self._chol[:n] = init["chol"].detach().to(dev, torch.float32)
+        self._feat[:n] = init["feat"].detach().to(dev, torch.float32)
+        self._opacity = torch.ones(cap, 1, dtype=torch.float32, device=dev)
+        if "opacity" in init:
+            self._opacity[:n] = init["opacity"].detach().to(dev, torch.float32)
+        low_pass = min(h * w / (9 * math.pi * n), 300)  # SLV bound, models/gaussianimage_cholesky.py:80-82
+        bound = init.get("bound", torch.tensor([low_pass, 0.0, low_pass])).detach().to(dev, torch.float32)
+        self.per_point_bound = bound.numel() == 3 * n and n > 1 or cap > n
+        if self.per_point_bound:  # growth gives new rows their own bound (densification_postfix :343-348)
+            self._bound = f32(cap, 3)
+            self._bound[:n] = bound.reshape(-1, 3)
+        else:
+            self._bound = bound.reshape(3).contiguous()
+        self._m_xyz, self._v_xyz = f32(cap, 2), f32(cap, 2)
+        self._m_chol, self._v_chol = f32(cap, 3), f32(cap, 3)
+        self._m_feat, self._v_feat = f32(cap, 3), f32(cap, 3)
+        self.xys, self.conics, self.radii, self.nth = f32(cap, 2), f32(cap, 3), i32(cap), i32(cap)
         self.out_img, self.tile_sse, self.status = f32(h, w, 3), f32(self.tx * self.ty), i32(4)
-        self.dbg_grads = f32(n, 8) if debug_grads else None
-        nbytes = self.lib.gi2d_fast_workspace_bytes(n, self.tx, self.ty)
+        self.dbg_grads = f32(cap, 8) if debug_grads else None
+        self.track_best = bool(track_best)
+        if track_best:
+            self.best_xyz, self.best_chol, self.best_feat, self.best_bound = f32(cap, 2), f32(cap, 3), f32(cap, 3), f32(cap, 3)
+            self.best_sse = torch.full((2,), float("inf"), dtype=torch.float32, device=dev)
+            self.best_info = i32(2)
+        nbytes = self.lib.gi2d_fast_workspace_bytes(cap, self.tx, self.ty)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), nbytes, n, self.tx, self.ty,
+            _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), nbytes, cap, self.tx, self.ty,
                       torch.cuda.current_stream(dev).cuda_stream)
         p = lambda t: t.data_ptr()
+        bp = (lambda t: p(t)) if track_best else (lambda t: None)
         self.state = _TrainState(
-            _KINDS[kind], n, h, w, float(clip_coe), float(radius_clip), p(self.xyz), p(self.chol), p(self.feat),
-            p(self.opacity), p(self.bound), 3 if self.bound.numel() == 3 * n and n > 1 else 0, 0,
-            p(self.m_xyz), p(self.v_xyz), p(self.m_chol), p(self.v_chol), p(self.m_feat), p(self.v_feat), p(self.gt),
-            p(self.xys), p(self.conics), p(self.radii), p(self.nth), p(self.out_img), p(self.tile_sse), p(self.status),
-            p(self.ws), nbytes, p(self.dbg_grads) if debug_grads else None)
+            _KINDS[kind], n, h, w, float(clip_coe), float(radius_clip), p(self._xyz), p(self._chol), p(self._feat),
+            p(self._opacity), p(self._bound), 3 if self.per_point_bound else 0, 0,
+            p(self._m_xyz), p(self._v_xyz), p(self._m_chol), p(self._v_chol), p(self._m_feat), p(self._v_feat),
+            p(self.gt), p(self.xys), p(self.conics), p(self.radii), p(self.nth), p(self.out_img), p(self.tile_sse),
+            p(self.status), p(self.ws), nbytes, p(self.dbg_grads) if debug_grads else None,
+            bp(getattr(self, "best_xyz", None)), bp(getattr(self, "best_chol", None)),
+            bp(getattr(self, "best_feat", None)), bp(getattr(self, "best_bound", None)),
+            bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)))
         self._state_ref = C.byref(self.state)
         self._lr3 = (C.c_float * 3)()
         self._step_fn = self.lib.gi2d_train_step
@@ -94,6 +158,23 @@ class NativeFitter:
         self._render_fn = self.lib.gi2d_train_render
         self._render_fn.argtypes = [C.c_void_p, C.c_void_p]
         self._render_fn.restype = C.c_int
+
+    # ------------------------------------------------------------------ views of the live rows
+    xyz = property(lambda self: self._xyz[:self.n])
+    chol = property(lambda self: self._chol[:self.n])
+    feat = property(lambda self: self._feat[:self.n])
+    opacity = property(lambda self: self._opacity[:self.n])
+    bound = property(lambda self: self._bound[:self.n] if self.per_point_bound else self._bound)
+    m_xyz = property(lambda self: self._m_xyz[:self.n])
+    v_xyz = property(lambda self: self._v_xyz[:self.n])
+    m_chol = property(lambda self: self._m_chol[:self.n])
+    v_chol = property(lambda self: self._v_chol[:self.n])
+    m_feat = property(lambda self: self._m_feat[:self.n])
+    v_feat = property(lambda self: self._v_feat[:self.n])
+
+    def _set_n(self, n: int):
+        self.n = int(n)
+        self.state.num_points = self.n
 
     # ------------------------------------------------------------------
     def _check(self, rc, what):
@@ -135,5 +216,99 @@ class NativeFitter:
         return 10 * math.log10(1.0 / max(mse, 1e-12))
 
     def check_status(self):
-        if int(self.status[1].item()):
-            raise RuntimeError("a tile bucket overflowed (> 128 gaussians per (tile, id mod 4)); results invalid")
+        """Raises if any step since the last check overflowed a tile bucket (sticky flag status[2])."""
+        now, sticky = self.status[1:3].tolist()
+        self.status[2] = 0
+        if now or sticky:
+            raise RuntimeError("a tile bucket overflowed (> 256 gaussians per (tile, id mod 4)); results invalid")
+
+    # ------------------------------------------------------------------ best-model snapshot (train.py:133-139,157-160)
+    def best(self):
+        """(psnr, step, num_points) of the on-device snapshot; (None, 0, 0) if no step has run."""
+        assert self.track_best
+        n_best, step = self.best_info.tolist()
+        if step == 0:
+            return None, 0, 0
+        sse = float(self.best_sse[(self.iteration + 1) & 1].item())
+        return 10 * math.log10(1.0 / max(sse / (3.0 * self.h * self.w), 1e-12)), step, n_best
+
+    def load_best(self):
+        """Make the snapshot the live model (what train.py does after its loop)."""
+        psnr, step, n_best = self.best()
+        if step == 0:
+            return None
+        self._xyz[:n_best] = self.best_xyz[:n_best]
+        self._chol[:n_best] = self.best_chol[:n_best]
+        self._feat[:n_best] = self.best_feat[:n_best]
+        if self.per_point_bound:
+            self._bound[:n_best] = self.best_bound[:n_best]
+        self._set_n(n_best)
+        return psnr
+
+    # ------------------------------------------------------------------ prune / grow (covariance model)
+    def _rows(self):
+        rows = [self._xyz, self._chol, self._feat, self._opacity, self._m_xyz, self._v_xyz, self._m_chol, self._v_chol,
+                self._m_feat, self._v_feat]
+        if self.per_point_bound:
+            rows.append(self._bound)
+        return rows
+
+    def prune_non_definite(self) -> int:
+        """non_semi_definite_prune (models/gaussianimage_covariance.py:352-370): drop gaussians whose covariance
+        (+ bound) is not positive definite, keeping the order of the others.  Returns the number pruned."""
+        if self.kind != "covariance":
+            return 0  # L L^T is positive semi-definite by construction; the reference never prunes that model
+        n = self.n
+        cov = self._chol[:n] + (self._bound[:n] if self.per_point_bound else self._bound)
+        valid = positive_definite_mask(cov)
+        to_prune = n - int(valid.sum().item())  # the one read-back of a prune check
+        if to_prune and n - to_prune > 0:
+            keep = n - to_prune
+            for t in self._rows():
+                t[:keep] = t[:n][valid]
+            self._set_n(keep)
+        return to_prune
+
+    def add_sample_positions(self, iteration: int, iterations: int, grow_iter: int, max_points: Optional[int] = None) -> int:
+        """train.py:85-118 with densification_postfix: append gaussians where the last render is worst.  Returns the
+        number of gaussians added."""
+        assert self.kind == "covariance", "growth places gaussians in pixel coordinates (covariance model)"
+        max_points = self.cap if max_points is None else min(int(max_points), self.cap)
+        count = growth_budget(iteration, iterations, grow_iter, self.n, max_points)
+        if not count:
+            return 0
+        rand3 = torch.rand(count, 3, generator=self.rng)
+        new = select_new_points(self.out_img.clamp(0, 1), self.gt, count, rand3)
+        k = int(new["xyz"].shape[0])
+        n0, n1 = self.n, self.n + k
+        self._xyz[n0:n1], self._chol[n0:n1], self._feat[n0:n1] = new["xyz"], new["cov2d"], new["feat"]
+        self._opacity[n0:n1] = 1.0
+        for t in (self._m_xyz, self._v_xyz, self._m_chol, self._v_chol, self._m_feat, self._v_feat):
+            t[n0:n1] = 0.0
+        if self.per_point_bound:  # SLV: the new rows get the low-pass bound of the new population size
+            low_pass = min(self.h * self.w / (9 * math.pi * n1), 300)
+            self._bound[n0:n1] = torch.tensor([low_pass, 0.0, low_pass], device=self.dev)
+        self._set_n(n1)
+        return k
+
+    def fit(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
+            max_points: Optional[int] = None, log=None) -> None:
+        """The per-image loop of train.py:120-160: train, prune every `prune_iter`, grow every `grow_iter` (not at
+        the very end).  Iterations between two such events are issued back to back without touching the host."""
+        start = self.iteration
+        end = start + int(iterations)
+        while self.iteration < end:
+            local = self.iteration - start
+            nxt = min((local // prune_iter + 1) * prune_iter, end - start)
+            if adaptive_add:
+                nxt = min(nxt, (local // grow_iter + 1) * grow_iter)
+            self.train(nxt - local)
+            local = self.iteration - start
+            if local % prune_iter == 0:
+                pruned = self.prune_non_definite()
+                if pruned and log:
+                    log(f"iter {local}: pruned {pruned} non-definite, {self.n} left")
+            if adaptive_add and local % grow_iter == 0 and local < iterations:
+                added = self.add_sample_positions(local, iterations, grow_iter, max_points)
+                if log:
+                    log(f"iter {local}: added {added} gaussians, now {self.n}")

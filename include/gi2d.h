@@ -239,15 +239,16 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
  *     gi2d_fast_workspace_init (zeroes the bucket cursors; every forward leaves them zero again).
  *     The forward fills it (tile-sorted ids, tile_bins, packed 48-byte gaussian records), the
  *     backward reads it: one workspace per in-flight forward/backward pair.
- *   - capacity: at most gi2d_fast_tile_capacity() (=128) gaussians per (tile, id mod 4) bucket.
+ *   - capacity: at most gi2d_fast_tile_capacity() (=256) gaussians per (tile, id mod 4) bucket.
  *     status i32[4] = {1 if any tile is non-empty else 0, 1 if a bucket overflowed (results
- *     invalid: use gi2d_bin_gaussians + the plain ops instead), 0, 0}; reset by the bin call,
- *     raised by the forward.  The intersection count itself is sum(num_tiles_hit).
+ *     invalid: use gi2d_bin_gaussians + the plain ops instead), sticky copy of the overflow flag
+ *     (never reset by the library: for loops that check once per many steps), 0}; [0], [1] are
+ *     reset by the bin call and raised by the forward.  The intersection count itself is sum(num_tiles_hit).
  *   - kind: 0 Cholesky (project_gaussians_2d), 1 covariance, 2 scale-rot (p0 = scales, p1 = rot).
  *   - gi2d_fast_rasterize_forward: final_Ts may be NULL (it is the constant 1); `background`
  *     non-NULL adds the "no intersection at all -> image = background" rule of
  *     rasterize_sum_plus.py:110-118 (one extra tiny launch); NULL leaves such an image at 0.
- *   - final_idx (positions in the workspace's strided list, tile*512 + rank) is optional in both
+ *   - final_idx (positions in the workspace's strided list, tile*1024 + rank) is optional in both
  *     directions: the fused backward does not need it (its forward evaluated every pair with the
  *     same instructions, so "idx <= final_idx" is implied by the alpha test); pass NULL to skip it.
  */
@@ -349,6 +350,12 @@ typedef struct gi2d_train_state {
     void *workspace;
     size_t workspace_bytes;
     float *dbg_grads;
+    /* optional best-model snapshot kept on the device (all NULL = off): when the squared error of a step's
+     * render is below best_sse, the parameters after that step's update are copied to best_* and best_info =
+     * {num_points, step} (train.py:133-139 without the host round trip).  best_sse f32[2], initialised to
+     * +inf by the caller, ping-pongs between steps: the current best is best_sse[(last step + 1) & 1]. */
+    float *best_xyz, *best_chol, *best_feat, *best_bound, *best_sse;
+    int32_t *best_info;
 } gi2d_train_state;
 int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
 int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,

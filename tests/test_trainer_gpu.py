@@ -99,3 +99,88 @@ def test_launcher_fit_functions_agree():
     b = fit_image_native(gt, 1500, 150, lr=1e-2, seed=5, eval_renders=2)
     assert abs(a["psnr"] - b["psnr"]) < 0.3, (a["psnr"], b["psnr"])
     assert b["psnr"] > 20
+
+
+def _cov_fitter(n, h, w, seed=2, **kw):
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    gt = synthetic_image(h, w, 7).to(DEV)
+    return NativeFitter(gt, n, kind="covariance", lr=0.018, eps=1e-15, seed=seed, **kw), gt
+
+
+def test_best_snapshot_on_device_equals_host_replay():
+    """train.py:133-139: whenever a step's render beats the best PSNR so far, the state dict AFTER that step is the
+    new best.  The device keeps that snapshot itself; replay the same run step by step on a second fitter and
+    take the snapshots on the host."""
+    n, h, w, steps = 800, 64, 96, 40
+    fit, _ = _cov_fitter(n, h, w, track_best=True)
+    ref, _ = _cov_fitter(n, h, w)
+    fit.train(steps)
+    best_sse, snap, snap_step = float("inf"), None, 0
+    for it in range(1, steps + 1):
+        ref.train(1)
+        sse = float(ref.tile_sse.sum().item())  # not the device's summation order: compare with a margin below
+        if sse < best_sse:
+            best_sse, snap, snap_step = sse, (ref.xyz.clone(), ref.chol.clone(), ref.feat.clone()), it
+    psnr, step, n_best = fit.best()
+    assert n_best == n and step == snap_step
+    assert torch.equal(fit.best_xyz[:n], snap[0]) and torch.equal(fit.best_chol[:n], snap[1])
+    assert torch.equal(fit.best_feat[:n], snap[2])
+    assert abs(psnr - 10 * math.log10(3.0 * h * w / best_sse)) < 1e-3
+    # lr 0.018 overshoots now and then: the best step is not simply the last one in a longer run, and load_best
+    # restores exactly the snapshot
+    got = fit.load_best()
+    assert abs(got - psnr) < 1e-9 and torch.equal(fit.xyz, snap[0])
+
+
+def test_prune_non_definite_compacts_parameters_and_moments():
+    h, w = 48, 64
+    fit, _ = _cov_fitter(600, h, w, max_points=900)
+    fit.train(3)
+    torch.cuda.synchronize()
+    first = fit.prune_non_definite()  # rand(3) + bound is not always definite: the initial draw loses some rows
+    n = fit.n
+    assert 0 < first < 300 and n == 600 - first
+    bad = torch.tensor([5, 17, 18, n // 2, n - 1], device=DEV)
+    fit._chol[bad] = torch.tensor([0.2, 5.0, 0.2], device=DEV) - fit._bound[bad]  # cov + bound = (0.2, 5, 0.2): indefinite
+    before = [t[:n].clone() for t in fit._rows()]
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[bad] = False
+    assert fit.prune_non_definite() == 5 and fit.n == n - 5
+    for t, b in zip(fit._rows(), before):
+        assert torch.equal(t[:fit.n], b[keep])
+    fit.train(2)  # the shorter model keeps training
+    fit.check_status()
+    assert fit.prune_non_definite() == 0 and fit.n == n - 5
+
+
+def test_adaptive_fit_grows_to_the_cap_and_improves():
+    from gaussianimage_plus_amd.trainer import select_new_points
+    n0, cap, h, w = 400, 2600, 96, 144
+    fit, gt = _cov_fitter(n0, h, w, max_points=cap, track_best=True)
+    fit.train(20)
+    # one growth step by hand: the same selection on a CPU copy of the render
+    torch.cuda.synchronize()
+    render = fit.out_img.clamp(0, 1).cpu()
+    state = fit.rng.get_state()
+    added = fit.add_sample_positions(20, 80, 20)
+    fit.rng.set_state(state)
+    want = select_new_points(render, gt.cpu(), 1000, torch.rand(1000, 3, generator=fit.rng))
+    assert added == want["xyz"].shape[0] and fit.n == n0 + added
+    assert torch.equal(fit.xyz[n0:].cpu(), want["xyz"]) and torch.equal(fit.chol[n0:].cpu(), want["cov2d"])
+    assert float(fit.m_chol[n0:].abs().sum()) == 0.0 and float(fit.feat[n0:].abs().sum()) == 0.0
+    low = min(h * w / (9 * math.pi * fit.n), 300)
+    assert torch.allclose(fit.bound[n0:], torch.tensor([low, 0.0, low], device=DEV))
+    assert torch.allclose(fit.bound[:n0], torch.tensor([min(h * w / (9 * math.pi * n0), 300), 0.0,
+                                                        min(h * w / (9 * math.pi * n0), 300)], device=DEV))
+    p_before = fit.psnr()
+    # the scheduled loop: 80 iterations, growth every 20 (the last one, at 60, releases the whole budget)
+    msgs = []
+    fit.fit(80, prune_iter=10, grow_iter=20, log=msgs.append)
+    fit.check_status()
+    assert fit.n <= cap and fit.n > cap - 200, msgs  # all but the non-definite draws
+    assert any("added" in m for m in msgs)
+    assert fit.psnr() > p_before + 1.0
+    psnr, step, n_best = fit.best()
+    assert n0 < n_best <= cap  # the snapshot carries its own population (it may predate a later prune)
+    assert fit.load_best() == psnr and abs(fit.psnr() - psnr) < 0.3
