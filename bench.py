@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--width", type=int, default=768)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--images-per-gpu-probe", action="store_true",
+                   help="also report the aggregate step rate of 2, 3 and 4 independent images stepped concurrently on "
+                        "separate HIP streams of this GPU (extra information, not `value`)")
     p.add_argument("--train-step", action="store_true",
                    help="also time the whole training iteration (gi2d_train_step) after the timed region")
     return p.parse_args()
@@ -54,10 +57,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL over xGMI on a real node; GI2D_BENCH_BACKEND=gloo only to rehearse N ranks on a box with fewer GPUs
+        dist.init_process_group(os.environ.get("GI2D_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU, no number"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # one GPU per rank; ranks share only in a 1-GPU rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from helpers import synth_cholesky, synth_gt
     from gaussianimage_plus_amd.hotpath import HotPath
@@ -94,8 +99,9 @@ def main():
     elapsed = time.perf_counter() - t0
     hp.check_status()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ms = torch.tensor([float(m)], dtype=torch.float64, device=dev)
+    red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    ms = torch.tensor([float(m)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ms, op=dist.ReduceOp.SUM)
@@ -136,6 +142,8 @@ def main():
         }
         if args.train_step:
             line["train_step"] = train_step_rate(gt, n, dev)
+        if args.images_per_gpu_probe:
+            line["concurrent_images"] = concurrent_images_rate(n, h, w, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(xyz, L, col, op, h, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)
@@ -159,6 +167,39 @@ def pmc_traffic(kernel, n, h, w):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def concurrent_images_rate(n, h, w, dev, rounds=300):
+    """Extra information, not `value`: K independent images (own buffers, own HIP stream) stepped round-robin from
+    this process.  One image leaves most CUs idle between its dependent phases, so the aggregate rate rises with K
+    until the host's launch rate (3 C-ABI calls per step) becomes the limit."""
+    from helpers import synth_cholesky, synth_gt
+    from gaussianimage_plus_amd.hotpath import HotPath
+    out = []
+    for k in (2, 3, 4):
+        hps, streams = [], []
+        for i in range(k):
+            hp = HotPath(n, h, w, device=dev)
+            hp.set_inputs(*synth_cholesky(n, h, w, 4000 + i))
+            hp.set_target(torch.from_numpy(synth_gt(h, w, 10 + i)).to(dev))
+            hps.append(hp)
+            streams.append(torch.cuda.Stream(device=dev))
+
+        def run(r):
+            for _ in range(r):
+                for hp, st in zip(hps, streams):
+                    with torch.cuda.stream(st):
+                        hp.step()
+        run(20)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(rounds)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        for hp in hps:
+            hp.check_status()
+        out.append({"images": k, "steps_per_s": k * rounds / dt, "us_per_round": dt / rounds * 1e6})
+    return out
 
 
 def train_step_rate(gt, n, dev, iters=400):

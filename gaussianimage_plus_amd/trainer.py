@@ -291,24 +291,37 @@ class NativeFitter:
         self._set_n(n1)
         return k
 
-    def fit(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
-            max_points: Optional[int] = None, log=None) -> None:
-        """The per-image loop of train.py:120-160: train, prune every `prune_iter`, grow every `grow_iter` (not at
-        the very end).  Iterations between two such events are issued back to back without touching the host."""
+    def fit_schedule(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
+                     max_points: Optional[int] = None, log=None, chunk: Optional[int] = None):
+        """The per-image loop of train.py:120-160 as a generator: train, prune every `prune_iter`, grow every
+        `grow_iter` (not at the very end).  Iterations between two such events are issued back to back without
+        touching the host; with `chunk` the generator yields after at most that many iterations, so a caller can
+        interleave several fitters on several HIP streams (launch.py)."""
         start = self.iteration
         end = start + int(iterations)
+        adaptive = self.kind == "covariance"
         while self.iteration < end:
             local = self.iteration - start
-            nxt = min((local // prune_iter + 1) * prune_iter, end - start)
-            if adaptive_add:
-                nxt = min(nxt, (local // grow_iter + 1) * grow_iter)
+            nxt = end - start
+            if adaptive:
+                nxt = min(nxt, (local // prune_iter + 1) * prune_iter)
+                if adaptive_add:
+                    nxt = min(nxt, (local // grow_iter + 1) * grow_iter)
+            if chunk:
+                nxt = min(nxt, local + int(chunk))
             self.train(nxt - local)
             local = self.iteration - start
-            if local % prune_iter == 0:
+            if adaptive and local % prune_iter == 0:
                 pruned = self.prune_non_definite()
                 if pruned and log:
                     log(f"iter {local}: pruned {pruned} non-definite, {self.n} left")
-            if adaptive_add and local % grow_iter == 0 and local < iterations:
+            if adaptive and adaptive_add and local % grow_iter == 0 and local < iterations:
                 added = self.add_sample_positions(local, iterations, grow_iter, max_points)
                 if log:
                     log(f"iter {local}: added {added} gaussians, now {self.n}")
+            yield local
+
+    def fit(self, iterations: int, **kw) -> None:
+        """Run fit_schedule to the end (same keyword arguments)."""
+        for _ in self.fit_schedule(iterations, **kw):
+            pass

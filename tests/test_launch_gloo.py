@@ -66,3 +66,20 @@ def test_two_ranks_shard_images_and_agree_on_the_average():
 def test_single_process_needs_no_process_group():
     out = reduce_metrics({"psnr": 60.0, "train_s": 4.0, "eval_s": 0.2, "num_gaussians": 10, "count": 2})
     assert out["images"] == 2 and out["avg_psnr"] == 30.0 and out["avg_train_s"] == 2.0
+
+
+def test_grouped_images_share_their_wall_time():
+    """--images_per_gpu: a rank fits its shard `group` images at a time; the group's wall time counts once."""
+    items = list(range(5))
+    calls = []
+
+    def fit_group(idx, its):
+        calls.append(list(idx))
+        return [{"psnr": 30.0 + i, "train_s": 2.0, "eval_s": 0.001, "num_gaussians": 10} for i in idx]
+
+    out = run_sharded(items, lambda i, it: (_ for _ in ()).throw(AssertionError("ungrouped")), 0, 1, group=2,
+                      fit_group=fit_group)
+    assert calls == [[0, 1], [2, 3], [4]]
+    assert out["images"] == 5 and abs(out["sum_train_s"] - 6.0) < 1e-12  # three groups of 2.0 s
+    assert abs(out["avg_psnr"] - 32.0) < 1e-12
+    assert [i for i, _ in out["rows"]] == [0, 1, 2, 3, 4]

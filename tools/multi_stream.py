@@ -15,7 +15,7 @@ for K in (1, 2, 3, 4, 6):
         hp.set_inputs(*synth_cholesky(n, h, w, 3047 + i))
         out = hp.forward()
         gt = torch.from_numpy(synth_gt(h, w, 1 + i)).to(dev)
-        hp.set_v_out((2 * (out.clamp(0, 1) - gt) / (3 * h * w)).contiguous())
+        hp.set_target(gt)
         hps.append(hp)
         streams.append(torch.cuda.Stream(device=dev))
     torch.cuda.synchronize()

@@ -13,5 +13,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o run -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/write.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/sq1 -o run -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/sq1.log
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/sq2 -o run -- python3 $REPO/bench.py $PMC_ARGS > /dev/null 2> $OUT/sq2.log
-cd $REPO && python3 bench.py --train-step > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+cd $REPO && python3 bench.py --train-step --images-per-gpu-probe > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 tail -n 1 $OUT/bench_plain.json | cut -c1-600
