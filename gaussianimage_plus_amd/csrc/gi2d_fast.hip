@@ -102,9 +102,6 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
-#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 0
-    if (tiles_x > 0) return;  // timing experiment: launch floor
-#endif
     if (tid < GI2D_FAST_SUB) {
         const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
         cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
@@ -118,9 +115,6 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     __syncthreads();
     const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
-#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 1
-    if (tiles_x > 0) return;  // + cursors
-#endif
     // my (up to GI2D_FAST_EPT) bucket entries
     int my_id[GI2D_FAST_EPT];
 #pragma unroll
@@ -135,9 +129,6 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         }
     }
     __syncthreads();
-#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 2
-    if (tiles_x > 0) { if (sm.ids[tid & 1] == 0x7ffffffe) status[3] = 1; return; }  // + bucket ids
-#endif
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
@@ -167,9 +158,6 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         }
     }
     __syncthreads();
-#if defined(GI2D_ABLATE_FWD_LEVEL) && GI2D_ABLATE_FWD_LEVEL == 3
-    if (tiles_x > 0) { if (sm.f.C[tid] == 12345.f) status[3] = 1; return; }  // + gather / rank / staging
-#endif
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     // "No intersection at all" (image = background) is a global property no single tile can decide: every
     // non-empty tile raises status[0] with a plain store as its LAST memory operation (no barrier waits on
@@ -209,20 +197,11 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
-#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 0
-    if (tiles_x > 0) return;  // timing experiment: launch floor
-#endif
     const int2 range = tile_bins[tile];
     const int full_len = range.y - range.x;
     if (full_len <= 0) return;
     const int len = full_len > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : full_len;
-#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 1
-    if (len > 0) return;  // + tile_bins load
-#endif
     bwd_stage_pixels(sm, tx, ty, img_w, img_h, final_idx, v_output);
-#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 2
-    if (len > 0) return;  // + pixel staging
-#endif
     unsigned mask = 0;
     int slot = 0;
     if (tid < len) {
@@ -234,13 +213,6 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
         slot = __float_as_int(q2.y);
         mask = (unsigned)__float_as_int(q2.w);
     }
-#if defined(GI2D_ABLATE_BWD_LEVEL) && GI2D_ABLATE_BWD_LEVEL == 3
-    if (len > 0) {  // + gaussian staging
-        __syncthreads();
-        if (sm.gCb[tid & 63] == 12345.f && mask == 77u) partial_big[0] = sm.pixA[tid & 127];
-        return;
-    }
-#endif
     float4 *dst = nullptr;
     if (tid < len)
         dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);

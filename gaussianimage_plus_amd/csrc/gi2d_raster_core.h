@@ -129,9 +129,6 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
         float *mysoa = soa + wv * GI2D_FWD_PAIRBUF;
         v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
         const v2f px2 = {px, px}, py2 = {py, py};
-#ifdef GI2D_ABLATE_FWD_COMPUTE
-        if (len < 0)  // timing experiment: skip the pixel loop
-#endif
         for (int c0 = 0; c0 < cnt; c0 += 64) {
             {
                 const int e = c0 + lane;
@@ -178,9 +175,6 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
     } else {
         // scalar form: four list entries per trip (indices are wave-uniform -> scalar)
         float e0 = 0.f, e1 = 0.f, e2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
-#ifdef GI2D_ABLATE_FWD_COMPUTE
-        if (len < 0)  // timing experiment: skip the pixel loop
-#endif
         for (int t = 0; t < cnt; t += 4) {
             const uint2 packed = *reinterpret_cast<const uint2 *>(mylist + t);
             const unsigned p0 = __builtin_amdgcn_readfirstlane(packed.x);
@@ -413,11 +407,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             const int idx = list_base + k;
             float vx = 0.f, vy = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, gop = 0.f;
             v2f gr = {0.f, 0.f}, gg = {0.f, 0.f}, gb = {0.f, 0.f}, ax = {0.f, 0.f}, ay = {0.f, 0.f};
-#ifdef GI2D_ABLATE_BWD_COMPUTE
-            const int row_end = (n_items < 0) ? row_hi : row_lo - 1;  // timing experiment: skip the pixel loop
-#else
             const int row_end = row_hi;
-#endif
 #pragma unroll 1
             for (int row = row_lo; row <= row_end; ++row) {
                 const float dy = gy - (ty0 + (float)row);

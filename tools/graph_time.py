@@ -13,7 +13,7 @@ for n in [int(a) for a in (sys.argv[1:] or ["10000", "50000"])]:
     hp.set_inputs(*synth_cholesky(n, h, w, 3047))
     out = hp.forward()
     gt = torch.from_numpy(synth_gt(h, w, 1)).to(dev)
-    hp.set_v_out((2 * (out.clamp(0, 1) - gt) / (3 * h * w)).contiguous())
+    hp.set_target(gt)
     for _ in range(20):
         hp.step()
     torch.cuda.synchronize()
