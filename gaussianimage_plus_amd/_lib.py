@@ -55,6 +55,7 @@ SIGNATURES.update({
     # struct gi2d_train_state* (gaussianimage_plus_amd/trainer.py::_TrainState)
     "gi2d_train_render": [_p, _p],
     "gi2d_train_step": [_p, _p, _f, _f, _f, _i, _p],
+    "gi2d_train_steps": [_p, _p, _f, _f, _f, _i, _i, _p],
 })
 SIZE_FUNCS = {
     "gi2d_fast_workspace_bytes": [_i, _i, _i],

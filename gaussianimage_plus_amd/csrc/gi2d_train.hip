@@ -94,13 +94,20 @@ __device__ __forceinline__ float adam(float p, float g, float &m, float &v, cons
     return p - a.step_size * (m / denom);             // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-template <int KIND>
+// What the update kernel needs to start the NEXT iteration itself (FILL_NEXT): the freshly updated parameters
+// are still in registers, so their activation + projection + bucket fill ride along and the next iteration
+// begins with its tile pass -- one launch and one parameter round trip less per iteration.
+struct NextFill {
+    float clip_coe;
+    int32_t *num_tiles_hit, *cursors, *buckets, *status;
+};
+
+template <int KIND, bool FILL_NEXT>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(
-    int n, TrainParams P, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
+    int n, TrainParams P, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
-    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
+    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
 #pragma clang fp contract(off)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     // Is the render of THIS step (made with the pre-update parameters) the best so far?  Every workgroup sums
@@ -179,6 +186,30 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
         P.m_feat[3 * g + q] = mf;
         P.v_feat[3 * g + q] = vf;
+    }
+    if (FILL_NEXT) {
+        // same code path as train_project_fill_kernel, on the values just written
+        if (g == 0) {
+            next.status[0] = 0;
+            next.status[1] = 0;
+            next.status[3] = 0;
+        }
+        float2 mean2;
+        float par2[3];
+        activate<KIND>(P, g, mean2, par2);
+        const ProjOut o =
+            project_one<KIND>(0, next.clip_coe, &mean2, par2, nullptr, img_w, img_h, tiles_x, tiles_y, radius_clip);
+        xys[g] = o.xy;
+        radii[g] = o.radius;
+        conics[3 * g] = o.k0;
+        conics[3 * g + 1] = o.k1;
+        conics[3 * g + 2] = o.k2;
+        next.num_tiles_hit[g] = o.tiles_hit;
+        if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
+            int mnx, mny, mxx, mxy;
+            tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+            fill_one(g, mnx, mny, mxx, mxy, tiles_x, next.cursors, next.buckets);
+        }
     }
     if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned)
         best.xyz[2 * g] = P.xyz[2 * g];
@@ -265,39 +296,25 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
                                        s->status, nullptr, nullptr, s->out_img, st_);
 }
 
-// One full iteration: render, L2 loss gradient + backward, Adam update.  lr[3] / step are host values:
-// learning rates of the xyz / cholesky / colour groups for THIS step and the 1-based Adam step count.
-int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps, int step,
-                    gi2d_stream_t st_) {
+// `count` full iterations: render, L2 loss gradient + backward, Adam update.  lr[3] / first_step are host values:
+// learning rates of the xyz / cholesky / colour groups (constant over the call) and the 1-based Adam step count of
+// the first iteration.  Launches: project+fill once, then per iteration the tile pass and the update kernel, which
+// also projects and bins the updated gaussians for the following iteration (all but the last) -- 2*count + 1.
+int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps,
+                     int first_step, int count, gi2d_stream_t st_) {
     int tx, ty;
     int rc = train_check(s, tx, ty);
     if (rc != GI2D_OK) return rc;
     hipStream_t st = (hipStream_t)st_;
     const int n = s->num_points;
-    if (n == 0 || !lr || step < 1) {
-        if (n == 0) return GI2D_OK;
-        set_error("train step: bad lr/step");
+    if (n == 0 || count <= 0) return GI2D_OK;
+    if (!lr || first_step < 1) {
+        set_error("train steps: bad lr/step");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(s->workspace, n, tx * ty);
     const TrainParams P = params_of(s);
     const float grad_scale = 2.f / (3.f * (float)s->img_height * (float)s->img_width);
-    train_launch_project_fill(s, w, P, tx, ty, st);
-    rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
-                                              s->radii, s->conics, s->feat, s->opacity, nullptr, nullptr, s->gt,
-                                              grad_scale, s->tile_sse, s->workspace, s->workspace_bytes, s->status,
-                                              s->out_img, st_);
-    if (rc != GI2D_OK) return rc;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamStep a[3];
-    for (int q = 0; q < 3; ++q) {
-        a[q].step_size = (float)((double)lr[q] / bc1);
-        a[q].bc2_sqrt = (float)sqrt(bc2);
-        a[q].one_minus_b1 = (float)(1.0 - (double)beta1);
-        a[q].b2 = beta2;
-        a[q].one_minus_b2 = (float)(1.0 - (double)beta2);
-        a[q].eps = eps;
-    }
     BestSnap best;
     best.xyz = s->best_xyz;
     best.chol = s->best_chol;
@@ -307,23 +324,60 @@ int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, flo
     best.info = s->best_info;
     best.tile_sse = s->tile_sse;
     best.num_tiles = tx * ty;
-    best.step = step;
     if (best.sse && (!best.xyz || !best.chol || !best.feat || !best.info || (s->bound_stride && !s->best_bound))) {
-        set_error("train step: best_sse given without the snapshot buffers");
+        set_error("train steps: best_sse given without the snapshot buffers");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
+    NextFill next;
+    next.clip_coe = s->clip_coe;
+    next.num_tiles_hit = s->num_tiles_hit;
+    next.cursors = w.cursors;
+    next.buckets = w.buckets;
+    next.status = s->status;
     const dim3 gg((n + 255) / 256), bb(256);
-    if (s->kind == 0)
-        hipLaunchKernelGGL(train_reduce_update_kernel<kCholesky>, gg, bb, 0, st, n, P, (const float2 *)s->xys,
-                           s->radii, s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins,
-                           w.partial_g, w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2],
-                           s->dbg_grads, best);
-    else
-        hipLaunchKernelGGL(train_reduce_update_kernel<kCovariance>, gg, bb, 0, st, n, P, (const float2 *)s->xys,
-                           s->radii, s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins,
-                           w.partial_g, w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2],
-                           s->dbg_grads, best);
-    return check_launch("train step");
+    train_launch_project_fill(s, w, P, tx, ty, st);
+    for (int it = 0; it < count; ++it) {
+        const int step = first_step + it;
+        rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
+                                                  s->radii, s->conics, s->feat, s->opacity, nullptr, nullptr, s->gt,
+                                                  grad_scale, s->tile_sse, s->workspace, s->workspace_bytes,
+                                                  s->status, s->out_img, st_);
+        if (rc != GI2D_OK) return rc;
+        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        AdamStep a[3];
+        for (int q = 0; q < 3; ++q) {
+            a[q].step_size = (float)((double)lr[q] / bc1);
+            a[q].bc2_sqrt = (float)sqrt(bc2);
+            a[q].one_minus_b1 = (float)(1.0 - (double)beta1);
+            a[q].b2 = beta2;
+            a[q].one_minus_b2 = (float)(1.0 - (double)beta2);
+            a[q].eps = eps;
+        }
+        best.step = step;
+        const bool more = it + 1 < count;
+#define GI2D_LAUNCH_RU(K, F)                                                                                          \
+    hipLaunchKernelGGL((train_reduce_update_kernel<K, F>), gg, bb, 0, st, n, P, (float2 *)s->xys, s->radii, s->conics, \
+                       tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g, w.partial_big,  \
+                       (float)s->img_width, (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, next)
+        if (s->kind == 0) {
+            if (more)
+                GI2D_LAUNCH_RU(kCholesky, true);
+            else
+                GI2D_LAUNCH_RU(kCholesky, false);
+        } else {
+            if (more)
+                GI2D_LAUNCH_RU(kCovariance, true);
+            else
+                GI2D_LAUNCH_RU(kCovariance, false);
+        }
+#undef GI2D_LAUNCH_RU
+    }
+    return check_launch("train steps");
+}
+
+int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps, int step,
+                    gi2d_stream_t st) {
+    return gi2d_train_steps(s, lr, beta1, beta2, eps, step, 1, st);
 }
 
 }  // extern "C"

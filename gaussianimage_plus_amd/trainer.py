@@ -97,6 +97,7 @@ class NativeFitter:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.lr_step, self.lr_gamma = int(lr_step), float(lr_gamma)
         self.iteration = 0
+        self.max_call = 256  # iterations per C-ABI call (bounds the time one call keeps the host thread)
         self.rng = torch.Generator(device="cpu").manual_seed(seed)
         n, cap, h, w, dev = self.n, self.cap, self.h, self.w, self.dev
         self.gt = gt_hwc.contiguous().float()
@@ -152,9 +153,9 @@ class NativeFitter:
             bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)))
         self._state_ref = C.byref(self.state)
         self._lr3 = (C.c_float * 3)()
-        self._step_fn = self.lib.gi2d_train_step
-        self._step_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
-        self._step_fn.restype = C.c_int
+        self._steps_fn = self.lib.gi2d_train_steps
+        self._steps_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        self._steps_fn.restype = C.c_int
         self._render_fn = self.lib.gi2d_train_render
         self._render_fn.argtypes = [C.c_void_p, C.c_void_p]
         self._render_fn.restype = C.c_int
@@ -186,18 +187,21 @@ class NativeFitter:
         return self.lr * self.lr_gamma ** (self.iteration // self.lr_step)
 
     def train(self, iterations: int) -> None:
-        """Run `iterations` training iterations (asynchronous: only kernel launches)."""
+        """Run `iterations` training iterations (asynchronous: only kernel launches).  One C-ABI call per stretch
+        of constant learning rate (StepLR changes it every `lr_step` iterations), at most `max_call` iterations each."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
         b1, b2 = self.betas
-        state, lr3, fn = self._state_ref, self._lr3, self._step_fn
+        left = int(iterations)
         with torch.cuda.device(self.dev):
-            for _ in range(int(iterations)):
+            while left > 0:
                 lr = self.current_lr()
-                lr3[0] = lr3[1] = lr3[2] = lr
-                self.iteration += 1
-                rc = fn(state, lr3, b1, b2, self.eps, self.iteration, st)
+                self._lr3[0] = self._lr3[1] = self._lr3[2] = lr
+                count = min(left, self.lr_step - self.iteration % self.lr_step, self.max_call)
+                rc = self._steps_fn(self._state_ref, self._lr3, b1, b2, self.eps, self.iteration + 1, count, st)
                 if rc != 0:
-                    self._check(rc, "gi2d_train_step")
+                    self._check(rc, "gi2d_train_steps")
+                self.iteration += count
+                left -= count
 
     def render(self) -> torch.Tensor:
         """Rasterize the current parameters; returns clamp(out_img, 0, 1) as [H, W, 3]."""

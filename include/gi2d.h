@@ -360,6 +360,11 @@ typedef struct gi2d_train_state {
 int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
 int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
                     float eps, int step, gi2d_stream_t stream);
+/* `count` iterations with constant learning rates in one call (Adam steps first_step ...): the
+ * update kernel of every iteration but the last also activates, projects and bins the updated
+ * gaussians for the next one, so the call issues 2*count + 1 launches instead of 3*count. */
+int gi2d_train_steps(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
+                     float eps, int first_step, int count, gi2d_stream_t stream);
 
 #ifdef __cplusplus
 }
