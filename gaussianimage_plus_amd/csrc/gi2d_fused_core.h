@@ -54,6 +54,7 @@ struct FusedLds {
         struct {  // forward phase
             unsigned short list[4][GI2D_TILE_LIST_CAP + 8];
             float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats; re-used as the RGB transpose stage
+            int gid_by_rank[GI2D_TILE_LIST_CAP];  // ids in list order (beyond `ids`): leave as whole-line stores
         };
         struct {  // backward phase (member names as BwdLds: bwd_run_tile is shared)
             float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];
@@ -137,10 +138,10 @@ __device__ __forceinline__ void fused_tile(
         const int rad = radii[g];
         int rank = 0;
         for (int q = 0; q < L; ++q) rank += (sm.ids[q] < g) ? 1 : 0;
-        gids_sorted[tile * GI2D_FAST_C + rank] = g;
         const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
         const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
         if (rank < GI2D_TILE_LIST_CAP) {
+            sm.gid_by_rank[rank] = g;
             sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
             sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
             sm.gCb[rank] = r.cb;
@@ -156,6 +157,8 @@ __device__ __forceinline__ void fused_tile(
     }
     __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
+    // the tile's ascending id list (only its first 256 entries are ever looked up: find_in_tile), contiguous
+    if (tid < len) gids_sorted[tile * GI2D_FAST_C + tid] = sm.gid_by_rank[tid];
     GI2D_TRACE(3);
 
     // ---- forward: per-wave list of the entries that reach this wave's 4-row strip, then the packed pair loop
