@@ -25,8 +25,9 @@ struct TrainParams {
     const float *opacity;  // [N]   (a buffer of ones in the reference models; not optimised)
     const float *bound;    // [3] or [N,3]: additive bound (cholesky_bound / cov bound)
     int bound_stride;      // 0 or 3
-    // Adam state
+    // Adam / Adan state: first moment, second moment; Adan only: moment of the gradient difference, previous gradient
     float *m_xyz, *v_xyz, *m_chol, *v_chol, *m_feat, *v_feat;
+    float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
 };
 
 // Best-model snapshot kept on the device (train.py:133-139 deep-copies the state dict on the host whenever the
@@ -83,8 +84,11 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
 
 struct AdamStep {
     float step_size;       // lr / (1 - beta1^t)
-    float bc2_sqrt;        // sqrt(1 - beta2^t)
+    float bc2_sqrt;        // sqrt(1 - beta2^t)            (Adan: sqrt(1 - beta3^t))
     float one_minus_b1, b2, one_minus_b2, eps;
+    // Adan only
+    float b1, b3, one_minus_b3, step_size_diff;  // lr * beta2 / (1 - beta2^t)
+    int first;                                     // Adam step count == 1: the previous gradient is this one
 };
 // torch/optim/adam.py::_single_tensor_adam (non-capturable, no amsgrad, no weight decay)
 __device__ __forceinline__ float adam(float p, float g, float &m, float &v, const AdamStep &a) {
@@ -102,7 +106,22 @@ struct NextFill {
     int32_t *num_tiles_hit, *cursors, *buckets, *status;
 };
 
-template <int KIND, bool FILL_NEXT>
+// optimizer.py::_multi_tensor_adan / _single_tensor_adan (weight_decay 0, no gradient clipping), operation by
+// operation in fp32.  `pg` holds the previous gradient (the reference keeps its negative, neg_pre_grad).
+__device__ __forceinline__ float adan(float p, float g, float &m, float &n, float &d, float &pg, const AdamStep &a) {
+    const float diff = a.first ? 0.f : (-pg) + g;     // neg_pre_grad.add_(grad); step 1: neg_pre_grad = -grad
+    m = m * a.b1 + g * a.one_minus_b1;                // exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
+    d = d * a.b2 + diff * a.one_minus_b2;             // exp_avg_diff.mul_(beta2).add_(diff, alpha=1 - beta2)
+    const float u = diff * a.b2 + g;                  // neg_pre_grad.mul_(beta2).add_(grad)
+    n = n * a.b3 + a.one_minus_b3 * (u * u);          // exp_avg_sq.mul_(beta3).addcmul_(u, u, value=1 - beta3)
+    const float denom = sqrtf(n) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);                // addcdiv_(exp_avg, denom, value=-lr/bc1)
+    p = p - a.step_size_diff * (d / denom);           // addcdiv_(exp_avg_diff, denom, value=-lr*beta2/bc2)
+    pg = g;                                           // neg_pre_grad = -grad
+    return p;
+}
+
+template <int KIND, bool FILL_NEXT, bool ADAN>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     int n, TrainParams P, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
@@ -167,25 +186,43 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         d[6] = gf[1];
         d[7] = gf[2];
     }
-    {
-        float m0 = P.m_xyz[2 * g], m1 = P.m_xyz[2 * g + 1], v0 = P.v_xyz[2 * g], v1 = P.v_xyz[2 * g + 1];
-        P.xyz[2 * g] = adam(P.xyz[2 * g], gx, m0, v0, a_xyz);
-        P.xyz[2 * g + 1] = adam(P.xyz[2 * g + 1], gy, m1, v1, a_xyz);
-        P.m_xyz[2 * g] = m0;
-        P.m_xyz[2 * g + 1] = m1;
-        P.v_xyz[2 * g] = v0;
-        P.v_xyz[2 * g + 1] = v1;
-    }
+    if (ADAN) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        float m = P.m_chol[3 * g + q], v = P.v_chol[3 * g + q];
-        P.chol[3 * g + q] = adam(P.chol[3 * g + q], gp[q], m, v, a_chol);
-        P.m_chol[3 * g + q] = m;
-        P.v_chol[3 * g + q] = v;
-        float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q];
-        P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
-        P.m_feat[3 * g + q] = mf;
-        P.v_feat[3 * g + q] = vf;
+        for (int q = 0; q < 2; ++q) {
+            float m = P.m_xyz[2 * g + q], v = P.v_xyz[2 * g + q], d = P.d_xyz[2 * g + q], pg = P.pg_xyz[2 * g + q];
+            P.xyz[2 * g + q] = adan(P.xyz[2 * g + q], q ? gy : gx, m, v, d, pg, a_xyz);
+            P.m_xyz[2 * g + q] = m, P.v_xyz[2 * g + q] = v, P.d_xyz[2 * g + q] = d, P.pg_xyz[2 * g + q] = pg;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float m = P.m_chol[3 * g + q], v = P.v_chol[3 * g + q], d = P.d_chol[3 * g + q], pg = P.pg_chol[3 * g + q];
+            P.chol[3 * g + q] = adan(P.chol[3 * g + q], gp[q], m, v, d, pg, a_chol);
+            P.m_chol[3 * g + q] = m, P.v_chol[3 * g + q] = v, P.d_chol[3 * g + q] = d, P.pg_chol[3 * g + q] = pg;
+            float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q], df = P.d_feat[3 * g + q], pf = P.pg_feat[3 * g + q];
+            P.feat[3 * g + q] = adan(P.feat[3 * g + q], gf[q], mf, vf, df, pf, a_feat);
+            P.m_feat[3 * g + q] = mf, P.v_feat[3 * g + q] = vf, P.d_feat[3 * g + q] = df, P.pg_feat[3 * g + q] = pf;
+        }
+    } else {
+        {
+            float m0 = P.m_xyz[2 * g], m1 = P.m_xyz[2 * g + 1], v0 = P.v_xyz[2 * g], v1 = P.v_xyz[2 * g + 1];
+            P.xyz[2 * g] = adam(P.xyz[2 * g], gx, m0, v0, a_xyz);
+            P.xyz[2 * g + 1] = adam(P.xyz[2 * g + 1], gy, m1, v1, a_xyz);
+            P.m_xyz[2 * g] = m0;
+            P.m_xyz[2 * g + 1] = m1;
+            P.v_xyz[2 * g] = v0;
+            P.v_xyz[2 * g + 1] = v1;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float m = P.m_chol[3 * g + q], v = P.v_chol[3 * g + q];
+            P.chol[3 * g + q] = adam(P.chol[3 * g + q], gp[q], m, v, a_chol);
+            P.m_chol[3 * g + q] = m;
+            P.v_chol[3 * g + q] = v;
+            float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q];
+            P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
+            P.m_feat[3 * g + q] = mf;
+            P.v_feat[3 * g + q] = vf;
+        }
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
@@ -243,6 +280,12 @@ static TrainParams params_of(const gi2d_train_state *s) {
     P.v_chol = s->v_chol;
     P.m_feat = s->m_feat;
     P.v_feat = s->v_feat;
+    P.d_xyz = s->d_xyz;
+    P.d_chol = s->d_chol;
+    P.d_feat = s->d_feat;
+    P.pg_xyz = s->pg_xyz;
+    P.pg_chol = s->pg_chol;
+    P.pg_feat = s->pg_feat;
     return P;
 }
 
@@ -328,6 +371,12 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
         set_error("train steps: best_sse given without the snapshot buffers");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
+    const bool adan_opt = s->optimizer == 1;
+    if (s->optimizer < 0 || s->optimizer > 1 ||
+        (adan_opt && (!s->d_xyz || !s->d_chol || !s->d_feat || !s->pg_xyz || !s->pg_chol || !s->pg_feat))) {
+        set_error("train steps: unknown optimizer, or Adan without its extra state (d_*, pg_*)");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
     NextFill next;
     next.clip_coe = s->clip_coe;
     next.num_tiles_hit = s->num_tiles_hit;
@@ -344,32 +393,47 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
                                                   s->status, s->out_img, st_);
         if (rc != GI2D_OK) return rc;
         const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+        const double bc3 = 1.0 - pow((double)s->beta3, (double)step);
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) {
             a[q].step_size = (float)((double)lr[q] / bc1);
-            a[q].bc2_sqrt = (float)sqrt(bc2);
+            a[q].bc2_sqrt = (float)sqrt(adan_opt ? bc3 : bc2);
             a[q].one_minus_b1 = (float)(1.0 - (double)beta1);
             a[q].b2 = beta2;
             a[q].one_minus_b2 = (float)(1.0 - (double)beta2);
             a[q].eps = eps;
+            a[q].b1 = beta1;
+            a[q].b3 = s->beta3;
+            a[q].one_minus_b3 = (float)(1.0 - (double)s->beta3);
+            a[q].step_size_diff = (float)((double)lr[q] * (double)beta2 / bc2);
+            a[q].first = step == 1;
         }
         best.step = step;
         const bool more = it + 1 < count;
-#define GI2D_LAUNCH_RU(K, F)                                                                                          \
-    hipLaunchKernelGGL((train_reduce_update_kernel<K, F>), gg, bb, 0, st, n, P, (float2 *)s->xys, s->radii, s->conics, \
-                       tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g, w.partial_big,  \
-                       (float)s->img_width, (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, next)
+#define GI2D_LAUNCH_RU(K, F, A)                                                                                      \
+    hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A>), gg, bb, 0, st, n, P, (float2 *)s->xys, s->radii,        \
+                       s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g,      \
+                       w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, \
+                       next)
+#define GI2D_LAUNCH_RU2(K, F) \
+    do {                      \
+        if (adan_opt)         \
+            GI2D_LAUNCH_RU(K, F, true); \
+        else                  \
+            GI2D_LAUNCH_RU(K, F, false); \
+    } while (0)
         if (s->kind == 0) {
             if (more)
-                GI2D_LAUNCH_RU(kCholesky, true);
+                GI2D_LAUNCH_RU2(kCholesky, true);
             else
-                GI2D_LAUNCH_RU(kCholesky, false);
+                GI2D_LAUNCH_RU2(kCholesky, false);
         } else {
             if (more)
-                GI2D_LAUNCH_RU(kCovariance, true);
+                GI2D_LAUNCH_RU2(kCovariance, true);
             else
-                GI2D_LAUNCH_RU(kCovariance, false);
+                GI2D_LAUNCH_RU2(kCovariance, false);
         }
+#undef GI2D_LAUNCH_RU2
 #undef GI2D_LAUNCH_RU
     }
     return check_launch("train steps");

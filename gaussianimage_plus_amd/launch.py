@@ -71,7 +71,7 @@ def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, floa
 def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: int, lr: float = 1e-3,
                       seed: int = 3047, eval_renders: int = 10, kind: str = "cholesky", max_points: int = 0,
                       prune_iter: int = 100, grow_iter: int = 5000, eps: float = 1e-8,
-                      chunk: int = 16) -> List[Dict[str, float]]:
+                      chunk: int = 16, optimizer: str = "adam") -> List[Dict[str, float]]:
     """Fit the images of `gts` CONCURRENTLY on one GPU, one HIP stream each, on the fused training iteration
     (trainer.NativeFitter -> gi2d_train_step: one C-ABI call, three kernel launches, no host synchronisation per
     iteration).  One image's kernels leave most of the chip idle between their dependent phases, so
@@ -83,7 +83,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
 
     dev = gts[0].device
     adaptive = kind == "covariance" and max_points > num_points
-    fitters = [NativeFitter(gt, num_points, kind=kind, lr=lr, seed=seed, eps=eps,
+    fitters = [NativeFitter(gt, num_points, kind=kind, lr=lr, seed=seed, eps=eps, optimizer=optimizer,
                             max_points=max_points if adaptive else None, track_best=adaptive) for gt in gts]
     streams = [torch.cuda.Stream(device=dev) for _ in fitters] if len(fitters) > 1 else [torch.cuda.current_stream(dev)]
     torch.cuda.synchronize(dev)
@@ -201,7 +201,10 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--num_points", type=int, default=5000)
     ap.add_argument("--iterations", type=int, default=2000)
-    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--lr", type=float, default=None,
+                    help="default: train.py's choice for the model (covariance 0.018, otherwise 0.001)")
+    ap.add_argument("--opt_type", choices=["adam", "adan"], default=None,
+                    help="default: train.py's choice for the model (covariance: adam, otherwise adan; main():251-257)")
     ap.add_argument("--seed", type=int, default=3047)
     ap.add_argument("--model", choices=["cholesky", "covariance"], default="cholesky",
                     help="covariance = train.py's default model (pixel coordinates, lr 0.018, Adam eps 1e-15)")
@@ -229,8 +232,12 @@ def main(argv=None):
     images = load_images(args.dataset, args.synthetic, args.height, args.width)
 
     cov = args.model == "covariance"
+    if args.lr is None:
+        args.lr = 0.018 if cov else 0.001
+    if args.opt_type is None:
+        args.opt_type = "adam" if cov else "adan"
     native_kw = dict(lr=args.lr, seed=args.seed, kind=args.model, max_points=args.max_num_points,
-                     prune_iter=args.prune_iter, grow_iter=args.grow_iter, eps=1e-15 if cov else 1e-8)
+                     prune_iter=args.prune_iter, grow_iter=args.grow_iter, eps=1e-15, optimizer=args.opt_type)
 
     def report(i, img, r):
         print(f"[rank {rank}] image {i}: {img.shape[0]}x{img.shape[1]}, PSNR:{r['psnr']:.4f}, "

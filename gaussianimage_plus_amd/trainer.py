@@ -50,6 +50,9 @@ class _TrainState(C.Structure):
         ("dbg_grads", C.c_void_p),
         ("best_xyz", C.c_void_p), ("best_chol", C.c_void_p), ("best_feat", C.c_void_p), ("best_bound", C.c_void_p),
         ("best_sse", C.c_void_p), ("best_info", C.c_void_p),
+        ("optimizer", C.c_int), ("beta3", C.c_float),
+        ("d_xyz", C.c_void_p), ("d_chol", C.c_void_p), ("d_feat", C.c_void_p),
+        ("pg_xyz", C.c_void_p), ("pg_chol", C.c_void_p), ("pg_feat", C.c_void_p),
     ]
 
 
@@ -84,17 +87,23 @@ def select_new_points(render_hwc: torch.Tensor, gt_hwc: torch.Tensor, count: int
 
 class NativeFitter:
     def __init__(self, gt_hwc: torch.Tensor, num_points: int, kind: str = "cholesky", lr: float = 1e-3,
-                 betas=(0.9, 0.999), eps: float = 1e-8, lr_step: int = 20000, lr_gamma: float = 0.5,
+                 betas=None, eps: float = 1e-8, lr_step: int = 20000, lr_gamma: float = 0.5,
                  seed: int = 3047, clip_coe: float = 3.0, radius_clip: float = 1.0,
                  init: Optional[dict] = None, debug_grads: bool = False, max_points: Optional[int] = None,
-                 track_best: bool = False):
+                 track_best: bool = False, optimizer: str = "adam"):
+        """optimizer: "adam" (torch.optim.Adam, betas (0.9, 0.999)) or "adan" (the reference's optimizer.py::Adan,
+        betas (0.98, 0.92, 0.99) -- what train.py picks for the Cholesky and RS models, with lr 1e-3, eps 1e-15)."""
         assert kind in _KINDS and gt_hwc.is_cuda and gt_hwc.dim() == 3 and gt_hwc.size(2) == 3
+        assert optimizer in ("adam", "adan")
+        self.optimizer = optimizer
+        if betas is None:
+            betas = (0.9, 0.999) if optimizer == "adam" else (0.98, 0.92, 0.99)
         self.lib = _lib.load()
         self.kind, self.dev = kind, gt_hwc.device
         self.h, self.w, self.n = int(gt_hwc.shape[0]), int(gt_hwc.shape[1]), int(num_points)
         self.cap = max(int(max_points or 0), self.n)
         self.tx, self.ty = (self.w + 15) // 16, (self.h + 15) // 16
-        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.lr, self.betas, self.eps = float(lr), tuple(float(b) for b in betas), float(eps)
         self.lr_step, self.lr_gamma = int(lr_step), float(lr_gamma)
         self.iteration = 0
         self.max_call = 256  # iterations per C-ABI call (bounds the time one call keeps the host thread)
@@ -127,6 +136,9 @@ class NativeFitter:
         self._m_xyz, self._v_xyz = f32(cap, 2), f32(cap, 2)
         self._m_chol, self._v_chol = f32(cap, 3), f32(cap, 3)
         self._m_feat, self._v_feat = f32(cap, 3), f32(cap, 3)
+        if optimizer == "adan":  # moment of the gradient difference, previous gradient
+            self._d_xyz, self._d_chol, self._d_feat = f32(cap, 2), f32(cap, 3), f32(cap, 3)
+            self._pg_xyz, self._pg_chol, self._pg_feat = f32(cap, 2), f32(cap, 3), f32(cap, 3)
         self.xys, self.conics, self.radii, self.nth = f32(cap, 2), f32(cap, 3), i32(cap), i32(cap)
         self.out_img, self.tile_sse, self.status = f32(h, w, 3), f32(self.tx * self.ty), i32(4)
         self.dbg_grads = f32(cap, 8) if debug_grads else None
@@ -150,7 +162,10 @@ class NativeFitter:
             p(self.status), p(self.ws), nbytes, p(self.dbg_grads) if debug_grads else None,
             bp(getattr(self, "best_xyz", None)), bp(getattr(self, "best_chol", None)),
             bp(getattr(self, "best_feat", None)), bp(getattr(self, "best_bound", None)),
-            bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)))
+            bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)),
+            1 if optimizer == "adan" else 0, self.betas[2] if optimizer == "adan" else 0.0,
+            *[(p(getattr(self, nm)) if optimizer == "adan" else None)
+              for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")])
         self._state_ref = C.byref(self.state)
         self._lr3 = (C.c_float * 3)()
         self._steps_fn = self.lib.gi2d_train_steps
@@ -190,7 +205,7 @@ class NativeFitter:
         """Run `iterations` training iterations (asynchronous: only kernel launches).  One C-ABI call per stretch
         of constant learning rate (StepLR changes it every `lr_step` iterations), at most `max_call` iterations each."""
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        b1, b2 = self.betas
+        b1, b2 = self.betas[0], self.betas[1]
         left = int(iterations)
         with torch.cuda.device(self.dev):
             while left > 0:
@@ -253,6 +268,8 @@ class NativeFitter:
     def _rows(self):
         rows = [self._xyz, self._chol, self._feat, self._opacity, self._m_xyz, self._v_xyz, self._m_chol, self._v_chol,
                 self._m_feat, self._v_feat]
+        if self.optimizer == "adan":
+            rows += [self._d_xyz, self._d_chol, self._d_feat, self._pg_xyz, self._pg_chol, self._pg_feat]
         if self.per_point_bound:
             rows.append(self._bound)
         return rows
@@ -287,7 +304,7 @@ class NativeFitter:
         n0, n1 = self.n, self.n + k
         self._xyz[n0:n1], self._chol[n0:n1], self._feat[n0:n1] = new["xyz"], new["cov2d"], new["feat"]
         self._opacity[n0:n1] = 1.0
-        for t in (self._m_xyz, self._v_xyz, self._m_chol, self._v_chol, self._m_feat, self._v_feat):
+        for t in self._rows()[4:]:  # optimizer moments of the new rows (the bound, if per point, is set below)
             t[n0:n1] = 0.0
         if self.per_point_bound:  # SLV: the new rows get the low-pass bound of the new population size
             low_pass = min(self.h * self.w / (9 * math.pi * n1), 300)

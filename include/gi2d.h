@@ -319,7 +319,7 @@ int gi2d_timer_elapsed_us(void *timer, float *microseconds);
 /* ------------------------------------------------------------------ fused fitting iteration
  * SURVEY 8f rank 2 (callers either side of the path): one whole training iteration of the
  * Cholesky (kind 0) or covariance (kind 1) model with L2 loss and Adam --
- * models/gaussianimage_cholesky.py:302-317 / models/gaussianimage_covariance.py:249-259 --
+ * (or Adan) -- models/gaussianimage_cholesky.py:302-317 / models/gaussianimage_covariance.py:249-259 --
  * in three launches: activations+projection+fill, one tile pass (rasterize forward, loss
  * gradient formed per pixel in registers, backward), gradient reduce + projection backward + activation
  * backward + torch.optim.Adam update.  All pointers are device pointers owned by the caller.
@@ -356,6 +356,13 @@ typedef struct gi2d_train_state {
      * +inf by the caller, ping-pongs between steps: the current best is best_sse[(last step + 1) & 1]. */
     float *best_xyz, *best_chol, *best_feat, *best_bound, *best_sse;
     int32_t *best_info;
+    /* optimizer: 0 = torch.optim.Adam (m_* = exp_avg, v_* = exp_avg_sq; beta1, beta2 of the step call);
+     * 1 = Adan (optimizer.py:125-330, what train.py selects for the Cholesky / RS models): v_* = exp_avg_sq n_t
+     * with beta3, d_* = exp_avg_diff, pg_* = previous gradient (the reference stores its negative), same shapes
+     * as the parameters; weight decay 0, no gradient-norm clipping. */
+    int optimizer;
+    float beta3;
+    float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
 } gi2d_train_state;
 int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
 int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _torch_loop(kind, gt, init, bound, iters, lr, eps=1e-8):
+def _torch_loop(kind, gt, init, bound, iters, lr, eps=1e-8, optimizer="adam"):
     import gaussianimage_plus_amd.gsplat as gs
     h, w = gt.shape[0], gt.shape[1]
     tb = ((w + 15) // 16, (h + 15) // 16, 1)
@@ -19,7 +19,11 @@ def _torch_loop(kind, gt, init, bound, iters, lr, eps=1e-8):
     chol = init["chol"].clone().to(DEV).requires_grad_(True)
     feat = init["feat"].clone().to(DEV).requires_grad_(True)
     opacity = torch.ones(xyz.shape[0], 1, device=DEV)
-    opt = torch.optim.Adam([xyz, chol, feat], lr=lr, eps=eps)
+    if optimizer == "adam":
+        opt = torch.optim.Adam([xyz, chol, feat], lr=lr, eps=eps)
+    else:
+        from helpers_adan import AdanRef
+        opt = AdanRef([xyz, chol, feat], lr=lr, eps=eps)
     bg = torch.ones(3, device=DEV)
     grads1, losses = None, []
     for it in range(iters):
@@ -34,7 +38,10 @@ def _torch_loop(kind, gt, init, bound, iters, lr, eps=1e-8):
             grads1 = torch.cat([xyz.grad, chol.grad, feat.grad], 1).clone()
         losses.append(float(loss.detach()))
         opt.step()
-        opt.zero_grad(set_to_none=True)
+        if optimizer == "adam":
+            opt.zero_grad(set_to_none=True)
+        else:
+            opt.zero_grad()
     return xyz.detach(), chol.detach(), feat.detach(), grads1, losses
 
 
@@ -184,3 +191,34 @@ def test_adaptive_fit_grows_to_the_cap_and_improves():
     psnr, step, n_best = fit.best()
     assert n0 < n_best <= cap  # the snapshot carries its own population (it may predate a later prune)
     assert fit.load_best() == psnr and abs(fit.psnr() - psnr) < 0.3
+
+
+def test_native_adan_matches_autograd_loop_with_reference_adan():
+    """train.py trains the Cholesky model with Adan (lr 1e-3, eps 1e-15; main(): opt_type "adan"): the fused update
+    kernel against the drop-in wrappers + autograd + the Adan statement that the reference fixture pins."""
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    n, h, w, iters, lr = 3000, 96, 144, 12, 1e-3
+    gt = synthetic_image(h, w, 5).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    init = {"xyz": torch.atanh(2 * (torch.rand(n, 2, generator=g) - 0.5) * 0.98),
+            "chol": torch.rand(n, 3, generator=g) * torch.tensor([1.0, 0.3, 1.0]),
+            "feat": torch.rand(n, 3, generator=g) * 0.3}
+    low_pass = min(h * w / (9 * math.pi * n), 300)
+    bound = torch.tensor([low_pass, 0.0, low_pass], device=DEV)
+    fit = NativeFitter(gt, n, kind="cholesky", lr=lr, eps=1e-15, init=init, optimizer="adan")
+    fit.train(5)
+    fit.train(iters - 5)   # two stretches: the previous gradient carries over between calls
+    fit.check_status()
+    want = _torch_loop("cholesky", gt, init, bound, iters, lr, eps=1e-15, optimizer="adan")
+    for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "chol"), (fit.feat, want[2], "feat")):
+        d = (got - ref).abs()
+        moved = (ref - init[nm].to(DEV)).abs().max().item()
+        assert moved > 2 * lr, nm                      # Adan's first steps are ~lr each: the parameters did move
+        assert d.max().item() < 0.15 * lr * iters, f"{nm} drifted by {d.max().item()}"
+        assert d.mean().item() < 2e-2 * lr * iters, nm
+    # one call of 12 iterations == 12 calls of one iteration, bit for bit
+    one = NativeFitter(gt, n, kind="cholesky", lr=lr, eps=1e-15, init=init, optimizer="adan")
+    for _ in range(iters):
+        one.train(1)
+    assert torch.equal(one.xyz, fit.xyz) and torch.equal(one.chol, fit.chol) and torch.equal(one.feat, fit.feat)
