@@ -382,7 +382,8 @@ int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, int tiles_x, in
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
-    hipLaunchKernelGGL(fast_fill_kernel, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0,
+    const int fbs = per_gaussian_block(n);
+    hipLaunchKernelGGL(fast_fill_kernel, dim3((n + fbs - 1) / fbs > 0 ? (n + fbs - 1) / fbs : 1), dim3(fbs), 0,
                        (hipStream_t)st, n, (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.cursors,
                        w.buckets, status);
     return check_launch("fast bin");
@@ -400,7 +401,8 @@ int gi2d_fast_project_bin(int kind, int n, float clip_coe, const float *means2d,
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
-    const dim3 grid((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), block(256);
+    const int bs = per_gaussian_block(n);
+    const dim3 grid((n + bs - 1) / bs > 0 ? (n + bs - 1) / bs : 1), block(bs);
 #define GI2D_LAUNCH_PF(K)                                                                                       \
     hipLaunchKernelGGL(fast_project_fill_kernel<K>, grid, block, 0, (hipStream_t)st, n, clip_coe,              \
                        (const float2 *)means2d, p0, p1, (float)w_, (float)h, tiles_x, tiles_y, radius_clip,    \
@@ -513,7 +515,8 @@ int gi2d_fast_rasterize_backward_reduce(int n, const float *xys, const int32_t *
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
-    hipLaunchKernelGGL(fast_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, n,
+    const int rbs = per_gaussian_block(n);
+    hipLaunchKernelGGL(fast_reduce_kernel, dim3((n + rbs - 1) / rbs), dim3(rbs), 0, (hipStream_t)st, n,
                        (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.gids_sorted,
                        (const int2 *)w.tile_bins, w.partial_g, w.partial_big, (float2 *)v_xy, v_conic, v_rgb,
                        v_opacity, (float4 *)v_abs_xy);
@@ -535,7 +538,8 @@ int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const fl
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
-    const dim3 grid((n + 255) / 256), block(256);
+    const int bs = per_gaussian_block(n);
+    const dim3 grid((n + bs - 1) / bs), block(bs);
 #define GI2D_LAUNCH_RP(K)                                                                                      \
     hipLaunchKernelGGL(fast_reduce_project_kernel<K>, grid, block, 0, (hipStream_t)st, n, (const float2 *)xys, \
                        radii, conics, tiles_x, tiles_y, radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, \

@@ -525,10 +525,13 @@ __device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, cons
     dst[2] = make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, 0.f);
 }
 
+__device__ __forceinline__ void add_partial_row(float acc[11], const float4 &p0, const float4 &p1, const float4 &p2);
 // STRIDE = float4 per row: 3 (packed 48-byte rows) or 4 (rows padded to one 64-byte line each)
 template <int STRIDE = 3>
 __device__ __forceinline__ void add_partial(float acc[11], const float4 *__restrict__ partials, size_t row) {
-    const float4 p0 = partials[STRIDE * row], p1 = partials[STRIDE * row + 1], p2 = partials[STRIDE * row + 2];
+    add_partial_row(acc, partials[STRIDE * row], partials[STRIDE * row + 1], partials[STRIDE * row + 2]);
+}
+__device__ __forceinline__ void add_partial_row(float acc[11], const float4 &p0, const float4 &p1, const float4 &p2) {
     acc[0] += p0.x;
     acc[1] += p0.y;
     acc[2] += p0.z;

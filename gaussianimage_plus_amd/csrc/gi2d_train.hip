@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (best.sse != nullptr) {
         __shared__ float red[256];
         float part = 0.f;
-        for (int t = threadIdx.x; t < best.num_tiles; t += 256) part += best.tile_sse[t];
+        for (int t = threadIdx.x; t < best.num_tiles; t += (int)blockDim.x) part += best.tile_sse[t];
         red[threadIdx.x] = part;
         __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
+        for (int d = (int)blockDim.x / 2; d >= 1; d >>= 1) {  // blockDim.x is 64 or 256
             if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
             __syncthreads();
         }
@@ -312,7 +312,8 @@ static int train_check(const gi2d_train_state *s, int &tx, int &ty) {
 static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w, const TrainParams &P, int tx,
                                       int ty, hipStream_t st) {
     const int n = s->num_points;
-    const dim3 gg((n + 255) / 256), bb(256);
+    const int bs = per_gaussian_block(n);
+    const dim3 gg((n + bs - 1) / bs), bb(bs);
     if (s->kind == 0)
         hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
@@ -383,7 +384,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     next.cursors = w.cursors;
     next.buckets = w.buckets;
     next.status = s->status;
-    const dim3 gg((n + 255) / 256), bb(256);
+    const int bs = per_gaussian_block(n);
+    const dim3 gg((n + bs - 1) / bs), bb(bs);
     train_launch_project_fill(s, w, P, tx, ty, st);
     for (int it = 0; it < count; ++it) {
         const int step = first_step + it;
