@@ -134,8 +134,16 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     bool snapshot = false;
     if (best.sse != nullptr) {
         __shared__ float red[256];
+        // 16-byte loads, several in flight per lane (a lane-serial chain of 4-byte loads cost 8 us per step)
         float part = 0.f;
-        for (int t = threadIdx.x; t < best.num_tiles; t += (int)blockDim.x) part += best.tile_sse[t];
+        const float4 *sse4 = reinterpret_cast<const float4 *>(best.tile_sse);
+        const int n4 = best.num_tiles >> 2;
+#pragma unroll 8
+        for (int t = threadIdx.x; t < n4; t += (int)blockDim.x) {
+            const float4 v = sse4[t];
+            part += (v.x + v.y) + (v.z + v.w);
+        }
+        for (int t = (n4 << 2) + threadIdx.x; t < best.num_tiles; t += (int)blockDim.x) part += best.tile_sse[t];
         red[threadIdx.x] = part;
         __syncthreads();
         for (int d = (int)blockDim.x / 2; d >= 1; d >>= 1) {  // blockDim.x is 64 or 256
