@@ -11,6 +11,28 @@
 // sort buffer, the forward's lists + pair buffers and the backward's pixel / item / hand-off buffers overlay
 // each other (they are live in disjoint phases, separated by workgroup barriers).
 #pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+// Development aid (-DGI2D_FUSED_TRACE): thread 0 of every workgroup stamps the 100 MHz wall clock at the phase
+// boundaries into a buffer set with gi2d_debug_set_trace (tools/trace_fused.py).
+#ifdef GI2D_FUSED_TRACE
+namespace gi2d {
+__device__ unsigned long long *g_fused_trace = nullptr;  // [tiles][16]
+}
+#define GI2D_TRACE_AT(wg, i)                                                                        \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && g_fused_trace) g_fused_trace[(wg) * 16 + (i)] = wall_clock64();     \
+    } while (0)
+#define GI2D_TRACE(i) GI2D_TRACE_AT(tile, i)
+#define GI2D_BWD_TRACE(i) GI2D_TRACE_AT(blockIdx.x, i)
+#else
+#define GI2D_TRACE(i) \
+    do {              \
+    } while (0)
+#endif
+
 #include "gi2d_fast_internal.h"
 
 namespace gi2d {
@@ -19,20 +41,6 @@ namespace gi2d {
 #define GI2D_FUSED_OCC 6 /* workgroups per CU the register allocator leaves room for: 1536 tiles of a 768x512 image
                             are then resident at once (measured: a 27 KB workgroup still gets only 5 per CU and a
                             second, 256-workgroup round; 23.7 KB gets 6) */
-#endif
-
-// Development aid (-DGI2D_FUSED_TRACE): thread 0 of every workgroup stamps the 100 MHz wall clock at the phase
-// boundaries into a buffer set with gi2d_debug_set_trace (tools/trace_fused.py).
-#ifdef GI2D_FUSED_TRACE
-__device__ unsigned long long *g_fused_trace = nullptr;  // [tiles][8]
-#define GI2D_TRACE(i)                                                                  \
-    do {                                                                               \
-        if (threadIdx.x == 0 && g_fused_trace) g_fused_trace[tile * 8 + (i)] = wall_clock64(); \
-    } while (0)
-#else
-#define GI2D_TRACE(i) \
-    do {              \
-    } while (0)
 #endif
 
 struct FusedLds {
@@ -278,7 +286,7 @@ __device__ __forceinline__ void fused_tile(
         dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
     }
     bwd_run_tile<false, false>(sm, len, cull, 0, tx0, ty0, dst);
-    GI2D_TRACE(7);
+    GI2D_TRACE(10);
     if (MODE == 1 && tid == 0) tile_sse[tile] = (sm.sse_w[0] + sm.sse_w[1]) + (sm.sse_w[2] + sm.sse_w[3]);
     // "No intersection at all" is a global property: see fast_fwd_kernel
     if (tid == 0 && L > 0) status[0] = 1;

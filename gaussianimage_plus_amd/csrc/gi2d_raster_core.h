@@ -350,6 +350,12 @@ __device__ __forceinline__ void bwd_stage_entry(Lds &sm, int k, const GaussRec &
 // USE_FIDX=false (fast path): the forward that produced the lists evaluates every pair with the same
 // instructions, so "idx <= final_idx" is implied by the alpha test and is not re-checked (pixels outside the
 // image still carry v_out = 0 and contribute nothing).
+#ifndef GI2D_BWD_TRACE  /* gi2d_fused_core.h defines it for its phase trace (development aid) */
+#define GI2D_BWD_TRACE(i) \
+    do {                  \
+    } while (0)
+#endif
+
 template <bool USE_FIDX>
 __device__ __forceinline__ bool fidx_admits(int idx, const float4 &p1, int half) {
     return !USE_FIDX || idx <= __float_as_int(half ? p1.w : p1.z);
@@ -381,6 +387,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         for (int p = 0; p < nitems; ++p) sm.item[excl++] = (unsigned char)tid;
     }
     __syncthreads();
+    GI2D_BWD_TRACE(7);
     const int n_items = sm.off[len];
 
     // pixel x coordinates of a row's first pair, exactly as the forward forms them: (float)j
@@ -476,6 +483,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                 res[PSTR - 1] = ay.x + ay.y;
             }
         }
+        GI2D_BWD_TRACE(8);  // this lane's item is done (lane 0: not the slowest one)
         // hand-off: the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row
         // order.  The LDS exchange buffer holds PART_ROWS item rows, so a round is handed over in
         // GI2D_BWD_ITEMS / PART_ROWS passes (half the buffer = two more barriers, 4.5 KB less LDS per workgroup).
@@ -513,6 +521,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             }
             __syncthreads();
         }
+        GI2D_BWD_TRACE(9);
         if (owner) store_partial_row<PSTR>(dst, acc);
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);

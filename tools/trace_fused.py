@@ -22,14 +22,14 @@ hp.set_inputs(xyz, L, col, op)
 hp.set_target(torch.from_numpy(synth_gt(h, w, 1)).to(dev))
 lib = _lib.load()
 lib.gi2d_debug_set_trace.argtypes = [ctypes.c_void_p]
-trace = torch.zeros(hp.T, 8, dtype=torch.int64, device=dev)
+trace = torch.zeros(hp.T, 16, dtype=torch.int64, device=dev)
 assert lib.gi2d_debug_set_trace(trace.data_ptr()) == 0
 for _ in range(20):
     hp.step()
 torch.cuda.synchronize()
-t = trace.cpu().numpy().astype(np.float64) * 0.01  # 100 MHz ticks -> us
+t = trace.cpu().numpy().astype(np.float64)[:, :11] * 0.01  # 100 MHz ticks -> us
 t -= t[:, 0].min()
-names = ["start", "cursors", "ids", "staged", "lists", "fwd loop", "pixel out", "bwd done"]
+names = ["start", "cursors", "ids", "staged", "lists", "fwd loop", "pixel out", "bwd items", "bwd lane0", "bwd handoff", "bwd done"]
 print(f"N={n} M={hp.num_intersects()} tiles={hp.T}   (us since the first workgroup started)")
 print(f"{'phase':10s} {'min':>7s} {'p50':>7s} {'p90':>7s} {'max':>7s}   {'dur p50':>8s} {'dur p90':>8s} {'dur max':>8s}")
 for i, nm in enumerate(names):
