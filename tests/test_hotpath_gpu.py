@@ -270,3 +270,43 @@ def test_single_pass_l2_target_matches_torch_loss_gradient(n, h, w):
     exact._l2_grad_from_render()
     inner = (fused.out_img > 0) & (fused.out_img < 1)
     assert torch.allclose(exact.v_out[inner], o.grad[inner], rtol=1e-6, atol=0)
+
+
+def test_single_pass_edge_geometries(oracle):
+    """The one-kernel tile pass on awkward inputs: an image smaller than a tile, gaussians covering hundreds of
+    tiles (wave-cooperative reduce, (tile, rank) partial rows), gaussians far outside, zero opacity, a single
+    gaussian -- against the capacity-free ops bit for bit and against the oracle."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    cases = []
+    rng = np.random.default_rng(77)
+    # (a) 9x7 image, 3 gaussians
+    cases.append((7, 9, (rng.random((3, 2)).astype(np.float32) - 0.5), np.array([[2, 0.1, 2]] * 3, np.float32),
+                  rng.random((3, 3)).astype(np.float32), np.ones((3, 1), np.float32)))
+    # (b) one gaussian in a 40x56 image
+    cases.append((40, 56, np.array([[0.1, -0.2]], np.float32), np.array([[3, 0.5, 2]], np.float32),
+                  np.array([[0.3, 0.6, 0.9]], np.float32), np.ones((1, 1), np.float32)))
+    # (c) 300 gaussians, some huge (cover the whole 160x240 image = 150 tiles), some outside, some transparent
+    n = 300
+    xyz = ((rng.random((n, 2)) - 0.5) * 1.9).astype(np.float32)
+    L = (rng.random((n, 3)) * np.array([3, 0.5, 3]) + np.array([1.5, 0, 1.5])).astype(np.float32)
+    L[:6] = [60, 4, 55]
+    xyz[6:10] = [4.0, -3.0]
+    op = np.ones((n, 1), np.float32)
+    op[10:14] = 0.0
+    cases.append((160, 240, xyz, L, rng.random((n, 3)).astype(np.float32), op))
+    for h, w, xyz, L, col, op in cases:
+        n = xyz.shape[0]
+        one = HotPath(n, h, w, device=DEV, mode="fused")
+        exact = HotPath(n, h, w, device=DEV, mode="exact")
+        gt = torch.from_numpy(synth_gt(h, w, 9)).to(DEV)
+        for hp in (one, exact):
+            hp.set_inputs(xyz, L, col, op)
+            hp.set_target(gt)
+            hp.step()
+            hp.check_status()
+        for name in ("out_img", "v_xy", "v_conic", "v_rgb", "v_opac", "v_mean2d", "v_params"):
+            assert torch.equal(getattr(one, name), getattr(exact, name)), (h, w, name)
+        ref = oracle.render_cholesky(xyz, L, col, op, h, w, with_aux=True)
+        out_o, fT, fidx, amb, absimg = ref["ras"]
+        check_close("edge out_img", one.out_img.cpu().numpy(), out_o, absimg,
+                    mask=np.repeat((amb == 0)[..., None], 3, -1), rtol=3e-5)
