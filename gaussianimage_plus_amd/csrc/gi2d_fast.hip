@@ -219,6 +219,11 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
 }
 
+__global__ __launch_bounds__(256) void iota_kernel(int n, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 // ----------------------------------------------------------------- forward + backward in one pass
 template <int MODE>
 __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
@@ -227,9 +232,10 @@ __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
     const float *__restrict__ opacities, int32_t *__restrict__ cursors, const int32_t *__restrict__ buckets,
     int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g,
     float4 *__restrict__ partial_big, int32_t *__restrict__ status, float *__restrict__ out_img,
-    const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
+    const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse,
+    const int32_t *__restrict__ tile_order) {
     __shared__ FusedLds sm;
-    fused_tile<MODE>(sm, blockIdx.x, tiles_x, tiles_y, img_w, img_h, xys, radii, conics, colors, opacities, cursors,
+    fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, xys, radii, conics, colors, opacities, cursors,
                      buckets, gids_sorted, tile_bins, partial_g, partial_big, status, out_img, vsrc, grad_scale,
                      tile_sse);
 }
@@ -370,7 +376,9 @@ int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int 
         set_error(hipGetErrorString(e));
         return (int)e;
     }
-    return GI2D_OK;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)st, (int)t,
+                       w.tile_order);
+    return check_launch("fast workspace init");
 }
 
 int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, int tiles_x, int tiles_y, float radius_clip,
@@ -469,12 +477,12 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
                           (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors,
                           (const int32_t *)w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big,
-                          status, out_img, v_output, 0.f, no_sse);
+                          status, out_img, v_output, 0.f, no_sse, (const int32_t *)w.tile_order);
     else
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
                           (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors,
                           (const int32_t *)w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big,
-                          status, out_img, target, grad_scale, tile_sse);
+                          status, out_img, target, grad_scale, tile_sse, (const int32_t *)w.tile_order);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);

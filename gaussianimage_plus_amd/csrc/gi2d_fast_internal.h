@@ -35,6 +35,8 @@ struct FastWs {
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
     float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
     float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
+    int32_t *tile_order;   // [T]                tile handled by workgroup b of the single-pass tile kernel: a
+                           //                    permutation that balances tile populations over the CUs
     size_t bytes;
 };
 static FastWs carve_fast(void *base, int n, int num_tiles) {
@@ -52,6 +54,10 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     off += align_up(t * 2 * sizeof(int32_t));
     w.packed = (GaussRec *)(b + off);
     off += align_up(t * GI2D_TILE_LIST_CAP * sizeof(GaussRec));
+    // cursors and tile_order carry state from call to call: both sit in front of every region whose offset depends
+    // on the gaussian count, so a workspace initialised for a capacity can be used with any smaller population
+    w.tile_order = (int32_t *)(b + off);
+    off += align_up(t * sizeof(int32_t));
     w.partial_g = (float4 *)(b + off);
     off += align_up(nn * GI2D_FAST_S * GI2D_FAST_ROW * sizeof(float4));
     w.partial_big = (float4 *)(b + off);
@@ -93,6 +99,72 @@ __device__ __forceinline__ int partial_slot(int g, const float2 xy, int rad, int
     const int w = mxx - mnx, ntiles = w * (mxy - mny);
     if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + (ty - mny) * w + (tx - mnx);
     return -big_row - 1;
+}
+
+// ------------------------------------------------------------------------------- tile order
+// All workgroups of the single-pass tile kernel are resident at once on a 768x512 image (6 per CU), and the
+// dispatcher was observed to put workgroups b, b + 256, b + 512, ... on the same CU; a CU is done when its six
+// tiles are, and tile populations differ (40...108 gaussians at N=50 000), so the slowest CU finished 5 us after
+// the fastest.  This routine -- one extra workgroup of the training update kernel, where it hides behind the other
+// workgroups -- sorts the tiles by the population the tile pass has just seen (counting sort, descending) and deals
+// them to workgroup indices in snake order over the 256 CU slots, for the NEXT iteration's tile pass (populations
+// drift slowly during training).  Any permutation gives the same results; placement is a pure speed choice
+// (dispatch order is undefined by contract).  Measured: training iteration at N=50 000 50.2 -> 44.6 us.  It is not
+// attached to the plain reduce+project kernel: its LDS histogram atomics (many lanes per bin) take ~5 us, longer
+// than that kernel, and the synthetic uniform scene of bench.py gains only 0.8 us in the tile pass.
+#define GI2D_ORDER_BINS 1025 /* populations 0 .. GI2D_FAST_C */
+#define GI2D_CU_SLOTS 256
+#define GI2D_ORDER_MAX_TILES 2048 /* larger grids run in several rounds of resident workgroups and balance themselves */
+__device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile_bins, int num_tiles,
+                                                   int32_t *__restrict__ tile_order) {
+    if (num_tiles <= GI2D_CU_SLOTS || num_tiles > GI2D_ORDER_MAX_TILES) return;  // order stays the identity
+    __shared__ int hist[GI2D_ORDER_BINS + 1];
+    const int tid = threadIdx.x, bs = blockDim.x;  // 64 or 256 lanes
+    for (int b = tid; b <= GI2D_ORDER_BINS; b += bs) hist[b] = 0;
+    // every lane's (<= 32) tile populations: all loads in flight together, kept in registers for both passes (a
+    // lane-serial chain of dependent loads would put this workgroup on the kernel's critical path)
+    constexpr int PL = GI2D_ORDER_MAX_TILES / 64;
+    int pop[PL];
+#pragma unroll
+    for (int q = 0; q < PL; ++q) {
+        const int t = tid + q * bs;
+        const int2 r = t < num_tiles ? tile_bins[t] : make_int2(0, 0);
+        pop[q] = min(max(r.y - r.x, 0), GI2D_ORDER_BINS - 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PL; ++q)
+        if (tid + q * bs < num_tiles) atomicAdd(&hist[GI2D_ORDER_BINS - 1 - pop[q]], 1);  // bin 0 = fullest tiles
+    __syncthreads();
+    // exclusive scan of the bins by the first wave: 17 bins per lane in registers, one wave scan of the lane sums
+    if (tid < 64) {
+        constexpr int PER = (GI2D_ORDER_BINS + 63) / 64;
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int b = tid * PER + q;
+            v[q] = b < GI2D_ORDER_BINS ? hist[b] : 0;
+            sum += v[q];
+        }
+        int run = wave_inclusive_scan(sum) - sum;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int b = tid * PER + q;
+            if (b < GI2D_ORDER_BINS) hist[b] = run;
+            run += v[q];
+        }
+    }
+    __syncthreads();
+    const int full_rounds = num_tiles / GI2D_CU_SLOTS;
+#pragma unroll
+    for (int q = 0; q < PL; ++q) {
+        const int t = tid + q * bs;
+        if (t >= num_tiles) continue;
+        const int rank = atomicAdd(&hist[GI2D_ORDER_BINS - 1 - pop[q]], 1);  // ties: any order
+        const int round = rank / GI2D_CU_SLOTS, pos = rank % GI2D_CU_SLOTS;
+        const int slot = (round < full_rounds && (round & 1)) ? GI2D_CU_SLOTS - 1 - pos : pos;
+        tile_order[round * GI2D_CU_SLOTS + slot] = t;
+    }
 }
 
 // acc[11] <- ordered sum of gaussian g's partial rows.  Must be called by whole waves.

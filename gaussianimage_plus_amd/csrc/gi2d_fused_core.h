@@ -26,10 +26,17 @@ __device__ unsigned long long *g_fused_trace = nullptr;  // [tiles][16]
         if (threadIdx.x == 0 && g_fused_trace) g_fused_trace[(wg) * 16 + (i)] = wall_clock64();     \
     } while (0)
 #define GI2D_TRACE(i) GI2D_TRACE_AT(tile, i)
+#define GI2D_TRACE_VALUE(i, v)                                                        \
+    do {                                                                              \
+        if (threadIdx.x == 0 && g_fused_trace) g_fused_trace[tile * 16 + (i)] = (v);  \
+    } while (0)
 #define GI2D_BWD_TRACE(i) GI2D_TRACE_AT(blockIdx.x, i)
 #else
 #define GI2D_TRACE(i) \
     do {              \
+    } while (0)
+#define GI2D_TRACE_VALUE(i, v) \
+    do {                       \
     } while (0)
 #endif
 
@@ -123,6 +130,9 @@ __device__ __forceinline__ void fused_tile(
     GI2D_TRACE(1);
     const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
+    GI2D_TRACE_VALUE(11, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID
+    GI2D_TRACE_VALUE(12, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));  // HW_REG_XCC_ID
+    GI2D_TRACE_VALUE(13, (unsigned long long)L);
     int my_id[GI2D_FAST_EPT];
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {

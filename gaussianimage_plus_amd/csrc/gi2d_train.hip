@@ -103,7 +103,7 @@ __device__ __forceinline__ float adam(float p, float g, float &m, float &v, cons
 // begins with its tile pass -- one launch and one parameter round trip less per iteration.
 struct NextFill {
     float clip_coe;
-    int32_t *num_tiles_hit, *cursors, *buckets, *status;
+    int32_t *num_tiles_hit, *cursors, *buckets, *status, *tile_order;
 };
 
 // optimizer.py::_multi_tensor_adan / _single_tensor_adan (weight_decay 0, no gradient clipping), operation by
@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
 #pragma clang fp contract(off)
+    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next iteration's tile order (gi2d_fast_internal.h)
+        compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);
+        return;
+    }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     // Is the render of THIS step (made with the pre-update parameters) the best so far?  Every workgroup sums
     // the per-tile squared errors in the same fixed order, so all take the same decision without a host round trip.
@@ -392,8 +396,9 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     next.cursors = w.cursors;
     next.buckets = w.buckets;
     next.status = s->status;
+    next.tile_order = w.tile_order;
     const int bs = per_gaussian_block(n);
-    const dim3 gg((n + bs - 1) / bs), bb(bs);
+    const dim3 gg((n + bs - 1) / bs + 1), bb(bs);  // + 1: the workgroup that orders the tiles
     train_launch_project_fill(s, w, P, tx, ty, st);
     for (int it = 0; it < count; ++it) {
         const int step = first_step + it;

@@ -27,7 +27,8 @@ assert lib.gi2d_debug_set_trace(trace.data_ptr()) == 0
 for _ in range(20):
     hp.step()
 torch.cuda.synchronize()
-t = trace.cpu().numpy().astype(np.float64)[:, :11] * 0.01  # 100 MHz ticks -> us
+raw = trace.cpu().numpy()
+t = raw.astype(np.float64)[:, :11] * 0.01  # 100 MHz ticks -> us
 t -= t[:, 0].min()
 names = ["start", "cursors", "ids", "staged", "lists", "fwd loop", "pixel out", "bwd items", "bwd lane0", "bwd handoff", "bwd done"]
 print(f"N={n} M={hp.num_intersects()} tiles={hp.T}   (us since the first workgroup started)")
@@ -39,3 +40,29 @@ for i, nm in enumerate(names):
           f"{np.percentile(d, 50):8.2f} {np.percentile(d, 90):8.2f} {d.max():8.2f}")
 late = t[:, 0] > 3.0
 print(f"workgroups starting later than 3 us: {int(late.sum())}")
+
+# placement: which workgroups shared a CU, and does the CU's total tile population explain who finishes last?
+hw, xcc, pop = raw[:, 11], raw[:, 12] & 0xf, raw[:, 13]
+cu_key = (xcc << 16) | (hw & 0xff00)  # XCC, SE/SH/CU fields of HW_ID
+end = t[:, 10]
+keys, inv = np.unique(cu_key, return_inverse=True)
+per_cu_n = np.bincount(inv)
+per_cu_pop = np.bincount(inv, weights=pop)
+per_cu_end = np.array([end[inv == i].max() for i in range(len(keys))])
+print(f"distinct CU keys: {len(keys)}, workgroups per CU min/max {per_cu_n.min()}/{per_cu_n.max()}")
+print(f"tile population: mean {pop.mean():.1f} max {pop.max()}; per-CU sum mean {per_cu_pop.mean():.0f} max {per_cu_pop.max():.0f}")
+print(f"corr(CU population sum, CU finish time) = {np.corrcoef(per_cu_pop, per_cu_end)[0, 1]:.2f};  "
+      f"corr(tile population, workgroup finish) = {np.corrcoef(pop, end)[0, 1]:.2f}")
+order = np.argsort(per_cu_end)
+print("slowest CUs: finish", np.round(per_cu_end[order[-5:]], 1), "population", per_cu_pop[order[-5:]], "n", per_cu_n[order[-5:]])
+print("fastest CUs: finish", np.round(per_cu_end[order[:5]], 1), "population", per_cu_pop[order[:5]], "n", per_cu_n[order[:5]])
+blk = np.arange(hp.T)
+same = [len(np.unique(blk[inv == i] % 8)) for i in range(len(keys))]
+print("blockIdx % 8 values per CU (1 = all workgroups of a CU share the residue):", np.bincount(same))
+for i in order[:3]:
+    print("blocks on one CU:", sorted(blk[inv == i].tolist()))
+d = np.diff(np.sort(blk[inv == order[0]]))
+print("block-index strides on that CU:", d.tolist())
+stride_sets = [tuple(np.diff(np.sort(blk[inv == i])).tolist()) for i in range(len(keys))]
+import collections
+print("most common stride patterns:", collections.Counter(stride_sets).most_common(4))
