@@ -8,6 +8,9 @@ i.e. the work one training iteration of models/gaussianimage_cholesky.py:302-317
 operator surface, with the gradient image derived from the step's own render exactly as loss.backward() does
 (clamp + MSE against a fixed synthetic target).  tanh / +bound / the optimizer are not part of the metric
 (BASELINE.json: "training iters/sec (fwd+bwd rasterize)"); they are in the separate `train_step` figure.
+In the timed loop a step is two launches, as in the training loop: the tile pass, then one kernel that finishes the
+step (gradient reduce + project backward) and projects + bins the gaussians for the next one (HotPath.step); every
+timed step contains exactly one of each operation.
 
 N GPUs: one process per GPU, one independent image per rank (images shard embarrassingly,
 no data-path collective) -> weak scaling; value = ranks * K / max-over-ranks time.

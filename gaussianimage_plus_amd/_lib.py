@@ -50,6 +50,8 @@ SIGNATURES.update({
     "gi2d_fast_rasterize_backward_reduce": [_i, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p, _p],
     "gi2d_fast_reduce_project_backward": [_i, _i, _p, _p, _u, _u, _p, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p,
                                           _p, _p, _p, _p, _p],
+    "gi2d_fast_reduce_project_backward_project_bin": [_i, _i, _f, _p, _p, _p, _u, _u, _p, _p, _p, _p, _p, _i, _i, _f, _p,
+                                                      _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_fast_tile_capacity": [],
     "gi2d_timer_create": [_p], "gi2d_timer_destroy": [_p], "gi2d_timer_arm": [_p], "gi2d_timer_elapsed_us": [_p, _p],
     # struct gi2d_train_state* (gaussianimage_plus_amd/trainer.py::_TrainState)

@@ -48,14 +48,13 @@ __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__r
     fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
 }
 
+// projection of gaussian g + its bucket fill (g == 0 also resets the per-call status words)
 template <int KIND>
-__global__ __launch_bounds__(256) void fast_project_fill_kernel(
-    int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
-    const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
-    float2 *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
-    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors,
-    int32_t *__restrict__ buckets, int32_t *__restrict__ status) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void project_fill_one(
+    int g, int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
+    const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip, float2 *xys,
+    float *__restrict__ depths, int32_t *radii, float *conics, int32_t *__restrict__ num_tiles_hit,
+    int32_t *__restrict__ cursors, int32_t *__restrict__ buckets, int32_t *__restrict__ status) {
     if (g == 0) {
         status[0] = 0;
         status[1] = 0;
@@ -77,6 +76,17 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
         tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
         fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
     }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void fast_project_fill_kernel(
+    int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
+    const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
+    float2 *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors,
+    int32_t *__restrict__ buckets, int32_t *__restrict__ status) {
+    project_fill_one<KIND>(blockIdx.x * blockDim.x + threadIdx.x, n, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x,
+                           tiles_y, radius_clip, xys, depths, radii, conics, num_tiles_hit, cursors, buckets, status);
 }
 
 // -------------------------------------------------------------------------------------- forward
@@ -254,15 +264,24 @@ __global__ __launch_bounds__(256) void fast_reduce_kernel(
     if (g < n) store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
 }
 
-template <int KIND>
+// What the reduce kernel needs to project and bin the gaussians for the NEXT step of a loop over unchanged or
+// caller-updated inputs (FILL_NEXT): the step then starts directly with its tile pass.
+struct NextProject {
+    float clip_coe;
+    const float2 *means2d;
+    float *depths;
+    int32_t *num_tiles_hit, *cursors, *buckets, *status;
+};
+
+template <int KIND, bool FILL_NEXT>
 __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
-    int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, const float *__restrict__ conics,
-    int tiles_x, int tiles_y, float radius_clip, const int32_t *__restrict__ gids_sorted,
-    const int2 *__restrict__ tile_bins, const float4 *__restrict__ partial_g,
-    const float4 *__restrict__ partial_big, const float *__restrict__ p0, const float *__restrict__ p1,
-    float img_w, float img_h, float2 *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_rgb,
-    float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy, float *__restrict__ v_cov2d,
-    float2 *__restrict__ v_mean2d, float *__restrict__ v_p0, float *__restrict__ v_p1) {
+    int n, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
+    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, const float *__restrict__ p0,
+    const float *__restrict__ p1, float img_w, float img_h, float2 *__restrict__ v_xy, float *__restrict__ v_conic,
+    float *__restrict__ v_rgb, float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy,
+    float *__restrict__ v_cov2d, float2 *__restrict__ v_mean2d, float *__restrict__ v_p0, float *__restrict__ v_p1,
+    NextProject next) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float acc[11];
     reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
@@ -278,6 +297,10 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
         r = project_bwd_one<KIND>(g, p0, p1, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
     }
     store_proj_grad(g, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
+    if (FILL_NEXT)
+        project_fill_one<KIND>(g, n, next.clip_coe, next.means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip,
+                               xys, next.depths, radii, conics, next.num_tiles_hit, next.cursors, next.buckets,
+                               next.status);
 }
 
 static int check_ws(const char *what, void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y) {
@@ -531,12 +554,11 @@ int gi2d_fast_rasterize_backward_reduce(int n, const float *xys, const int32_t *
     return check_launch("fast rasterize backward reduce");
 }
 
-int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const float *p1, unsigned h, unsigned w_,
-                                      const float *xys, const int32_t *radii, const float *conics, int tiles_x,
-                                      int tiles_y, float radius_clip, void *ws, size_t ws_bytes, float *v_xy,
-                                      float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
-                                      float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
-                                      gi2d_stream_t st) {
+static int reduce_project_impl(int kind, int n, const float *p0, const float *p1, unsigned h, unsigned w_, float *xys,
+                               int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip, void *ws,
+                               size_t ws_bytes, float *v_xy, float *v_conic, float *v_rgb, float *v_opacity,
+                               float *v_abs_xy, float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
+                               const NextProject *next, gi2d_stream_t st) {
     int rc = check_ws("fast reduce+project backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     if (n == 0) return GI2D_OK;
@@ -546,21 +568,71 @@ int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const fl
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    NextProject np;
+    np.clip_coe = 0.f;
+    np.means2d = nullptr;
+    np.depths = nullptr;
+    np.num_tiles_hit = np.status = nullptr;
+    if (next) np = *next;
+    np.cursors = w.cursors;
+    np.buckets = w.buckets;
     const int bs = per_gaussian_block(n);
     const dim3 grid((n + bs - 1) / bs), block(bs);
-#define GI2D_LAUNCH_RP(K)                                                                                      \
-    hipLaunchKernelGGL(fast_reduce_project_kernel<K>, grid, block, 0, (hipStream_t)st, n, (const float2 *)xys, \
-                       radii, conics, tiles_x, tiles_y, radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, \
-                       w.partial_g, w.partial_big, p0, p1, (float)w_, (float)h, (float2 *)v_xy, v_conic, v_rgb, \
-                       v_opacity, (float4 *)v_abs_xy, v_cov2d, (float2 *)v_mean2d, v_p0, v_p1)
+#define GI2D_LAUNCH_RP(K, F)                                                                                        \
+    hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, (float2 *)xys, radii, \
+                       conics, tiles_x, tiles_y, radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g, \
+                       w.partial_big, p0, p1, (float)w_, (float)h, (float2 *)v_xy, v_conic, v_rgb, v_opacity,        \
+                       (float4 *)v_abs_xy, v_cov2d, (float2 *)v_mean2d, v_p0, v_p1, np)
+#define GI2D_LAUNCH_RP2(K)           \
+    do {                             \
+        if (next)                    \
+            GI2D_LAUNCH_RP(K, true); \
+        else                         \
+            GI2D_LAUNCH_RP(K, false); \
+    } while (0)
     if (kind == 0)
-        GI2D_LAUNCH_RP(kCholesky);
+        GI2D_LAUNCH_RP2(kCholesky);
     else if (kind == 1)
-        GI2D_LAUNCH_RP(kCovariance);
+        GI2D_LAUNCH_RP2(kCovariance);
     else
-        GI2D_LAUNCH_RP(kScaleRot);
+        GI2D_LAUNCH_RP2(kScaleRot);
+#undef GI2D_LAUNCH_RP2
 #undef GI2D_LAUNCH_RP
     return check_launch("fast reduce+project backward");
+}
+
+int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const float *p1, unsigned h, unsigned w_,
+                                      const float *xys, const int32_t *radii, const float *conics, int tiles_x,
+                                      int tiles_y, float radius_clip, void *ws, size_t ws_bytes, float *v_xy,
+                                      float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                      float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
+                                      gi2d_stream_t st) {
+    return reduce_project_impl(kind, n, p0, p1, h, w_, (float *)xys, (int32_t *)radii, (float *)conics, tiles_x, tiles_y,
+                               radius_clip, ws, ws_bytes, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy, v_cov2d, v_mean2d,
+                               v_p0, v_p1, nullptr, st);
+}
+
+int gi2d_fast_reduce_project_backward_project_bin(int kind, int n, float clip_coe, const float *means2d,
+                                                  const float *p0, const float *p1, unsigned h, unsigned w_,
+                                                  float *xys, float *depths, int32_t *radii, float *conics,
+                                                  int32_t *nth, int tiles_x, int tiles_y, float radius_clip,
+                                                  void *ws, size_t ws_bytes, int32_t *status, float *v_xy,
+                                                  float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                                  float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
+                                                  gi2d_stream_t st) {
+    if (n > 0 && (!means2d || !depths || !nth || !status)) {
+        set_error("fast reduce+project backward + project+bin: null pointer");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    NextProject np;
+    np.clip_coe = clip_coe;
+    np.means2d = (const float2 *)means2d;
+    np.depths = depths;
+    np.num_tiles_hit = nth;
+    np.status = status;
+    np.cursors = np.buckets = nullptr;
+    return reduce_project_impl(kind, n, p0, p1, h, w_, xys, radii, conics, tiles_x, tiles_y, radius_clip, ws, ws_bytes,
+                               v_xy, v_conic, v_rgb, v_opacity, v_abs_xy, v_cov2d, v_mean2d, v_p0, v_p1, &np, st);
 }
 
 #ifdef GI2D_FUSED_TRACE

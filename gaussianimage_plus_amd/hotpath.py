@@ -5,10 +5,14 @@ issues the C-ABI calls with pre-built argument lists, so one step costs four nat
 nothing else: no allocation, no host read-back, nothing but kernel launches on the current HIP stream
 (so a step can be captured into a hipGraph: `capture_graph()`).
 
-  mode "fused" (default) -- the fast path (csrc/gi2d_fast.hip), 3 launches per step():
-      gi2d_fast_project_bin -> gi2d_fast_rasterize_forward_backward (one tile pass for both directions)
-      -> gi2d_fast_reduce_project_backward
-    (forward() / backward() called separately use gi2d_fast_rasterize_forward / _backward_tiles)
+  mode "fused" (default) -- the fast path (csrc/gi2d_fast.hip).  step() in a loop is TWO launches:
+      gi2d_fast_rasterize_forward_backward (one tile pass for both directions)
+      -> gi2d_fast_reduce_project_backward_project_bin (ends this step AND projects + bins for the next one,
+         from the inputs as they are at that moment -- the shape of a training loop, where the optimizer update
+         sits in the same place: trainer.py);
+    the first step after construction / set_inputs() is preceded by a stand-alone gi2d_fast_project_bin.
+    (forward() / backward() called separately use gi2d_fast_rasterize_forward / _backward_tiles; step(pipelined=
+    False) issues the three calls project+bin, tile pass, reduce+project backward.)
   mode "exact" -- the capacity-free ops (any tile population):
       gi2d_project_*_forward -> gi2d_bin_gaussians -> gi2d_rasterize_sum_forward
       -> gi2d_rasterize_backward_tiles -> gi2d_rasterize_backward_reduce -> gi2d_project_*_backward
@@ -72,6 +76,7 @@ class HotPath:
         self.capacity = 0
         self._exact_ready = False
         self._graph = None
+        self._binned = False  # the workspace's buckets already hold the projection of the current inputs
         self._build_fused_calls()
 
     # ------------------------------------------------------------------ call lists
@@ -96,6 +101,11 @@ class HotPath:
                          p(self.status), p(self.out_img)])
         self._f_tiles = (L.gi2d_fast_rasterize_backward_tiles, "fast rasterize backward tiles",
                          [n, tx, ty, w, h, None, p(self.v_out), 0, ws, wsb])
+        self._f_red_next = (L.gi2d_fast_reduce_project_backward_project_bin, "fast reduce+project backward + project+bin",
+                            [k, n, self.clip_coe, p(self.means), p(self.params), rot, h, w, p(self.xys), p(self.depths),
+                             p(self.radii), p(self.conics), p(self.nth), tx, ty, self.radius_clip, ws, wsb,
+                             p(self.status), p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,
+                             p(self.v_cov2d), p(self.v_mean2d), p(self.v_params), v_rot])
         self._f_red = (L.gi2d_fast_reduce_project_backward, "fast reduce+project backward",
                        [k, n, p(self.params), rot, h, w, p(self.xys), p(self.radii), p(self.conics), tx, ty,
                         self.radius_clip, ws, wsb, p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,
@@ -160,6 +170,16 @@ class HotPath:
             pairs.append((self.rot, rot))
         for dst, src in pairs:
             dst.copy_(torch.as_tensor(np.ascontiguousarray(src) if isinstance(src, np.ndarray) else src).to(self.dev))
+        self._drop_bins()
+
+    def _drop_bins(self):
+        self._graph = None  # a captured step assumes the buckets it left behind
+        """Buckets filled ahead for inputs that have changed meanwhile: empty them (cursors back to zero)."""
+        if self._binned:
+            with torch.cuda.device(self.dev):
+                _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), self.ws.numel(), self.n, self.tx, self.ty,
+                          self._stream())
+            self._binned = False
 
     def set_v_out(self, v_out: torch.Tensor):
         """Use a fixed gradient image dL/d(out_img) [H,W,3]."""
@@ -188,8 +208,10 @@ class HotPath:
         st = self._stream()
         with torch.cuda.device(self.dev):
             if self.mode == "fused":
-                self._run(self._f_bin, st)
+                if not self._binned:
+                    self._run(self._f_bin, st)
                 self._run(self._f_fwd, st)
+                self._binned = False  # the tile kernel consumed the buckets
             else:
                 self._exact_forward(st)
         return self.out_img
@@ -221,15 +243,21 @@ class HotPath:
                 for c in self._e_rest:
                     self._run(c, st)
 
-    def step(self, timer=None, index: int = 0):
+    def step(self, timer=None, index: int = 0, pipelined: bool = True):
         st = self._stream()
         with torch.cuda.device(self.dev):
             if self.mode == "fused":
-                self._run(self._f_bin, st)
+                if not self._binned:
+                    self._run(self._f_bin, st)
                 if timer is not None:  # start/stop events ride on the tile-pass dispatch itself
                     self.lib.gi2d_timer_arm(timer["rast"][index])
                 self._run(self._f_both, st)
-                self._run(self._f_red, st)
+                if pipelined:  # finish this step and project + bin for the next one in the same launch
+                    self._run(self._f_red_next, st)
+                    self._binned = True
+                else:
+                    self._run(self._f_red, st)
+                    self._binned = False
                 return
             else:
                 if not self._exact_ready:
@@ -244,8 +272,9 @@ class HotPath:
         self.backward(timer, index)
 
     def step_safe(self):
-        """One step with the overflow check the fused path needs (host read-back of 8 bytes)."""
-        self.step()
+        """One step with the overflow check the fused path needs (host read-back of 8 bytes); not pipelined, so
+        the flag of this step's tile pass is still there to read."""
+        self.step(pipelined=False)
         if self.mode == "fused" and self.status[1].item():
             self.mode = "exact"
             try:
@@ -277,7 +306,12 @@ class HotPath:
         return int(self.nth.sum().item())
 
     def check_status(self):
-        m, overflow = self.num_intersects(), int(self.status[1].item())
+        # status[2] is the sticky copy of the overflow flag: status[1] is reset by every project+bin, which in the
+        # pipelined step runs BEHIND the tile pass that may have raised it
+        m = self.num_intersects()
+        now, sticky = self.status[1:3].tolist()
+        self.status[2] = 0
+        overflow = int(bool(now or sticky))
         if overflow:
             what = "a tile bucket" if self.mode == "fused" else f"the intersection capacity {self.capacity}"
             raise RuntimeError(f"{what} overflowed (M={m}); results of the last step are invalid")
@@ -340,6 +374,7 @@ class HotPath:
 
     def describe(self) -> str:
         if self.mode == "fused":
-            return ("HotPath[fused]: 3 C-ABI calls/step (project+bin, rasterize fwd+bwd tile pass, reduce+project bwd) on "
+            return ("HotPath[fused]: 2 C-ABI calls/step in a loop (rasterize fwd+bwd tile pass; reduce+project bwd of this "
+                    "step fused with project+bin of the next) on "
                     "persistent HBM buffers, eager launches on the current HIP stream")
         return f"HotPath[exact]: 6 C-ABI calls/step, intersection capacity {self.capacity}"

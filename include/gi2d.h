@@ -307,6 +307,19 @@ int gi2d_fast_reduce_project_backward(int kind, int num_points, const float *p0,
                                       float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
                                       gi2d_stream_t stream);
 
+/* The call that ends step i of a loop can also start step i+1: reduce + projection backward of the
+ * gradients just produced, then projection + bucket fill (gi2d_fast_project_bin) of the same gaussians
+ * from means2d / p0 / p1 as they are NOW, in one launch -- xys / radii / conics / num_tiles_hit are
+ * overwritten with the new projection after the backward has consumed the old one, and the next
+ * gi2d_fast_rasterize_forward[_backward] finds its buckets filled.  A caller that then changes the
+ * inputs or wants to bin again must first restore the cursors with gi2d_fast_workspace_init. */
+int gi2d_fast_reduce_project_backward_project_bin(
+    int kind, int num_points, float clip_coe, const float *means2d, const float *p0, const float *p1,
+    unsigned img_height, unsigned img_width, float *xys, float *depths, int32_t *radii, float *conics,
+    int32_t *num_tiles_hit, int tiles_x, int tiles_y, float radius_clip, void *workspace,
+    size_t workspace_bytes, int32_t *status, float *v_xy, float *v_conic, float *v_rgb, float *v_opacity,
+    float *v_abs_xy, float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1, gi2d_stream_t stream);
+
 /* Kernel timer for measurement code: an armed timer attaches start/stop events to the NEXT
  * gi2d_fast_rasterize_forward_backward launch issued by the calling thread (hipExtLaunchKernelGGL), so
  * gi2d_timer_elapsed_us returns that kernel's own execution time -- the figure rocprofv3's kernel
