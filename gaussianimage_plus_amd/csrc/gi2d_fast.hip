@@ -271,6 +271,8 @@ struct NextProject {
     const float2 *means2d;
     float *depths;
     int32_t *num_tiles_hit, *cursors, *buckets, *status;
+    int32_t *tile_order;  // non-null: one extra workgroup re-balances the next tile pass (large populations only,
+                          // where this kernel is long enough to hide it)
 };
 
 template <int KIND, bool FILL_NEXT>
@@ -282,6 +284,10 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     float *__restrict__ v_rgb, float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy,
     float *__restrict__ v_cov2d, float2 *__restrict__ v_mean2d, float *__restrict__ v_p0, float *__restrict__ v_p1,
     NextProject next) {
+    if (FILL_NEXT && next.tile_order != nullptr && blockIdx.x == gridDim.x - 1) {
+        compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);  // the extra workgroup (see there)
+        return;
+    }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float acc[11];
     reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
@@ -572,12 +578,13 @@ static int reduce_project_impl(int kind, int n, const float *p0, const float *p1
     np.clip_coe = 0.f;
     np.means2d = nullptr;
     np.depths = nullptr;
-    np.num_tiles_hit = np.status = nullptr;
+    np.num_tiles_hit = np.status = np.tile_order = nullptr;
     if (next) np = *next;
     np.cursors = w.cursors;
     np.buckets = w.buckets;
     const int bs = per_gaussian_block(n);
-    const dim3 grid((n + bs - 1) / bs), block(bs);
+    np.tile_order = (next && bs == 256) ? w.tile_order : nullptr;
+    const dim3 grid((n + bs - 1) / bs + (np.tile_order ? 1 : 0)), block(bs);
 #define GI2D_LAUNCH_RP(K, F)                                                                                        \
     hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, (float2 *)xys, radii, \
                        conics, tiles_x, tiles_y, radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g, \

@@ -109,9 +109,9 @@ __device__ __forceinline__ int partial_slot(int g, const float2 xy, int rad, int
 // workgroups -- sorts the tiles by the population the tile pass has just seen (counting sort, descending) and deals
 // them to workgroup indices in snake order over the 256 CU slots, for the NEXT iteration's tile pass (populations
 // drift slowly during training).  Any permutation gives the same results; placement is a pure speed choice
-// (dispatch order is undefined by contract).  Measured: training iteration at N=50 000 50.2 -> 44.6 us.  It is not
-// attached to the plain reduce+project kernel: its LDS histogram atomics (many lanes per bin) take ~5 us, longer
-// than that kernel, and the synthetic uniform scene of bench.py gains only 0.8 us in the tile pass.
+// (dispatch order is undefined by contract).  Measured: training iteration at N=50 000 50.2 -> 44.6 us; hot-path
+// step 38.3 -> 37.0 us.  Its LDS histogram atomics (many lanes per bin) take ~5 us, so it only rides on kernels that
+// are longer than that (the training update kernel; the end-of-step kernel above 32k gaussians).
 #define GI2D_ORDER_BINS 1025 /* populations 0 .. GI2D_FAST_C */
 #define GI2D_CU_SLOTS 256
 #define GI2D_ORDER_MAX_TILES 2048 /* larger grids run in several rounds of resident workgroups and balance themselves */
