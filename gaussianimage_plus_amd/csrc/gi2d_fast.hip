@@ -93,12 +93,8 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
 struct FastFwdLds {
     FwdLds f;
     int cnt[GI2D_FAST_SUB];
-    union {  // the id sort buffer is dead once the records are staged
-        int ids[GI2D_FAST_C];
-        float4 soa[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats: pair-interleaved copy of 64 list entries,
-                                       // afterwards the RGB transpose stage
-    };
 };
+static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id sort buffer overlays the pair buffers");
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
@@ -109,6 +105,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     int32_t *__restrict__ status, float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
     float *__restrict__ out_img) {
     __shared__ FastFwdLds sm;
+    int *ids = reinterpret_cast<int *>(sm.f.pairbuf);  // id sort buffer: dead before the pair buffers are first written
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
             const int sub = (e >= c0) + (e >= c1) + (e >= c2);
             const int off = e - (sub == 0 ? 0 : (sub == 1 ? c0 : (sub == 2 ? c1 : c2)));
             my_id[u] = buckets[(tile * GI2D_FAST_SUB + sub) * GI2D_FAST_CSUB + off];
-            sm.ids[e] = my_id[u];
+            ids[e] = my_id[u];
         }
     }
     __syncthreads();
@@ -148,13 +145,13 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         GaussRec r = load_gaussian(g, xys, conics, colors, opacities);
         const int rad = radii[g];
         int rank = 0;
-        for (int j = 0; j < L; ++j) rank += (sm.ids[j] < g) ? 1 : 0;
+        for (int j = 0; j < L; ++j) rank += (ids[j] < g) ? 1 : 0;
         gids_sorted[tile * GI2D_FAST_C + rank] = g;
         const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
         const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
         if (rank < GI2D_TILE_LIST_CAP) {
             const unsigned mask = cull_word(r, tx0, ty0, img_h);
-            fwd_stage_entry(sm.f, rank, r, mask & 15u);
+            fwd_stage_entry(sm.f, rank, r, mask);
             float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
             dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
             dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
@@ -175,11 +172,10 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     // fix-up kernel for that corner case.
     if (final_idx)
         fwd_rasterize_staged<true>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
-                                   final_Ts, final_idx, out_img, reinterpret_cast<float *>(sm.soa));
+                                   final_Ts, final_idx, out_img);
     else
         fwd_rasterize_staged<false>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
-                                    final_Ts, final_idx, out_img, reinterpret_cast<float *>(sm.soa),
-                                    reinterpret_cast<float *>(sm.soa));
+                                    final_Ts, final_idx, out_img);
     if (tid == 0 && L > 0) status[0] = 1;
 }
 

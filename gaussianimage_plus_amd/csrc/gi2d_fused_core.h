@@ -67,9 +67,8 @@ struct FusedLds {
             int ids[GI2D_FAST_C];
         };
         struct {  // forward phase
-            unsigned short list[4][GI2D_TILE_LIST_CAP + 8];
-            float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats; re-used as the RGB transpose stage
-            int gid_by_rank[GI2D_TILE_LIST_CAP];  // ids in list order (beyond `ids`): leave as whole-line stores
+            unsigned char lists[4][2 * GI2D_FWD_LISTLEN];  // per wave: left-half list, right-half list
+            float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats; afterwards the RGB transpose stage
         };
         struct {  // backward phase (member names as BwdLds: bwd_run_tile is shared)
             float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];
@@ -87,6 +86,17 @@ struct FusedLds {
 // MODE 1: `vsrc` is the target image gt[H,W,3]; the pixel gradient is that of mean((clamp(out,0,1) - gt)^2):
 //         grad_scale * (clamp(out) - gt) where the clamp passes gradient (models/gaussianimage_cholesky.py:307-310
 //         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
+// ids in list order, kept until they leave as whole-line stores: entry k sits in the last 64 words of the (not yet
+// used) pair buffer of the wave that will read it -- no wave can overwrite what another one still has to read, and
+// even wave 0's slots lie beyond the id sort buffer that is still being read while they are written
+__device__ __forceinline__ int *gid_slot(FusedLds &sm, int k) {
+    return reinterpret_cast<int *>(reinterpret_cast<float *>(sm.pairbuf) + (k >> 6) * GI2D_FWD_PAIRBUF +
+                                   (GI2D_FWD_PAIRBUF - 64)) + (k & 63);
+}
+static_assert(sizeof(unsigned char) * 4 * 2 * GI2D_FWD_LISTLEN + sizeof(float) * (GI2D_FWD_PAIRBUF - 64) >=
+                  sizeof(int) * GI2D_FAST_C,
+              "gid slots of wave 0 must lie beyond the id sort buffer");
+
 template <int MODE>
 __device__ __forceinline__ void fused_tile(
     FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
@@ -159,7 +169,7 @@ __device__ __forceinline__ void fused_tile(
         const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
         const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
         if (rank < GI2D_TILE_LIST_CAP) {
-            sm.gid_by_rank[rank] = g;
+            *gid_slot(sm, rank) = g;
             sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
             sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
             sm.gCb[rank] = r.cb;
@@ -176,92 +186,27 @@ __device__ __forceinline__ void fused_tile(
     __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     // the tile's ascending id list (only its first 256 entries are ever looked up: find_in_tile), contiguous
-    if (tid < len) gids_sorted[tile * GI2D_FAST_C + tid] = sm.gid_by_rank[tid];
+    if (tid < len) gids_sorted[tile * GI2D_FAST_C + tid] = *gid_slot(sm, tid);
     GI2D_TRACE(3);
 
-    // ---- forward: per-wave list of the entries that reach this wave's 4-row strip, then the packed pair loop
-    // (same arithmetic, same order as fwd_rasterize_staged's packed form: bitwise identical pixels)
-    unsigned short *mylist = sm.list[wv];
-    int cnt = 0;
-    for (int base = 0; base < len; base += 64) {
-        const int k = base + lane;
-        const bool take = (k < len) && ((sm.cullw[k] >> wv) & 1u);
-        const unsigned long long m = __ballot(take);
-        if (take) mylist[cnt + __popcll(m & lanemask_lt())] = (unsigned short)k;
-        cnt += __popcll(m);
-    }
-    __builtin_amdgcn_wave_barrier();
-    GI2D_TRACE(4);
+    // ---- forward (the routine every forward kernel shares: gi2d_raster_core.h::fwd_pixel_half_lists)
     float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF;
-    const float px = (float)j, py = (float)i;
-    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
-    const v2f px2 = {px, px}, py2 = {py, py};
-    for (int e0 = 0; e0 < cnt; e0 += 64) {
-        {
-            const int e = e0 + lane;
-            const int k = e < cnt ? (int)mylist[e] : GI2D_TILE_LIST_CAP;
+    float o0, o1, o2;
+    int last_unused;
+    GI2D_TRACE(4);
+    fwd_pixel_half_lists<false>(
+        sm.lists[wv], mybuf, len, [&](int k) { return sm.cullw[k]; },
+        [&](int k) {
             const float4 A = sm.gA[k], B = sm.gB[k];
-            const float cb = sm.gCb[k];
-            const ConicS s = scale_conic(A.z, A.w, B.x);
-            float *w = mybuf + (lane >> 1) * 20 + (lane & 1);
-            w[0] = A.x;
-            w[2] = A.y;
-            w[4] = s.ha;
-            w[6] = s.hb;
-            w[8] = s.hc;
-            w[10] = B.y;
-            w[12] = B.z;
-            w[14] = B.w;
-            w[16] = cb;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int m = min(64, cnt - e0);
-        for (int t = 0; t < m; t += 2) {
-            const float4 *q = reinterpret_cast<const float4 *>(mybuf + t * 10);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
-            const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
-            const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
-            const v2f dx = gx - px2, dy = gy - py2;
-            const v2f bdy = hb * dy, cdy2 = hc * dy * dy;
-            const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
-            const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
-            const v2f tt = op * vis;
-            const v2f alpha = {fminf(1.f, tt.x), fminf(1.f, tt.y)};
-            const bool ok0 = !(sig.x < 0.f || alpha.x < GI2D_ALPHA_MIN);
-            const bool ok1 = !(sig.y < 0.f || alpha.y < GI2D_ALPHA_MIN);
-            const v2f am = {ok0 ? alpha.x : 0.f, ok1 ? alpha.y : 0.f};
-            a0 = __builtin_elementwise_fma(cr, am, a0);
-            a1 = __builtin_elementwise_fma(cg, am, a1);
-            a2 = __builtin_elementwise_fma(cb, am, a2);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    const float o0 = a0.x + a0.y, o1 = a1.x + a1.y, o2 = a2.x + a2.y;
+            const ConicS cs = scale_conic(A.z, A.w, B.x);
+            FwdRec r;
+            r.gx = A.x, r.gy = A.y, r.ha = cs.ha, r.hb = cs.hb, r.hc = cs.hc, r.op = B.y, r.cr = B.z, r.cg = B.w;
+            r.cb = sm.gCb[k];
+            return r;
+        },
+        (float)j, (float)i, o0, o1, o2, last_unused);
     GI2D_TRACE(5);
-
-    // image out: transpose RGB through the wave's (now idle) pair buffer, 12 x 16-byte stores per pixel row
-    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
-    if (full_tile) {
-        const int r = lane >> 4;
-        mybuf[r * 48 + lx * 3 + 0] = o0;
-        mybuf[r * 48 + lx * 3 + 1] = o1;
-        mybuf[r * 48 + lx * 3 + 2] = o2;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 48) {
-            const int rr = lane / 12, q = lane % 12;
-            const int ii = ty * GI2D_TILE + wv * 4 + rr;
-            if (ii < img_h) {
-                const float4 v = reinterpret_cast<const float4 *>(mybuf)[rr * 12 + q];
-                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
-                dst[q] = v;
-            }
-        }
-    } else if (inside) {
-        out_img[3 * pix + 0] = o0;
-        out_img[3 * pix + 1] = o1;
-        out_img[3 * pix + 2] = o2;
-    }
+    fwd_store_pixels(mybuf, o0, o1, o2, tx, ty, img_w, img_h, out_img);
 
     // ---- this pixel's gradient
     float v0 = p0, v1 = p1, v2 = p2, sse = 0.f;

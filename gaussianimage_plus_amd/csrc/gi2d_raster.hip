@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     const int32_t *__restrict__ num_intersects_dev, float *__restrict__ final_Ts,
     int32_t *__restrict__ final_idx, float *__restrict__ out_img) {
     __shared__ FwdLds sm;
-    __shared__ float stage[4 * GI2D_FWD_STAGE];
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
@@ -50,12 +49,12 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     // dependent global loads), and records which 4-row strips each gaussian can reach
     if (tid < len) {
         const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
-        fwd_stage_entry(sm, tid, r, cull_word(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h) & 15u);
+        fwd_stage_entry(sm, tid, r, cull_word(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h));
     }
     if (tid == 0) fwd_stage_dummy(sm);
     __syncthreads();
     const bool bg = (num_intersects_dev != nullptr) && (*num_intersects_dev < 1);
-    fwd_rasterize_staged(sm, len, range.x, tx, ty, img_w, img_h, bg, background, final_Ts, final_idx, out_img, stage);
+    fwd_rasterize_staged(sm, len, range.x, tx, ty, img_w, img_h, bg, background, final_Ts, final_idx, out_img);
 }
 
 // ----------------------------------------------------------------------------------- backward

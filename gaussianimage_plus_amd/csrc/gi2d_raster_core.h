@@ -60,23 +60,160 @@ __device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, floa
 }
 
 // =========================================================================================== forward
+// One lane per pixel; wave w owns pixel rows 4w..4w+3 (a "strip"), lanes with column < 8 its left half, the others
+// its right half.  A gaussian's alpha >= 1/255 box (cull_word) typically spans ~8 columns at 50 000 gaussians per
+// 768x512 image, i.e. one half of a strip more often than both, so each wave keeps TWO ascending lists -- entries
+// whose box reaches the left half, entries whose box reaches the right half (an entry may sit in both) -- and the
+// two halves of the wave walk their own list side by side: per trip a lane evaluates two consecutive entries of
+// ITS list with packed fp32 (v_pk_fma_f32 & co), entry 2p feeding one accumulator set and 2p+1 another (summed
+// at the end).  A wave needs max(|left|, |right|) / 2 trips instead of |left u right| / 2 (-37 % at that size).
+// Entries are copied GI2D_FWD_CHUNK at a time into a wave-private pair-interleaved buffer -- entries 2p and 2p+1
+// side by side, 20 floats per pair: (gx gx' gy gy') (ha ha' hb hb') (hc hc' op op') (cr cr' cg cg') (cb cb' k k') --
+// so one pair costs four ds_read_b128 + one or two ds_read_b64; the two halves' buffers are 128 bytes out of
+// phase, so the two addresses of one read never share a bank.  Every forward kernel (plain, fast, single-pass)
+// runs this one routine: identical pixels bit for bit.
 #define GI2D_FWD_DUMMY GI2D_TILE_LIST_CAP /* index of a never-contributing entry used as list padding */
-#define GI2D_FWD_PAIRBUF (32 * 20)        /* floats per wave of the packed loop's pair-interleaved buffer */
+#define GI2D_FWD_CHUNK 32                 /* list entries per half copied per trip */
+#define GI2D_FWD_HALF (GI2D_FWD_CHUNK / 2 * 20 + 32) /* floats from the left buffer to the right one (incl. bank shift) */
+#define GI2D_FWD_PAIRBUF (GI2D_FWD_HALF + GI2D_FWD_CHUNK / 2 * 20) /* floats per wave */
+#define GI2D_FWD_LISTLEN (GI2D_TILE_LIST_CAP + 8)
+
+struct FwdRec {  // one staged entry as the pixel loop consumes it (conic pre-scaled: scale_conic)
+    float gx, gy, ha, hb, hc, op, cr, cg, cb;
+};
+
+// lists: [2][GI2D_FWD_LISTLEN] bytes of this wave (left, right); buf: GI2D_FWD_PAIRBUF floats of this wave (16-byte
+// aligned).  cull_of(k) -> cull_word of entry k, rec_of(k) -> FwdRec of entry k (k == GI2D_FWD_DUMMY must give an
+// entry with opacity 0).  Returns the pixel in o0..o2 and, with NEED_FIDX, the last contributing entry (-1: none).
+template <bool NEED_FIDX, class CullOf, class RecOf>
+__device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float *buf, int len, CullOf cull_of,
+                                                     RecOf rec_of, float px, float py, float &o0, float &o1,
+                                                     float &o2, int &last_k) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned char *left = lists, *right = lists + GI2D_FWD_LISTLEN;
+    int n_left = 0, n_right = 0;
+    for (int base = 0; base < len; base += 64) {
+        const int k = base + lane;
+        const unsigned w = k < len ? cull_of(k) : 0u;
+        const bool reach = (w >> wv) & 1u;
+        const bool tl = reach && ((w >> 16) & 15u) <= 3u;  // first pixel pair q0 <= 3: touches columns 0..7
+        const bool tr = reach && ((w >> 20) & 15u) >= 4u;  // last pixel pair q1 >= 4: touches columns 8..15
+        const unsigned long long ml = __ballot(tl), mr = __ballot(tr);
+        if (tl) left[n_left + __popcll(ml & lanemask_lt())] = (unsigned char)k;
+        if (tr) right[n_right + __popcll(mr & lanemask_lt())] = (unsigned char)k;
+        n_left += __popcll(ml);
+        n_right += __popcll(mr);
+    }
+    __builtin_amdgcn_wave_barrier();  // wave-private lists: DS ops of one wave complete in order
+
+    const int my_half = (lane >> 3) & 1;           // which list this pixel walks
+    const float *mine = buf + my_half * GI2D_FWD_HALF;
+    const int bh = lane >> 5, be = lane & 31;      // build role: lanes 0-31 copy left entries, 32-63 right entries
+    const unsigned char *blist = bh ? right : left;
+    const int bcnt = bh ? n_right : n_left;
+    float *bdst = buf + bh * GI2D_FWD_HALF + (be >> 1) * 20 + (be & 1);
+    const int n_max = max(n_left, n_right);
+    v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+    const v2f px2 = {px, px}, py2 = {py, py};
+    int last = -1;
+    for (int c0 = 0; c0 < n_max; c0 += GI2D_FWD_CHUNK) {
+        {
+            const int e = c0 + be;
+            const int k = e < bcnt ? (int)blist[e] : GI2D_FWD_DUMMY;
+            const FwdRec r = rec_of(k);
+            bdst[0] = r.gx;
+            bdst[2] = r.gy;
+            bdst[4] = r.ha;
+            bdst[6] = r.hb;
+            bdst[8] = r.hc;
+            bdst[10] = r.op;
+            bdst[12] = r.cr;
+            bdst[14] = r.cg;
+            bdst[16] = r.cb;
+            if (NEED_FIDX) bdst[18] = __int_as_float(k);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int m = min(GI2D_FWD_CHUNK, n_max - c0);
+        for (int t = 0; t < m; t += 2) {
+            const float4 *q = reinterpret_cast<const float4 *>(mine + t * 10);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
+            const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
+            const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
+            const v2f dx = gx - px2, dy = gy - py2;
+            const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
+            const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
+            const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+            const v2f tt = op * vis;
+            const v2f alpha = {fminf(1.f, tt.x), fminf(1.f, tt.y)};
+            const bool ok0 = !(sig.x < 0.f || alpha.x < GI2D_ALPHA_MIN);  // forward.cu:541
+            const bool ok1 = !(sig.y < 0.f || alpha.y < GI2D_ALPHA_MIN);
+            const v2f am = {ok0 ? alpha.x : 0.f, ok1 ? alpha.y : 0.f};
+            a0 = __builtin_elementwise_fma(cr, am, a0);
+            a1 = __builtin_elementwise_fma(cg, am, a1);
+            a2 = __builtin_elementwise_fma(cb, am, a2);
+            if (NEED_FIDX) {  // entries ascend within a list: the last one that lands is the largest
+                const float2 ks = *reinterpret_cast<const float2 *>(mine + t * 10 + 18);
+                last = ok0 ? __float_as_int(ks.x) : last;
+                last = ok1 ? __float_as_int(ks.y) : last;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    o0 = a0.x + a0.y;
+    o1 = a1.x + a1.y;
+    o2 = a2.x + a2.y;
+    last_k = last;
+}
+
+// A 16x16 tile's RGB leaves as 16-byte stores of whole 192-byte rows: transposed through `buf` (>= 192 floats of
+// this wave's LDS, idle by now).
+__device__ __forceinline__ void fwd_store_pixels(float *buf, float o0, float o1, float o2, int tx, int ty, int img_w,
+                                                 int img_h, float *__restrict__ out_img) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
+    const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
+    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
+    if (full_tile) {
+        const int r = lane >> 4;
+        buf[r * 48 + lx * 3 + 0] = o0;
+        buf[r * 48 + lx * 3 + 1] = o1;
+        buf[r * 48 + lx * 3 + 2] = o2;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 48) {
+            const int rr = lane / 12, q = lane % 12;
+            const int ii = ty * GI2D_TILE + wv * 4 + rr;
+            if (ii < img_h) {
+                const float4 v = reinterpret_cast<const float4 *>(buf)[rr * 12 + q];
+                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
+                dst[q] = v;
+            }
+        }
+    } else if (i < img_h && j < img_w) {
+        const size_t pix = (size_t)i * img_w + j;
+        out_img[3 * pix + 0] = o0;
+        out_img[3 * pix + 1] = o1;
+        out_img[3 * pix + 2] = o2;
+    }
+}
+
+// LDS of the stand-alone forward kernels: staged entries (conic pre-scaled), their cull words, per-wave lists and
+// pair buffers.
 struct FwdLds {
     float4 AB[2 * (GI2D_TILE_LIST_CAP + 1)];  // [k]: (gx, gy, ha, hb), (hc, opac, cr, cg)
     float C[GI2D_TILE_LIST_CAP + 4];          // cb
-    unsigned char strips[GI2D_TILE_LIST_CAP]; // bit w: the gaussian can reach pixel rows 4w..4w+3
-    unsigned short list[4][GI2D_TILE_LIST_CAP + 8];  // per-wave ascending indices, padded to x4
+    unsigned cullw[GI2D_TILE_LIST_CAP];       // cull_word() of the entry
+    unsigned char lists[4][2 * GI2D_FWD_LISTLEN];
+    float4 pairbuf[GI2D_FWD_PAIRBUF];         // 4 waves x GI2D_FWD_PAIRBUF floats
 };
-#define GI2D_FWD_STAGE (4 * 48) /* floats per wave of the RGB transpose buffer the caller provides */
 
 // phase 1 helper: lane `k` publishes its gaussian (list position k of the tile)
-__device__ __forceinline__ void fwd_stage_entry(FwdLds &sm, int k, const GaussRec &r, unsigned mask) {
+__device__ __forceinline__ void fwd_stage_entry(FwdLds &sm, int k, const GaussRec &r, unsigned cull) {
     const ConicS s = scale_conic(r.a, r.b, r.c);
     sm.AB[2 * k] = make_float4(r.gx, r.gy, s.ha, s.hb);
     sm.AB[2 * k + 1] = make_float4(s.hc, r.opac, r.cr, r.cg);
     sm.C[k] = r.cb;
-    sm.strips[k] = (unsigned char)mask;
+    sm.cullw[k] = cull;
 }
 __device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
     // padding entry: opacity 0 -> alpha = 0 < 1/255, never contributes
@@ -86,8 +223,7 @@ __device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
 }
 
 // phases 2-4 of the forward for one tile whose `len` (<= 256) entries are staged in ascending order.
-// Must be called by all 256 lanes after a __syncthreads() that follows the staging.  `stage_base`: 4 x
-// GI2D_FWD_STAGE floats of LDS; `soa`: 4 x GI2D_FWD_PAIRBUF floats of LDS or nullptr (scalar loop form).
+// Must be called by all 256 lanes after a __syncthreads() that follows the staging.
 // NEED_FIDX=false (fast path: nobody consumes final_idx) drops the per-pair index tracking and the store.
 template <bool NEED_FIDX = true>
 __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int list_base, int tx, int ty,
@@ -95,123 +231,24 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
                                                      const float *__restrict__ background,
                                                      float *__restrict__ final_Ts,
                                                      int32_t *__restrict__ final_idx,
-                                                     float *__restrict__ out_img, float *stage_base,
-                                                     float *soa = nullptr) {
+                                                     float *__restrict__ out_img) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
     const bool inside = (i < img_h) && (j < img_w);
-
-    // phase 2: each wave compacts the indices of the gaussians that reach its strip (ascending)
-    unsigned short *mylist = sm.list[wv];
-    int cnt = 0;
-    for (int base = 0; base < len; base += 64) {
-        const int k = base + lane;
-        const bool take = (k < len) && ((sm.strips[k] >> wv) & 1);
-        const unsigned long long m = __ballot(take);
-        if (take) mylist[cnt + __popcll(m & lanemask_lt())] = (unsigned short)k;
-        cnt += __popcll(m);
-    }
-    if (lane < 4) mylist[cnt + lane] = (unsigned short)GI2D_FWD_DUMMY;
-    __builtin_amdgcn_wave_barrier();  // wave-private list: DS ops of one wave complete in order
-
-    // phase 3: one pixel per lane.  Entries 2p and 2p+1 of the wave's list feed two separate accumulator
-    // sets (summed at the end) in both loop forms below, so they give bitwise identical pixels.
-    const float px = (float)j, py = (float)i;
+    float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF;
     float o0, o1, o2;
-    int last_k = -1;
-    if (!NEED_FIDX && soa != nullptr) {
-        // packed form: the wave copies its list 64 entries at a time into a private pair-interleaved buffer --
-        // entries 2p and 2p+1 side by side, 20 floats per pair: (gx gx' gy gy') (ha ha' hb hb') (hc hc' op op')
-        // (cr cr' cg cg') (cb cb' - -) -- so one pair costs four ds_read_b128 + one ds_read_b64 (18 LDS cycles;
-        // nine separate 64-bit words get merged into ds_read2_b64 at half the LDS rate, which bound this loop),
-        // and evaluates both entries with v_pk_* instructions
-        float *mysoa = soa + wv * GI2D_FWD_PAIRBUF;
-        v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
-        const v2f px2 = {px, px}, py2 = {py, py};
-        for (int c0 = 0; c0 < cnt; c0 += 64) {
-            {
-                const int e = c0 + lane;
-                const int k = e < cnt ? (int)mylist[e] : GI2D_FWD_DUMMY;
-                const float4 A = sm.AB[2 * k], B = sm.AB[2 * k + 1];
-                const float cb = sm.C[k];
-                float *w = mysoa + (lane >> 1) * 20 + (lane & 1);
-                w[0] = A.x;
-                w[2] = A.y;
-                w[4] = A.z;
-                w[6] = A.w;
-                w[8] = B.x;
-                w[10] = B.y;
-                w[12] = B.z;
-                w[14] = B.w;
-                w[16] = cb;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int m = min(64, cnt - c0);
-            for (int t = 0; t < m; t += 2) {
-                const float4 *q = reinterpret_cast<const float4 *>(mysoa + t * 10);
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
-                const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
-                const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
-                const v2f dx = gx - px2, dy = gy - py2;
-                const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
-                const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
-                const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
-                const v2f tt = op * vis;
-                const v2f alpha = {fminf(1.f, tt.x), fminf(1.f, tt.y)};
-                const bool ok0 = !(sig.x < 0.f || alpha.x < GI2D_ALPHA_MIN);
-                const bool ok1 = !(sig.y < 0.f || alpha.y < GI2D_ALPHA_MIN);
-                const v2f am = {ok0 ? alpha.x : 0.f, ok1 ? alpha.y : 0.f};
-                a0 = __builtin_elementwise_fma(cr, am, a0);
-                a1 = __builtin_elementwise_fma(cg, am, a1);
-                a2 = __builtin_elementwise_fma(cb, am, a2);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        o0 = a0.x + a0.y;
-        o1 = a1.x + a1.y;
-        o2 = a2.x + a2.y;
-    } else {
-        // scalar form: four list entries per trip (indices are wave-uniform -> scalar)
-        float e0 = 0.f, e1 = 0.f, e2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        for (int t = 0; t < cnt; t += 4) {
-            const uint2 packed = *reinterpret_cast<const uint2 *>(mylist + t);
-            const unsigned p0 = __builtin_amdgcn_readfirstlane(packed.x);
-            const unsigned p1 = __builtin_amdgcn_readfirstlane(packed.y);
-            const int ks[4] = {(int)(p0 & 0xffffu), (int)(p0 >> 16), (int)(p1 & 0xffffu), (int)(p1 >> 16)};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = ks[u];
-                const float4 A = sm.AB[2 * k];
-                const float4 B = sm.AB[2 * k + 1];
-                const float cb = sm.C[k];
-                ConicS s;
-                s.ha = A.z;
-                s.hb = A.w;
-                s.hc = B.x;
-                const float dx = A.x - px, dy = A.y - py;
-                const float sig = pair_sigma(s, dx, row_term_b(s, dy), row_term_c(s, dy));
-                const float vis = pair_vis(sig);
-                const float alpha = fminf(1.f, B.y * vis);
-                const bool ok = !(sig < 0.f || alpha < GI2D_ALPHA_MIN);  // forward.cu:541
-                const float am = ok ? alpha : 0.f;
-                if (u & 1) {
-                    d0 = __builtin_fmaf(B.z, am, d0);
-                    d1 = __builtin_fmaf(B.w, am, d1);
-                    d2 = __builtin_fmaf(cb, am, d2);
-                } else {
-                    e0 = __builtin_fmaf(B.z, am, e0);
-                    e1 = __builtin_fmaf(B.w, am, e1);
-                    e2 = __builtin_fmaf(cb, am, e2);
-                }
-                if (NEED_FIDX) last_k = ok ? k : last_k;
-            }
-        }
-        o0 = e0 + d0;
-        o1 = e1 + d1;
-        o2 = e2 + d2;
-    }
+    int last_k;
+    fwd_pixel_half_lists<NEED_FIDX>(
+        sm.lists[wv], mybuf, len, [&](int k) { return sm.cullw[k]; },
+        [&](int k) {
+            const float4 A = sm.AB[2 * k], B = sm.AB[2 * k + 1];
+            FwdRec r;
+            r.gx = A.x, r.gy = A.y, r.ha = A.z, r.hb = A.w, r.hc = B.x, r.op = B.y, r.cr = B.z, r.cg = B.w;
+            r.cb = sm.C[k];
+            return r;
+        },
+        (float)j, (float)i, o0, o1, o2, last_k);
     int cur_idx = last_k < 0 ? 0 : list_base + last_k;  // forward.cu:497,550: 0 when nothing landed
     if (background_fill) {
         // rasterize_sum_plus.py:110-118: no intersections at all -> image = background
@@ -220,36 +257,12 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
         o2 = background[2];
         cur_idx = 0;
     }
-
-    const int pix = i * img_w + j;
     if (inside) {
+        const int pix = i * img_w + j;
         if (final_Ts) final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
         if (NEED_FIDX) final_idx[pix] = cur_idx;
     }
-    // phase 4: transpose RGB through the wave's LDS so a 16-pixel row leaves as 12 x 16-byte stores
-    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
-    if (full_tile) {
-        // 4 rows x 48 floats, wave-private: the wave's own (now idle) pair buffer, or the caller's stage buffer
-        float *stage = (!NEED_FIDX && soa != nullptr) ? soa + wv * GI2D_FWD_PAIRBUF : stage_base + wv * GI2D_FWD_STAGE;
-        const int r = lane >> 4;
-        stage[r * 48 + lx * 3 + 0] = o0;
-        stage[r * 48 + lx * 3 + 1] = o1;
-        stage[r * 48 + lx * 3 + 2] = o2;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 48) {
-            const int rr = lane / 12, q = lane % 12;
-            const int ii = ty * GI2D_TILE + wv * 4 + rr;
-            if (ii < img_h) {
-                const float4 v = reinterpret_cast<const float4 *>(stage)[rr * 12 + q];
-                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
-                dst[q] = v;
-            }
-        }
-    } else if (inside) {
-        out_img[3 * (size_t)pix + 0] = o0;
-        out_img[3 * (size_t)pix + 1] = o1;
-        out_img[3 * (size_t)pix + 2] = o2;
-    }
+    fwd_store_pixels(mybuf, o0, o1, o2, tx, ty, img_w, img_h, out_img);
 }
 
 // ========================================================================================== backward
