@@ -293,6 +293,7 @@ def test_single_pass_edge_geometries(oracle):
     xyz[6:10] = [4.0, -3.0]
     op = np.ones((n, 1), np.float32)
     op[10:14] = 0.0
+    op[14:20] = 2.5  # alpha clamps to 1 near the centre
     cases.append((160, 240, xyz, L, rng.random((n, 3)).astype(np.float32), op))
     for h, w, xyz, L, col, op in cases:
         n = xyz.shape[0]
