@@ -50,6 +50,18 @@ __device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &me
     const float *bd = P.bound + (size_t)P.bound_stride * g;
 #pragma unroll
     for (int q = 0; q < 3; ++q) par[q] = P.chol[3 * g + q] + bd[q];  // get_cholesky_elements / get_cov2d_elements
+    if (KIND == kScaleRot) {
+        // models/gaussianimage_rs.py:166-172: scaling = |_scaling + bound|, rotation = sigmoid(_rotation) * 2 pi;
+        // `chol` holds (_scaling.x, _scaling.y, _rotation), `bound` (0.5, 0.5, unused)
+        par[0] = fabsf(par[0]);
+        par[1] = fabsf(par[1]);
+        par[2] = (1.f / (1.f + __expf(-P.chol[3 * g + 2]))) * 6.283185307179586f;
+    }
+}
+// p1 argument of the projection routines: the rotation of the scale-rot model sits in par[2]
+template <int KIND>
+__device__ __forceinline__ const float *rot_of(const float (&par)[3]) {
+    return KIND == kScaleRot ? &par[2] : nullptr;
 }
 
 template <int KIND>
@@ -68,7 +80,8 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     float2 mean;
     float par[3];
     activate<KIND>(P, g, mean, par);
-    const ProjOut o = project_one<KIND>(0, clip_coe, &mean, par, nullptr, img_w, img_h, tiles_x, tiles_y, radius_clip);
+    const ProjOut o =
+        project_one<KIND>(0, clip_coe, &mean, par, rot_of<KIND>(par), img_w, img_h, tiles_x, tiles_y, radius_clip);
     xys[g] = o.xy;
     radii[g] = o.radius;
     conics[3 * g] = o.k0;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (radii[g] > 0) {
         const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
         const float vc[3] = {acc[2], acc[3], acc[4]};
-        r = project_bwd_one<KIND>(0, par, nullptr, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
+        r = project_bwd_one<KIND>(0, par, rot_of<KIND>(par), img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
     }
     // activation backward: tanh' = 1 - tanh^2 (Cholesky model), identity otherwise; the bound is a constant
     float gx = r.v_mean.x, gy = r.v_mean.y;
@@ -185,7 +198,17 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         gx = gx * (1.f - mean.x * mean.x);
         gy = gy * (1.f - mean.y * mean.y);
     }
-    const float gp[3] = {r.o0, r.o1, r.o2};
+    float gp[3] = {r.o0, r.o1, r.o2};
+    if (KIND == kScaleRot) {  // through |.| (torch.abs: sign, 0 at 0) and sigmoid * 2 pi
+        const float *bd = P.bound + (size_t)P.bound_stride * g;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float pre = P.chol[3 * g + q] + bd[q];
+            gp[q] = pre > 0.f ? gp[q] : (pre < 0.f ? -gp[q] : 0.f);
+        }
+        const float sg = par[2] * (1.f / 6.283185307179586f);
+        gp[2] = gp[2] * (6.283185307179586f * sg * (1.f - sg));
+    }
     const float gf[3] = {acc[5], acc[6], acc[7]};
     if (dbg_grads) {  // [N,8]: gradients w.r.t. the raw parameters (tests)
         float *d = dbg_grads + 8 * (size_t)g;
@@ -247,7 +270,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         float par2[3];
         activate<KIND>(P, g, mean2, par2);
         const ProjOut o =
-            project_one<KIND>(0, next.clip_coe, &mean2, par2, nullptr, img_w, img_h, tiles_x, tiles_y, radius_clip);
+            project_one<KIND>(0, next.clip_coe, &mean2, par2, rot_of<KIND>(par2), img_w, img_h, tiles_x, tiles_y,
+                              radius_clip);
         xys[g] = o.xy;
         radii[g] = o.radius;
         conics[3 * g] = o.k0;
@@ -302,7 +326,7 @@ static TrainParams params_of(const gi2d_train_state *s) {
 }
 
 static int train_check(const gi2d_train_state *s, int &tx, int &ty) {
-    if (!s || s->kind < 0 || s->kind > 1 || s->num_points < 0 || s->img_height <= 0 || s->img_width <= 0) {
+    if (!s || s->kind < 0 || s->kind > 2 || s->num_points < 0 || s->img_height <= 0 || s->img_width <= 0) {
         set_error("train: bad state");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
@@ -326,7 +350,11 @@ static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w
     const int n = s->num_points;
     const int bs = per_gaussian_block(n);
     const dim3 gg((n + bs - 1) / bs), bb(bs);
-    if (s->kind == 0)
+    if (s->kind == 2)
+        hipLaunchKernelGGL(train_project_fill_kernel<kScaleRot>, gg, bb, 0, st, n, s->clip_coe, P,
+                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
+                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+    else if (s->kind == 0)
         hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
                            s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
@@ -437,7 +465,12 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
         else                  \
             GI2D_LAUNCH_RU(K, F, false); \
     } while (0)
-        if (s->kind == 0) {
+        if (s->kind == 2) {
+            if (more)
+                GI2D_LAUNCH_RU2(kScaleRot, true);
+            else
+                GI2D_LAUNCH_RU2(kScaleRot, false);
+        } else if (s->kind == 0) {
             if (more)
                 GI2D_LAUNCH_RU2(kCholesky, true);
             else

@@ -206,8 +206,9 @@ def main(argv=None):
     ap.add_argument("--opt_type", choices=["adam", "adan"], default=None,
                     help="default: train.py's choice for the model (covariance: adam, otherwise adan; main():251-257)")
     ap.add_argument("--seed", type=int, default=3047)
-    ap.add_argument("--model", choices=["cholesky", "covariance"], default="cholesky",
-                    help="covariance = train.py's default model (pixel coordinates, lr 0.018, Adam eps 1e-15)")
+    ap.add_argument("--model", choices=["cholesky", "covariance", "scale_rot"], default="cholesky",
+                    help="covariance = train.py's default model (pixel coordinates, lr 0.018, Adam eps 1e-15); "
+                         "scale_rot = the rotation-scale parameterisation of models/gaussianimage_rs.py")
     ap.add_argument("--max_num_points", type=int, default=0,
                     help="> num_points: adaptive growth/pruning as in train.py (covariance model, native loop)")
     ap.add_argument("--prune_iter", type=int, default=100)

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 
-_KINDS = {"cholesky": 0, "covariance": 1}
+_KINDS = {"cholesky": 0, "covariance": 1, "scale_rot": 2}
 
 
 class _TrainState(C.Structure):
@@ -113,9 +113,11 @@ class NativeFitter:
         if init is None:  # models/gaussianimage_cholesky.py:57-58,99 / gaussianimage_covariance.py:52-57
             if kind == "cholesky":
                 xyz = torch.atanh(2 * (torch.rand(n, 2, generator=self.rng) - 0.5))
-            else:
+            else:  # pixel coordinates: the covariance and scale-rot projections take them as they are
                 xyz = torch.rand(n, 2, generator=self.rng) * torch.tensor([float(w), float(h)])
             init = {"xyz": xyz, "chol": torch.rand(n, 3, generator=self.rng), "feat": torch.zeros(n, 3)}
+        if kind == "scale_rot" and "bound" not in init:  # models/gaussianimage_rs.py:57: bound = (0.5, 0.5)
+            init = dict(init, bound=torch.tensor([0.5, 0.5, 0.0]))
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)
         self._xyz, self._chol, self._feat = f32(cap, 2), f32(cap, 3), f32(cap, 3)

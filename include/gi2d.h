@@ -331,13 +331,15 @@ int gi2d_timer_elapsed_us(void *timer, float *microseconds);
 
 /* ------------------------------------------------------------------ fused fitting iteration
  * SURVEY 8f rank 2 (callers either side of the path): one whole training iteration of the
- * Cholesky (kind 0) or covariance (kind 1) model with L2 loss and Adam --
+ * Cholesky (kind 0), covariance (kind 1) or scale-rot (kind 2) model with L2 loss and Adam --
  * (or Adan) -- models/gaussianimage_cholesky.py:302-317 / models/gaussianimage_covariance.py:249-259 --
  * in three launches: activations+projection+fill, one tile pass (rasterize forward, loss
  * gradient formed per pixel in registers, backward), gradient reduce + projection backward + activation
  * backward + torch.optim.Adam update.  All pointers are device pointers owned by the caller.
- *   xyz   f32[N,2]  raw positions (kind 0: pre-tanh; kind 1: pixels)      updated in place
- *   chol  f32[N,3]  raw Cholesky / covariance triple (bound is added)     updated in place
+ *   xyz   f32[N,2]  raw positions (kind 0: pre-tanh; kinds 1, 2: pixels)  updated in place
+ *   chol  f32[N,3]  raw Cholesky / covariance triple (bound is added), or, kind 2 (scale-rot model,
+ *                   models/gaussianimage_rs.py:166-172): (_scaling.x, _scaling.y, _rotation) with
+ *                   scale = |_scaling + bound[0:2]|, rotation = sigmoid(_rotation) * 2 pi   updated in place
  *   feat  f32[N,3]  colours                                              updated in place
  *   opacity f32[N] (not optimised), bound f32[3] (bound_stride 0) or f32[N,3] (bound_stride 3)
  *   m_*, v_*        Adam moments, same shapes as the parameters           updated in place

@@ -29,6 +29,10 @@ def _torch_loop(kind, gt, init, bound, iters, lr, eps=1e-8, optimizer="adam"):
     for it in range(iters):
         if kind == "cholesky":
             xys, depths, radii, conics, nth = gs.project_gaussians_2d(torch.tanh(xyz), chol + bound, h, w, tb)
+        elif kind == "scale_rot":  # models/gaussianimage_rs.py:166-172
+            scales = torch.abs(chol[:, :2] + bound[:2])
+            rot = torch.sigmoid(chol[:, 2:3]) * 2 * math.pi
+            xys, depths, radii, conics, nth = gs.project_gaussians_2d_scale_rot(xyz, scales, rot, h, w, tb)
         else:
             xys, depths, radii, conics, nth = gs.project_gaussians_2d_covariance(xyz, chol + bound, h, w, tb)
         img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, feat, opacity, h, w, 16, 16, background=bg)
@@ -222,3 +226,31 @@ def test_native_adan_matches_autograd_loop_with_reference_adan():
     for _ in range(iters):
         one.train(1)
     assert torch.equal(one.xyz, fit.xyz) and torch.equal(one.chol, fit.chol) and torch.equal(one.feat, fit.feat)
+
+
+def test_native_scale_rot_model_matches_autograd_loop():
+    """The rotation-scale parameterisation (models/gaussianimage_rs.py: scale = |s + 0.5|, rot = sigmoid(r) 2 pi,
+    pixel coordinates) on the native loop against the wrappers + autograd + torch Adam."""
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    n, h, w, iters, lr = 3000, 96, 144, 10, 5e-3
+    gt = synthetic_image(h, w, 6).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    init = {"xyz": torch.rand(n, 2, generator=g) * torch.tensor([float(w), float(h)]),
+            "chol": torch.cat([torch.rand(n, 2, generator=g) * 3.0 - 1.5, torch.rand(n, 1, generator=g) * 4 - 2], 1),
+            "feat": torch.rand(n, 3, generator=g) * 0.3}
+    assert (init["chol"][:, :2] + 0.5 < 0).any()  # the |.| branch with a negative argument is exercised
+    bound = torch.tensor([0.5, 0.5, 0.0], device=DEV)
+    fit = NativeFitter(gt, n, kind="scale_rot", lr=lr, init=init, debug_grads=True)
+    fit.train(1)
+    fit.check_status()
+    g_native = fit.dbg_grads.clone()
+    want = _torch_loop("scale_rot", gt, init, bound, iters, lr)
+    scale = want[3].abs().max(dim=0, keepdim=True).values + 1e-20
+    err = ((g_native - want[3]).abs() / scale).max().item()
+    assert err < 3e-4, f"first-step gradient mismatch {err}"
+    fit.train(iters - 1)
+    for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "chol"), (fit.feat, want[2], "feat")):
+        d = (got - ref).abs()
+        assert d.max().item() < 0.15 * lr * iters, f"{nm} drifted by {d.max().item()}"
+        assert d.mean().item() < 2e-2 * lr * iters, nm
