@@ -362,8 +362,8 @@ int gi2d_timer_destroy(void *timer) {
     KernelTimer *t = (KernelTimer *)timer;
     if (!t) return GI2D_OK;
     if (g_armed_timer == t) g_armed_timer = nullptr;
-    hipEventDestroy(t->begin);
-    hipEventDestroy(t->end);
+    (void)hipEventDestroy(t->begin);
+    (void)hipEventDestroy(t->end);
     delete t;
     return GI2D_OK;
 }
