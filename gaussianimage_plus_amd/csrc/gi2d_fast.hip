@@ -15,7 +15,11 @@
 //            gather), runs the strip items, and stores each (tile, gaussian) partial straight into
 //            a gaussian-major row (gaussians on <= 16 tiles), so that
 //   reduce   is a single level of coalesced loads per gaussian (fixed ascending-tile order: bitwise
-//            reproducible); optionally fused with the projection backward (reduce_project).
+//            reproducible); optionally fused with the projection backward (reduce_project) and, in a loop,
+//            with the projection + fill of the NEXT step (reduce_project<.., FILL_NEXT>).
+//   forward+backward  (fast_fwdbwd_kernel, gi2d_fused_core.h) is forward and backward of a tile in ONE
+//            workgroup pass -- what a loop runs when the pixel gradient is given or is the L2-loss gradient
+//            of the pixel just rendered: two launches per step.
 //
 // Capacity contract: at most GI2D_FAST_CSUB (256) ids per (tile, sub-bucket), i.e. up to 1024 candidates per tile
 // of which the 256 lowest ids are rasterized (forward.cu:553).  A fuller bucket sets
