@@ -1,0 +1,50 @@
+"""GPU: bench.py prints ONE JSON line with the fields the driver and the judge read (small workload, short CPU leg)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_has_the_contract_fields():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4",
+           "--num-points", "3000", "--height", "96", "--width", "144", "--cpu-seconds", "0.5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 4 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert r["traffic"] is None  # the committed counters are for the default workload, not this one
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_launcher_cli_runs_both_loops_and_reports_the_average_line():
+    base = [sys.executable, "-m", "gaussianimage_plus_amd.launch", "--synthetic", "2", "--height", "96", "--width",
+            "144", "--num_points", "1500", "--iterations", "60"]
+    for extra in (["--model", "cholesky"], ["--model", "covariance", "--max_num_points", "3000", "--grow_iter", "20",
+                                            "--prune_iter", "10", "--images_per_gpu", "2"]):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [l for l in out.stdout.splitlines() if l.startswith("[rank 0] image")]
+        avg = [l for l in out.stdout.splitlines() if l.startswith("Average:")]
+        assert len(rows) == 2 and len(avg) == 1
+        assert "images:2" in avg[0] and "gpus:1" in avg[0] and "PSNR:" in avg[0]
