@@ -60,8 +60,8 @@ struct FusedLds {
     float gCb[GI2D_TILE_LIST_CAP + 4];  // cb
     unsigned cullw[GI2D_TILE_LIST_CAP]; // cull_word() of the entry
     int slot[GI2D_TILE_LIST_CAP];       // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big)
-    int cnt[GI2D_FAST_SUB];
     float sse_w[4];
+    int scan_w[4];  // per-wave totals of the backward's item scan (outside the overlay: written during the forward phase)
     union {
         struct {
             int ids[GI2D_FAST_C];
@@ -121,28 +121,26 @@ __device__ __forceinline__ void fused_tile(
         p2 = vsrc[3 * pix + 2];
     }
 
-    // ---- bucket -> ordered, staged list (as fast_fwd_kernel)
-    if (tid < GI2D_FAST_SUB) {
-        const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
-        cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
-        if (c > GI2D_FAST_CSUB) {
-            atomicOr(&status[1], 1);
-            atomicOr(&status[2], 1);
-        }
-        sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
-    }
+    // ---- bucket -> ordered, staged list (as fast_fwd_kernel, but every lane reads the four cursors itself -- one
+    // broadcast transaction each -- instead of four lanes publishing them through LDS behind a barrier)
+    int cnt4[GI2D_FAST_SUB];
+#pragma unroll
+    for (int q = 0; q < GI2D_FAST_SUB; ++q)
+        cnt4[q] = cursors[(tile * GI2D_FAST_SUB + q) * GI2D_CURSOR_STRIDE];
     if (tid == 0) {
         sm.gA[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
         sm.gB[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
         sm.gCb[GI2D_TILE_LIST_CAP] = 0.f;
+        if (cnt4[0] > GI2D_FAST_CSUB || cnt4[1] > GI2D_FAST_CSUB || cnt4[2] > GI2D_FAST_CSUB ||
+            cnt4[3] > GI2D_FAST_CSUB) {
+            atomicOr(&status[1], 1);
+            atomicOr(&status[2], 1);
+        }
     }
-    __syncthreads();
     GI2D_TRACE(1);
-    const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
+    const int c0 = min(cnt4[0], GI2D_FAST_CSUB), c1 = c0 + min(cnt4[1], GI2D_FAST_CSUB),
+              c2 = c1 + min(cnt4[2], GI2D_FAST_CSUB), L = c2 + min(cnt4[3], GI2D_FAST_CSUB);
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
-    GI2D_TRACE_VALUE(11, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID
-    GI2D_TRACE_VALUE(12, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));  // HW_REG_XCC_ID
-    GI2D_TRACE_VALUE(13, (unsigned long long)L);
     int my_id[GI2D_FAST_EPT];
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
@@ -157,6 +155,8 @@ __device__ __forceinline__ void fused_tile(
     }
     __syncthreads();
     GI2D_TRACE(2);
+    // every lane has read the cursors: ready them for the next call
+    if (tid < GI2D_FAST_SUB) cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
@@ -228,19 +228,20 @@ __device__ __forceinline__ void fused_tile(
         for (int d = 32; d >= 1; d >>= 1) sse += __shfl_xor(sse, d, 64);
         if (lane == 0) sm.sse_w[wv] = sse;
     }
+    // the backward's item scan starts here, ahead of the barrier that is needed anyway
+    const unsigned cull = tid < len ? sm.cullw[tid] : 0u;
+    const int scan_incl = bwd_prescan(sm.scan_w, cull);
     __syncthreads();  // every wave is done with its list / pair buffer: the overlay becomes the backward's buffers
 
     GI2D_TRACE(6);
     // ---- backward on the same staged records
     bwd_publish_pixel(sm, lx, ly, v0, v1, v2, 0.f);
-    unsigned cull = 0u;
     float4 *dst = nullptr;
     if (tid < len) {
-        cull = sm.cullw[tid];
         const int slot = sm.slot[tid];
         dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
     }
-    bwd_run_tile<false, false>(sm, len, cull, 0, tx0, ty0, dst);
+    bwd_run_tile<false, false, true>(sm, len, cull, 0, tx0, ty0, dst, scan_incl, sm.scan_w);
     GI2D_TRACE(10);
     if (MODE == 1 && tid == 0) tile_sse[tile] = (sm.sse_w[0] + sm.sse_w[1]) + (sm.sse_w[2] + sm.sse_w[3]);
     // "No intersection at all" is a global property: see fast_fwd_kernel

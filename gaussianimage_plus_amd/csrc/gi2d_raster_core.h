@@ -379,21 +379,39 @@ __device__ __forceinline__ bool fidx_admits(int, const float2 &, int) {
     return true;
 }
 
-template <bool WITH_ABS, bool USE_FIDX = true, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
+// number of items (row pairs) of the gaussian with cull word `cull`
+__device__ __forceinline__ int bwd_items_of(unsigned cull) {
+    const int p0 = (int)((cull >> 9) & 7u), p1 = (int)((cull >> 13) & 7u);
+    return (cull & 15u) ? (p1 - p0 + 1) : 0;
+}
+// First half of the item scan: this wave's inclusive scan, its total published in `wsum[wave]`.  A caller whose
+// next workgroup barrier comes anyway may run it ahead of that barrier and pass the result to bwd_run_tile
+// (PRESCANNED), which then needs one barrier less; wsum must not live in memory other waves still use.
+__device__ __forceinline__ int bwd_prescan(int *wsum, unsigned cull) {
+    const int incl = wave_inclusive_scan(bwd_items_of(cull));
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    return incl;
+}
+
+template <bool WITH_ABS, bool USE_FIDX = true, bool PRESCANNED = false, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
 __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, int list_base, float tx0, float ty0,
-                                             float4 *__restrict__ dst) {
+                                             float4 *__restrict__ dst, int prescan_incl = 0,
+                                             const int *prescan_wsum = nullptr) {
     constexpr int PSTR = Lds::PSTR;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, wv = tid >> 6;
     {
-        // row pairs this gaussian reaches: p0..p1; its pixel-pair range rides along in sm.xr
-        const int p0 = (int)((cull >> 9) & 7u), p1 = (int)((cull >> 13) & 7u);
-        const int nitems = (cull & 15u) ? (p1 - p0 + 1) : 0;
+        // one item per row pair this gaussian reaches; its row / pixel-pair ranges ride along in sm.xr
+        const int nitems = bwd_items_of(cull);
         if (tid < len) sm.xr[tid] = (cull >> 8) & 0xffffu;  // r0 | r1 << 4 | q0 << 8 | q1 << 12
-        const int incl = wave_inclusive_scan(nitems);
-        if (lane == 63) sm.wsum[wv] = incl;
-        __syncthreads();
+        int incl = prescan_incl;
+        const int *wsum = prescan_wsum;
+        if (!PRESCANNED) {
+            incl = bwd_prescan(sm.wsum, cull);
+            wsum = sm.wsum;
+            __syncthreads();
+        }
         int base = 0;
-        for (int k = 0; k < wv; ++k) base += sm.wsum[k];
+        for (int k = 0; k < wv; ++k) base += wsum[k];
         int excl = base + incl - nitems;
         if (tid < len) sm.off[tid] = (unsigned short)excl;
         if (tid == 255) sm.off[len] = (unsigned short)(excl + nitems);  // lanes >= len carry 0 items
@@ -518,6 +536,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         }
 #pragma unroll
         for (int h0 = 0; h0 < GI2D_BWD_ITEMS; h0 += PROWS) {
+            if (h0 > 0 && round0 + h0 >= round1) break;  // nothing left in this round (tile-uniform)
             if (it < round1 && tid >= h0 && tid < h0 + PROWS) {
                 float *out = &sm.part[(tid - h0) * PSTR];
 #pragma unroll
@@ -532,7 +551,9 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                     for (int q = 0; q < PSTR; ++q) acc[q] += in[q];
                 }
             }
-            __syncthreads();
+            // the hand-off buffer is rewritten by the next pass / round: wait, unless this was the last one
+            const bool last = (round0 + h0 + PROWS >= round1) && (round0 + GI2D_BWD_ITEMS >= n_items);
+            if (!last) __syncthreads();
         }
         GI2D_BWD_TRACE(9);
         if (owner) store_partial_row<PSTR>(dst, acc);
