@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
 // -------------------------------------------------------------------------------------- forward
 struct FastFwdLds {
     FwdLds f;
-    int cnt[GI2D_FAST_SUB];
 };
 static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id sort buffer overlays the pair buffers");
 
@@ -113,18 +112,20 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
-    if (tid < GI2D_FAST_SUB) {
-        const int c = cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE];
-        cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;  // ready for the next call
-        if (c > GI2D_FAST_CSUB) {
+    // every lane reads the four cursors itself (one broadcast transaction each): no LDS hop, no barrier
+    int cnt4[GI2D_FAST_SUB];
+#pragma unroll
+    for (int q = 0; q < GI2D_FAST_SUB; ++q) cnt4[q] = cursors[(tile * GI2D_FAST_SUB + q) * GI2D_CURSOR_STRIDE];
+    if (tid == 0) {
+        fwd_stage_dummy(sm.f);
+        if (cnt4[0] > GI2D_FAST_CSUB || cnt4[1] > GI2D_FAST_CSUB || cnt4[2] > GI2D_FAST_CSUB ||
+            cnt4[3] > GI2D_FAST_CSUB) {
             atomicOr(&status[1], 1);
             atomicOr(&status[2], 1);
         }
-        sm.cnt[tid] = min(c, GI2D_FAST_CSUB);
     }
-    if (tid == 0) fwd_stage_dummy(sm.f);
-    __syncthreads();
-    const int c0 = sm.cnt[0], c1 = c0 + sm.cnt[1], c2 = c1 + sm.cnt[2], L = c2 + sm.cnt[3];
+    const int c0 = min(cnt4[0], GI2D_FAST_CSUB), c1 = c0 + min(cnt4[1], GI2D_FAST_CSUB),
+              c2 = c1 + min(cnt4[2], GI2D_FAST_CSUB), L = c2 + min(cnt4[3], GI2D_FAST_CSUB);
     if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
     // my (up to GI2D_FAST_EPT) bucket entries
     int my_id[GI2D_FAST_EPT];
@@ -140,6 +141,8 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
         }
     }
     __syncthreads();
+    // every lane has read the cursors: ready them for the next call
+    if (tid < GI2D_FAST_SUB) cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
