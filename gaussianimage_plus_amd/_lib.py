@@ -58,12 +58,20 @@ SIGNATURES.update({
     "gi2d_train_render": [_p, _p],
     "gi2d_train_step": [_p, _p, _f, _f, _f, _i, _p],
     "gi2d_train_steps": [_p, _p, _f, _f, _f, _i, _i, _p],
+    # quantisers: struct gi2d_quant_spec* (gaussianimage_plus_amd/quantize.py::_QuantSpec)
+    "gi2d_quant_init": [_p, _i, _p, _p, _p, _sz, _p],
+    "gi2d_quant_forward": [_p, _i, _p, _p, _p, _p, _p, _sz, _p],
+    "gi2d_quant_backward": [_p, _i, _p, _p, _p, _p, _p, _p, _sz, _p],
+    "gi2d_quant_compress": [_p, _i, _p, _p, _p, _p, _p],
+    "gi2d_quant_decompress": [_p, _i, _p, _p, _p, _p],
+    "gi2d_quant_half": [_sz, _p, _p, _p],
 })
 SIZE_FUNCS = {
     "gi2d_fast_workspace_bytes": [_i, _i, _i],
     "gi2d_sort_workspace_bytes": [_i, _i],
     "gi2d_rasterize_backward_workspace_bytes": [_i, _i],
     "gi2d_bin_workspace_bytes": [_i, _i],
+    "gi2d_quant_workspace_bytes": [_i],
 }
 STRING_FUNCS = ["gi2d_version", "gi2d_last_error_string"]
 

@@ -388,6 +388,51 @@ int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float b
 int gi2d_train_steps(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
                      float eps, int first_step, int count, gi2d_stream_t stream);
 
+/* ------------------------------------------------------------------ quantisation-aware front end
+ * the quantisers train_quantize.py puts in front of the projection after its warm-up
+ * (models/gaussianimage_covariance.py:384-410 forward_quantize, :412-443 compress_wo_ec), from
+ * /root/reference/quantize.py:
+ *   GI2D_QUANT_LSQ  UniformQuantizer (LSQ+) :39-156   code = clamp((x - beta)/scale, qmin, qmax), y = round(code)*scale + beta,
+ *                                                      learned per-channel scale / beta, straight-through rounding (:23-24)
+ *   GI2D_QUANT_LOG  LogQuantizer, learned=False :158-259   t = log(|x| + 1e-6), range [min t, max t] recomputed from the
+ *                                                      data on every forward, y = exp(round(code)*scale + beta) (no sign)
+ *   HybirdQuant :336-389 on [N,3] rows (a, b, c) is the spec {LOG, LSQ, LOG}; a plain LogQuantizer on [N,2] is {LOG, LOG}.
+ * Rows are f32[N, channels], channels <= 4.  `params` is f32[channels][4] = {scale, beta, max t, 0} on the device:
+ * read for LSQ channels; WRITTEN by gi2d_quant_forward for log channels (all log channels of a spec share one range
+ * there: LogQuantizer.forward reduces over its whole input) and by gi2d_quant_init for every channel (per-channel
+ * ranges: _init_data :69-77 / :192-201, which is also what LogQuantizer.compress uses).
+ *   gi2d_quant_forward   -> dequant f32[N,C] and/or code f32[N,C] (rounded integer codes as floats; NULL = skip)
+ *   gi2d_quant_backward  given v_dequant: v_x f32[N,C] and v_params f32[C][2] = {v_scale, v_beta} (0 for log channels).
+ *                        Follows the autograd graph of the forward as written, including the gradient that reaches the
+ *                        elements at the extremes of the log range through beta = min() and scale = (max() - min())/Q
+ *                        (spread evenly over ties, as torch.min()/max() do).
+ *   gi2d_quant_compress  forward with the per-channel ranges in `params` (no range pass): compress() :149-152, :243-255
+ *   gi2d_quant_decompress code -> value: decompress() :154-156, :257-259
+ *   gi2d_quant_half      FakeQuantizationHalf :27-37 (x.half().float()); its backward is the identity
+ * workspace: gi2d_quant_workspace_bytes(N) bytes of scratch; sums are two-stage in a fixed order (bitwise reproducible). */
+#define GI2D_QUANT_LSQ 0
+#define GI2D_QUANT_LOG 1
+#define GI2D_QUANT_MAX_CHANNELS 4
+typedef struct gi2d_quant_spec {
+    int32_t channels;
+    int32_t kind[GI2D_QUANT_MAX_CHANNELS];
+    float qmin[GI2D_QUANT_MAX_CHANNELS], qmax[GI2D_QUANT_MAX_CHANNELS];
+} gi2d_quant_spec;
+size_t gi2d_quant_workspace_bytes(int num_rows);
+int gi2d_quant_init(const gi2d_quant_spec *spec_host, int num_rows, const float *x, float *params,
+                    void *workspace, size_t workspace_bytes, gi2d_stream_t stream);
+int gi2d_quant_forward(const gi2d_quant_spec *spec_host, int num_rows, const float *x, float *params,
+                       float *dequant, float *code, void *workspace, size_t workspace_bytes,
+                       gi2d_stream_t stream);
+int gi2d_quant_backward(const gi2d_quant_spec *spec_host, int num_rows, const float *x, const float *params,
+                        const float *v_dequant, float *v_x, float *v_params, void *workspace,
+                        size_t workspace_bytes, gi2d_stream_t stream);
+int gi2d_quant_compress(const gi2d_quant_spec *spec_host, int num_rows, const float *x, const float *params,
+                        float *dequant, float *code, gi2d_stream_t stream);
+int gi2d_quant_decompress(const gi2d_quant_spec *spec_host, int num_rows, const float *code,
+                          const float *params, float *out, gi2d_stream_t stream);
+int gi2d_quant_half(size_t count, const float *x, float *y, gi2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

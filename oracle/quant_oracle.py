@@ -174,7 +174,8 @@ def hybrid_size(bits, cov_bits):
 
 # ------------------------------------------------------------------------------------------------------ half precision
 def half_forward(x):
-    return np.asarray(x, F).astype(np.float16).astype(F)
+    with np.errstate(over="ignore"):  # beyond 65504 the half is inf, as in torch
+        return np.asarray(x, F).astype(np.float16).astype(F)
 
 
 def half_backward(g):
