@@ -14,6 +14,7 @@
 // The glue the reference runs as ~25 small PyTorch kernels plus two host syncs per iteration
 // (models/gaussianimage_cholesky.py:302-317) is folded into the kernels either side of the rasterizer.
 #include "gi2d_fast_internal.h"
+#include "gi2d_quant_core.h"
 
 namespace gi2d {
 
@@ -134,20 +135,9 @@ __device__ __forceinline__ float adan(float p, float g, float &m, float &n, floa
     return p;
 }
 
-template <int KIND, bool FILL_NEXT, bool ADAN>
-__global__ __launch_bounds__(256) void train_reduce_update_kernel(
-    int n, TrainParams P, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
-    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
-    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
-    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
-#pragma clang fp contract(off)
-    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next iteration's tile order (gi2d_fast_internal.h)
-        compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);
-        return;
-    }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    // Is the render of THIS step (made with the pre-update parameters) the best so far?  Every workgroup sums
-    // the per-tile squared errors in the same fixed order, so all take the same decision without a host round trip.
+// Is the render of THIS step (made with the pre-update parameters) the best so far?  Every workgroup sums the
+// per-tile squared errors in the same fixed order, so all take the same decision without a host round trip.
+__device__ __forceinline__ bool best_decision(const BestSnap &best, int n, int g) {
     bool snapshot = false;
     if (best.sse != nullptr) {
         __shared__ float red[256];
@@ -177,6 +167,22 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
             }
         }
     }
+    return snapshot;
+}
+
+template <int KIND, bool FILL_NEXT, bool ADAN>
+__global__ __launch_bounds__(256) void train_reduce_update_kernel(
+    int n, TrainParams P, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
+    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
+    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
+#pragma clang fp contract(off)
+    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next iteration's tile order (gi2d_fast_internal.h)
+        compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);
+        return;
+    }
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool snapshot = best_decision(best, n, g);
     float acc[11];
     reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
                partial_g, partial_big, acc);
@@ -296,6 +302,378 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     }
 }
 
+
+// =====================================================================================================================
+// Quantisation-aware iteration: GaussianImage_Covariance.train_iter_quantize
+// (models/gaussianimage_covariance.py:219-247, forward_quantize :384-410) -- after train_quantize.py's warm-up the
+// positions go through an LSQ quantiser, the covariance rows through HybirdQuant (log quantiser on the variances,
+// LSQ on the covariance) and the colours through an LSQ quantiser before projection / rasterization, and the twelve
+// learned quantiser values (scale, beta per LSQ channel) are trained by their own Adam optimizers.
+//
+// Launches per iteration: project+fill on the quantised values, the tile pass (colours = dequantised colours), the
+// update kernel (gradient reduce, projection backward, quantiser backward, Adam on the gaussians, partial sums for
+// everything that needs a whole-array reduction) and one single-workgroup finish kernel that closes the reductions:
+//   * v_scale / v_beta of the six LSQ channels -> Adam on the quantiser values;
+//   * the log quantiser's range is min()/max() of the CURRENT variances and stays in the autograd graph, so the
+//     elements that attain the extremes receive sum-type gradients.  The update kernel cannot finish those elements
+//     (their gradient needs the global sums): it parks them in a short list and the finish kernel updates them;
+//   * the log range of the NEXT iteration (min / max / tie counts of the updated variances).
+struct QuantTrain {
+    float qmax_xy, qmax_cov, qmax_col;  // unsigned quantisers: qmin = 0
+    float *qparams;                     // [12] xy scale[2], xy beta[2], cov scale, cov beta, colour scale[3], colour beta[3]
+    float *qm, *qv;                     // [12] Adam moments of qparams
+    float *range;                       // [4] min log, max log, #elements at the min, #at the max (variance channels)
+    float *qfeat;                       // [N,3] dequantised colours
+    float *partial;                     // [blocks][GI2D_QT_ROW]
+    int32_t *defer;                     // [1 + 2*defer_cap]: count, then (flat index into chol, gradient bits)
+    int defer_cap;
+    float *best_q, *dbg_q;              // [12] snapshot of qparams / [16] gradients (tests), or null
+};
+#define GI2D_QT_ROW 24  // 12 LSQ sums, 2 log sums, next range (min, #min, max, #max), padding
+
+struct QuantVals {
+    float xs[2], xb[2], cs, cb, fs[3], fb[3];
+    float lbeta, lmax, lscale;
+};
+__device__ __forceinline__ QuantVals load_quant(const QuantTrain &Q) {
+    QuantVals v;
+    v.xs[0] = Q.qparams[0], v.xs[1] = Q.qparams[1], v.xb[0] = Q.qparams[2], v.xb[1] = Q.qparams[3];
+    v.cs = Q.qparams[4], v.cb = Q.qparams[5];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v.fs[q] = Q.qparams[6 + q], v.fb[q] = Q.qparams[9 + q];
+    v.lbeta = Q.range[0];
+    v.lmax = Q.range[1];
+    v.lscale = quant_log_scale(v.lbeta, v.lmax, 0.f, Q.qmax_cov);
+    return v;
+}
+
+struct QuantRow {
+    QuantEval xy[2], cov[3], col[3];
+    float covx[3];  // _cov2d + bound: what the covariance quantiser sees
+};
+__device__ __forceinline__ void quantise_row(const TrainParams &P, const QuantTrain &Q, const QuantVals &v, int g,
+                                             QuantRow &r) {
+    const float *bd = P.bound + (size_t)P.bound_stride * g;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) r.xy[q] = quant_eval<GI2D_QUANT_LSQ>(P.xyz[2 * g + q], v.xs[q], v.xb[q], 0.f, Q.qmax_xy);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.covx[q] = P.chol[3 * g + q] + bd[q];
+    r.cov[0] = quant_eval<GI2D_QUANT_LOG>(r.covx[0], v.lscale, v.lbeta, 0.f, Q.qmax_cov);
+    r.cov[1] = quant_eval<GI2D_QUANT_LSQ>(r.covx[1], v.cs, v.cb, 0.f, Q.qmax_cov);
+    r.cov[2] = quant_eval<GI2D_QUANT_LOG>(r.covx[2], v.lscale, v.lbeta, 0.f, Q.qmax_cov);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        r.col[q] = quant_eval<GI2D_QUANT_LSQ>(P.feat[3 * g + q], v.fs[q], v.fb[q], 0.f, Q.qmax_col);
+}
+
+__global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
+    int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
+    float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
+    int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors, int32_t *__restrict__ buckets,
+    int32_t *__restrict__ status) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        status[0] = 0;
+        status[1] = 0;
+        status[3] = 0;
+    }
+    if (g >= n) return;
+    const QuantVals v = load_quant(Q);
+    QuantRow r;
+    quantise_row(P, Q, v, g, r);
+    const float2 mean = make_float2(r.xy[0].dequant, r.xy[1].dequant);
+    const float par[3] = {r.cov[0].dequant, r.cov[1].dequant, r.cov[2].dequant};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) Q.qfeat[3 * g + q] = r.col[q].dequant;
+    const ProjOut o =
+        project_one<kCovariance>(0, clip_coe, &mean, par, nullptr, img_w, img_h, tiles_x, tiles_y, radius_clip);
+    xys[g] = o.xy;
+    radii[g] = o.radius;
+    conics[3 * g] = o.k0;
+    conics[3 * g + 1] = o.k1;
+    conics[3 * g + 2] = o.k2;
+    num_tiles_hit[g] = o.tiles_hit;
+    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
+        int mnx, mny, mxx, mxy;
+        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
+    }
+}
+
+// (min, count) / (max, count) combination: equal extremes add their counts
+__device__ __forceinline__ void range_min_combine(float &m, float &c, float m2, float c2) {
+    if (m2 < m) {
+        m = m2;
+        c = c2;
+    } else if (m2 == m) {
+        c += c2;
+    }
+}
+__device__ __forceinline__ void range_max_combine(float &m, float &c, float m2, float c2) {
+    if (m2 > m) {
+        m = m2;
+        c = c2;
+    } else if (m2 == m) {
+        c += c2;
+    }
+}
+__device__ __forceinline__ void wave_range_reduce(float &mn, float &cmn, float &mx, float &cmx) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float a = __shfl_xor(mn, d, 64), ac = __shfl_xor(cmn, d, 64);
+        const float b = __shfl_xor(mx, d, 64), bc = __shfl_xor(cmx, d, 64);
+        range_min_combine(mn, cmn, a, ac);
+        range_max_combine(mx, cmx, b, bc);
+    }
+}
+
+// Workgroup-level close of one partial row: sums[14] per lane in, row written by the first lanes.
+__device__ __forceinline__ void block_partial_row(float (&sums)[14], float mn, float cmn, float mx, float cmx,
+                                                  float *row) {
+    __shared__ float red[4][18];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = (int)blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) sums[k] = wave_sum(sums[k]);
+    wave_range_reduce(mn, cmn, mx, cmx);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 14; ++k) red[wave][k] = sums[k];
+        red[wave][14] = mn, red[wave][15] = cmn, red[wave][16] = mx, red[wave][17] = cmx;
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) {
+        float t = red[0][threadIdx.x];
+        for (int w = 1; w < waves; ++w) t += red[w][threadIdx.x];
+        row[threadIdx.x] = t;
+    } else if (threadIdx.x == 14) {
+        float a = red[0][14], ac = red[0][15], b = red[0][16], bc = red[0][17];
+        for (int w = 1; w < waves; ++w) {
+            range_min_combine(a, ac, red[w][14], red[w][15]);
+            range_max_combine(b, bc, red[w][16], red[w][17]);
+        }
+        row[14] = a, row[15] = ac, row[16] = b, row[17] = bc;
+    }
+}
+
+// Range of the variance channels of the current parameters (start of a call, after the host touched them)
+__global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainParams P, QuantTrain Q) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    float sums[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) sums[k] = 0.f;
+    float mn = INFINITY, cmn = 0.f, mx = -INFINITY, cmx = 0.f;
+    if (g < n) {
+        const float *bd = P.bound + (size_t)P.bound_stride * g;
+#pragma unroll
+        for (int q = 0; q < 3; q += 2) {
+            const float t = quant_log_of(P.chol[3 * g + q] + bd[q]);
+            range_min_combine(mn, cmn, t, 1.f);
+            range_max_combine(mx, cmx, t, 1.f);
+        }
+    }
+    block_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)blockIdx.x * GI2D_QT_ROW);
+}
+
+__global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
+    int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
+    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
+    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best,
+    int32_t *__restrict__ status) {
+#pragma clang fp contract(off)
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool snapshot = best_decision(best, n, g);
+    float acc[11];
+    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
+               partial_big, acc);
+    float sums[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) sums[k] = 0.f;
+    float mn = INFINITY, cmn = 0.f, mx = -INFINITY, cmx = 0.f;
+    if (g < n) {
+        const QuantVals v = load_quant(Q);
+        QuantRow qr;
+        quantise_row(P, Q, v, g, qr);
+        const float par[3] = {qr.cov[0].dequant, qr.cov[1].dequant, qr.cov[2].dequant};
+        ProjGrad r;
+        r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
+        r.v_mean = make_float2(0.f, 0.f);
+        if (radii[g] > 0) {
+            const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
+            const float vc[3] = {acc[2], acc[3], acc[4]};
+            r = project_bwd_one<kCovariance>(0, par, nullptr, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
+        }
+        // quantiser backward: sums[0..11] = (v_scale, v_beta) of xy.x, xy.y, cov, colour r, g, b; sums[12,13] = log
+        const float gx = quant_grad<GI2D_QUANT_LSQ>(qr.xy[0], r.v_mean.x, v.xs[0], sums[0], sums[1]);
+        const float gy = quant_grad<GI2D_QUANT_LSQ>(qr.xy[1], r.v_mean.y, v.xs[1], sums[2], sums[3]);
+        const float go[3] = {r.o0, r.o1, r.o2};
+        float gp[3];
+        gp[1] = quant_grad<GI2D_QUANT_LSQ>(qr.cov[1], go[1], v.cs, sums[4], sums[5]);
+        float gf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            gf[q] = quant_grad<GI2D_QUANT_LSQ>(qr.col[q], acc[5 + q], v.fs[q], sums[6 + 2 * q], sums[7 + 2 * q]);
+        bool parked[3] = {false, false, false};
+#pragma unroll
+        for (int q = 0; q < 3; q += 2) {
+            const float vt = quant_grad<GI2D_QUANT_LOG>(qr.cov[q], go[q], v.lscale, sums[12], sums[13]);
+            const float t = quant_log_of(qr.covx[q]);
+            gp[q] = vt * quant_log_chain(qr.covx[q]);
+            if (t == v.lbeta || t == v.lmax) {  // its gradient also needs the global sums: the finish kernel's job
+                parked[q] = true;
+                const int slot = atomicAdd(&Q.defer[0], 1);
+                if (slot < Q.defer_cap) {
+                    Q.defer[1 + 2 * slot] = 3 * g + q;
+                    Q.defer[2 + 2 * slot] = __float_as_int(vt);
+                } else {
+                    atomicOr(&status[2], 2);
+                }
+            }
+        }
+        if (dbg_grads) {
+            float *d = dbg_grads + 8 * (size_t)g;
+            d[0] = gx, d[1] = gy, d[2] = gp[0], d[3] = gp[1], d[4] = gp[2], d[5] = gf[0], d[6] = gf[1], d[7] = gf[2];
+        }
+        {
+            float m0 = P.m_xyz[2 * g], m1 = P.m_xyz[2 * g + 1], v0 = P.v_xyz[2 * g], v1 = P.v_xyz[2 * g + 1];
+            P.xyz[2 * g] = adam(P.xyz[2 * g], gx, m0, v0, a_xyz);
+            P.xyz[2 * g + 1] = adam(P.xyz[2 * g + 1], gy, m1, v1, a_xyz);
+            P.m_xyz[2 * g] = m0, P.m_xyz[2 * g + 1] = m1, P.v_xyz[2 * g] = v0, P.v_xyz[2 * g + 1] = v1;
+        }
+        const float *bd = P.bound + (size_t)P.bound_stride * g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (!parked[q]) {
+                float m = P.m_chol[3 * g + q], vv = P.v_chol[3 * g + q];
+                const float nv = adam(P.chol[3 * g + q], gp[q], m, vv, a_chol);
+                P.chol[3 * g + q] = nv;
+                P.m_chol[3 * g + q] = m;
+                P.v_chol[3 * g + q] = vv;
+                if (q != 1) {  // this variance's place in the NEXT iteration's log range
+                    const float t = quant_log_of(nv + bd[q]);
+                    range_min_combine(mn, cmn, t, 1.f);
+                    range_max_combine(mx, cmx, t, 1.f);
+                }
+            }
+            float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q];
+            P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
+            P.m_feat[3 * g + q] = mf;
+            P.v_feat[3 * g + q] = vf;
+        }
+        if (snapshot) {
+            best.xyz[2 * g] = P.xyz[2 * g];
+            best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                best.chol[3 * g + q] = P.chol[3 * g + q];  // parked entries are patched by the finish kernel
+                best.feat[3 * g + q] = P.feat[3 * g + q];
+                if (best.bound) best.bound[3 * g + q] = bd[q];
+            }
+        }
+    }
+    block_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)blockIdx.x * GI2D_QT_ROW);
+}
+
+// One workgroup closes the reductions of an iteration (RANGE_ONLY: just the log range, start of a call).
+template <bool RANGE_ONLY>
+__global__ __launch_bounds__(256) void train_quant_finish_kernel(int blocks, TrainParams P, QuantTrain Q,
+                                                                 AdamStep a_chol, AdamStep a_qxy, AdamStep a_qcov,
+                                                                 AdamStep a_qcol, float *__restrict__ dbg_grads,
+                                                                 BestSnap best) {
+#pragma clang fp contract(off)
+    __shared__ double dred[4][14];
+    __shared__ double tot[14];
+    __shared__ float rred[4][4];
+    __shared__ float ext[2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // next range from the partial rows
+    float mn = INFINITY, cmn = 0.f, mx = -INFINITY, cmx = 0.f;
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+        const float *row = Q.partial + (size_t)b * GI2D_QT_ROW;
+        range_min_combine(mn, cmn, row[14], row[15]);
+        range_max_combine(mx, cmx, row[16], row[17]);
+    }
+    if (!RANGE_ONLY) {
+        for (int k = 0; k < 14; ++k) {
+            double v = 0.0;
+            for (int b = threadIdx.x; b < blocks; b += 256) v += (double)Q.partial[(size_t)b * GI2D_QT_ROW + k];
+            v = wave_sum_d(v);
+            if (lane == 0) dred[wave][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 14) tot[threadIdx.x] = (dred[0][threadIdx.x] + dred[1][threadIdx.x]) +
+                                                 (dred[2][threadIdx.x] + dred[3][threadIdx.x]);
+        __syncthreads();
+        const bool snap = best.sse != nullptr && best.info[1] == best.step;
+        // Adam on the twelve quantiser values: qparams = xs[2] xb[2] cs cb fs[3] fb[3]; tot = (s,b) pairs per channel
+        if (threadIdx.x < 12) {
+            const int k = threadIdx.x;
+            // channel and which of (scale, beta) this slot is
+            int ch, isb;
+            if (k < 4) ch = k & 1, isb = k >> 1;
+            else if (k < 6) ch = 2, isb = k - 4;
+            else ch = 3 + (k - 6) % 3, isb = (k - 6) / 3;
+            const float grad = (float)tot[2 * ch + isb];
+            const AdamStep &a = k < 4 ? a_qxy : (k < 6 ? a_qcov : a_qcol);
+            float m = Q.qm[k], v = Q.qv[k];
+            const float nv = adam(Q.qparams[k], grad, m, v, a);
+            Q.qparams[k] = nv;
+            Q.qm[k] = m;
+            Q.qv[k] = v;
+            if (Q.dbg_q) Q.dbg_q[k] = grad;
+            if (snap && Q.best_q) Q.best_q[k] = nv;
+        }
+        // range gradient: scale = (max - beta)/Q is in the graph, so beta gets -v_scale/Q too and max +v_scale/Q,
+        // spread evenly over the elements that attain them
+        const double qrange = (double)Q.qmax_cov;
+        const float e_min = Q.range[2] > 0.f ? (float)((tot[13] - tot[12] / qrange) / (double)Q.range[2]) : 0.f;
+        const float e_max = Q.range[3] > 0.f ? (float)((tot[12] / qrange) / (double)Q.range[3]) : 0.f;
+        if (threadIdx.x == 0 && Q.dbg_q) {
+            Q.dbg_q[12] = (float)tot[12];
+            Q.dbg_q[13] = (float)tot[13];
+            Q.dbg_q[14] = e_min;
+            Q.dbg_q[15] = e_max;
+        }
+        const int parked = min(Q.defer[0], Q.defer_cap);
+        const float lbeta = Q.range[0], lmax = Q.range[1];
+        for (int e = threadIdx.x; e < parked; e += 256) {
+            const int idx = Q.defer[1 + 2 * e];
+            const float vt0 = __int_as_float(Q.defer[2 + 2 * e]);
+            const int g = idx / 3, q = idx - 3 * g;
+            const float bdq = P.bound[(size_t)P.bound_stride * g + q];
+            const float x = P.chol[idx] + bdq, t = quant_log_of(x);
+            float vt = vt0;
+            if (t == lbeta) vt = vt + e_min;
+            if (t == lmax) vt = vt + e_max;
+            const float gxv = vt * quant_log_chain(x);
+            float m = P.m_chol[idx], v = P.v_chol[idx];
+            const float nv = adam(P.chol[idx], gxv, m, v, a_chol);
+            P.chol[idx] = nv;
+            P.m_chol[idx] = m;
+            P.v_chol[idx] = v;
+            if (dbg_grads) dbg_grads[8 * (size_t)g + 2 + q] = gxv;
+            if (snap) best.chol[idx] = nv;
+            const float t2 = quant_log_of(nv + bdq);
+            range_min_combine(mn, cmn, t2, 1.f);
+            range_max_combine(mx, cmx, t2, 1.f);
+        }
+    }
+    wave_range_reduce(mn, cmn, mx, cmx);
+    if (lane == 0) rred[wave][0] = mn, rred[wave][1] = cmn, rred[wave][2] = mx, rred[wave][3] = cmx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = rred[0][0], ac = rred[0][1], b = rred[0][2], bc = rred[0][3];
+        for (int w = 1; w < 4; ++w) {
+            range_min_combine(a, ac, rred[w][0], rred[w][1]);
+            range_max_combine(b, bc, rred[w][2], rred[w][3]);
+        }
+        Q.range[0] = a, Q.range[1] = b, Q.range[2] = ac, Q.range[3] = bc;
+        Q.defer[0] = 0;
+    }
+    (void)ext;
+}
+
 }  // namespace gi2d
 
 using namespace gi2d;
@@ -364,6 +742,79 @@ static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w
                            s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
 }
 
+
+static AdamStep make_adam_step(double lr, double beta1, double beta2, double beta3, float eps, int step, bool adan_opt) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double bc3 = 1.0 - pow(beta3, (double)step);
+    AdamStep a;
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(adan_opt ? bc3 : bc2);
+    a.one_minus_b1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.one_minus_b2 = (float)(1.0 - beta2);
+    a.eps = eps;
+    a.b1 = (float)beta1;
+    a.b3 = (float)beta3;
+    a.one_minus_b3 = (float)(1.0 - beta3);
+    a.step_size_diff = (float)(lr * beta2 / bc2);
+    a.first = step == 1;
+    return a;
+}
+
+static int quant_of(const gi2d_train_state *s, QuantTrain &Q) {
+    const gi2d_train_quant *q = s->quant;
+    if (s->kind != 1 || s->optimizer != 0) {
+        set_error("train: quantisation is wired for the covariance model with Adam (train_quantize.py)");
+        return GI2D_ERR_UNSUPPORTED;
+    }
+    if (q->xy_bits < 1 || q->xy_bits > 16 || q->cov_bits < 1 || q->cov_bits > 16 || q->color_bits < 1 ||
+        q->color_bits > 16 || !q->qparams || !q->qm || !q->qv || !q->range || !q->qfeat || !q->partial || !q->defer ||
+        q->defer_capacity < 2) {
+        set_error("train: bad quantisation state");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    Q.qmax_xy = (float)((1 << q->xy_bits) - 1);
+    Q.qmax_cov = (float)((1 << q->cov_bits) - 1);
+    Q.qmax_col = (float)((1 << q->color_bits) - 1);
+    Q.qparams = q->qparams;
+    Q.qm = q->qm;
+    Q.qv = q->qv;
+    Q.range = q->range;
+    Q.qfeat = q->qfeat;
+    Q.partial = q->partial;
+    Q.defer = q->defer;
+    Q.defer_cap = q->defer_capacity;
+    Q.best_q = q->best_qparams;
+    Q.dbg_q = q->dbg_qgrads;
+    return GI2D_OK;
+}
+
+static BestSnap no_best() {
+    BestSnap b;
+    b.xyz = b.chol = b.feat = b.bound = b.sse = nullptr;
+    b.info = nullptr;
+    b.tile_sse = nullptr;
+    b.num_tiles = b.step = 0;
+    return b;
+}
+
+// log range of the current variances (2 launches), then activations/quantisers + projection + fill
+static void train_launch_quant_range(const gi2d_train_state *s, const TrainParams &P, const QuantTrain &Q,
+                                     hipStream_t st) {
+    const int n = s->num_points, bs = per_gaussian_block(n), blocks = (n + bs - 1) / bs;
+    const AdamStep z = make_adam_step(0.0, 0.9, 0.999, 0.0, 1.f, 1, false);
+    hipLaunchKernelGGL(train_quant_range_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q);
+    hipLaunchKernelGGL(train_quant_finish_kernel<true>, dim3(1), dim3(256), 0, st, blocks, P, Q, z, z, z, z,
+                       (float *)nullptr, no_best());
+}
+static void train_launch_project_fill_quant(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
+                                            const QuantTrain &Q, int tx, int ty, hipStream_t st) {
+    const int n = s->num_points, bs = per_gaussian_block(n);
+    hipLaunchKernelGGL(train_project_fill_quant_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P, Q,
+                       (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
+                       s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+}
+
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
 int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
     int tx, ty;
@@ -374,6 +825,16 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
     if (n == 0) return GI2D_OK;
     FastWs w = carve_fast(s->workspace, n, tx * ty);
     const TrainParams P = params_of(s);
+    if (s->quant) {  // forward_quantize (models/gaussianimage_covariance.py:384-410)
+        QuantTrain Q;
+        rc = quant_of(s, Q);
+        if (rc != GI2D_OK) return rc;
+        train_launch_quant_range(s, P, Q, st);
+        train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
+        return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
+                                           s->radii, s->conics, Q.qfeat, s->opacity, nullptr, s->workspace,
+                                           s->workspace_bytes, s->status, nullptr, nullptr, s->out_img, st_);
+    }
     train_launch_project_fill(s, w, P, tx, ty, st);
     return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys, s->radii,
                                        s->conics, s->feat, s->opacity, nullptr, s->workspace, s->workspace_bytes,
@@ -418,6 +879,41 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
         set_error("train steps: unknown optimizer, or Adan without its extra state (d_*, pg_*)");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
+    if (s->quant) {
+        QuantTrain Q;
+        rc = quant_of(s, Q);
+        if (rc != GI2D_OK) return rc;
+        const gi2d_train_quant *q = s->quant;
+        if (q->first_step < 1) {
+            set_error("train steps: quantiser optimizer step must be >= 1");
+            return GI2D_ERR_INVALID_ARGUMENT;
+        }
+        const int bs = per_gaussian_block(n), blocks = (n + bs - 1) / bs;
+        train_launch_quant_range(s, P, Q, st);
+        for (int it = 0; it < count; ++it) {
+            const int step = first_step + it, qstep = q->first_step + it;
+            train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
+            rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
+                                                      s->xys, s->radii, s->conics, Q.qfeat, s->opacity, nullptr,
+                                                      nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
+                                                      s->workspace_bytes, s->status, s->out_img, st_);
+            if (rc != GI2D_OK) return rc;
+            AdamStep a[3], aq[3];
+            for (int k = 0; k < 3; ++k) {
+                a[k] = make_adam_step(lr[k], beta1, beta2, 0.0, eps, step, false);
+                aq[k] = make_adam_step(q->lr[k], q->beta1, q->beta2, 0.0, q->eps[k], qstep, false);
+            }
+            best.step = step;
+            hipLaunchKernelGGL(train_reduce_update_quant_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
+                               (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
+                               s->radius_clip, (const int32_t *)w.gids_sorted, (const int2 *)w.tile_bins,
+                               (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
+                               (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, s->status);
+            hipLaunchKernelGGL(train_quant_finish_kernel<false>, dim3(1), dim3(256), 0, st, blocks, P, Q, a[1], aq[0],
+                               aq[1], aq[2], s->dbg_grads, best);
+        }
+        return check_launch("train steps (quantised)");
+    }
     NextFill next;
     next.clip_coe = s->clip_coe;
     next.num_tiles_hit = s->num_tiles_hit;
@@ -435,22 +931,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
                                                   grad_scale, s->tile_sse, s->workspace, s->workspace_bytes,
                                                   s->status, s->out_img, st_);
         if (rc != GI2D_OK) return rc;
-        const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-        const double bc3 = 1.0 - pow((double)s->beta3, (double)step);
         AdamStep a[3];
-        for (int q = 0; q < 3; ++q) {
-            a[q].step_size = (float)((double)lr[q] / bc1);
-            a[q].bc2_sqrt = (float)sqrt(adan_opt ? bc3 : bc2);
-            a[q].one_minus_b1 = (float)(1.0 - (double)beta1);
-            a[q].b2 = beta2;
-            a[q].one_minus_b2 = (float)(1.0 - (double)beta2);
-            a[q].eps = eps;
-            a[q].b1 = beta1;
-            a[q].b3 = s->beta3;
-            a[q].one_minus_b3 = (float)(1.0 - (double)s->beta3);
-            a[q].step_size_diff = (float)((double)lr[q] * (double)beta2 / bc2);
-            a[q].first = step == 1;
-        }
+        for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s->beta3, eps, step, adan_opt);
         best.step = step;
         const bool more = it + 1 < count;
 #define GI2D_LAUNCH_RU(K, F, A)                                                                                      \

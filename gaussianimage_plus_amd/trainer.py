@@ -53,6 +53,19 @@ class _TrainState(C.Structure):
         ("optimizer", C.c_int), ("beta3", C.c_float),
         ("d_xyz", C.c_void_p), ("d_chol", C.c_void_p), ("d_feat", C.c_void_p),
         ("pg_xyz", C.c_void_p), ("pg_chol", C.c_void_p), ("pg_feat", C.c_void_p),
+        ("quant", C.c_void_p),
+    ]
+
+
+class _TrainQuant(C.Structure):
+    """struct gi2d_train_quant (include/gi2d.h), field for field."""
+    _fields_ = [
+        ("xy_bits", C.c_int), ("cov_bits", C.c_int), ("color_bits", C.c_int), ("defer_capacity", C.c_int),
+        ("qparams", C.c_void_p), ("qm", C.c_void_p), ("qv", C.c_void_p), ("range", C.c_void_p),
+        ("qfeat", C.c_void_p), ("partial", C.c_void_p), ("defer", C.c_void_p),
+        ("best_qparams", C.c_void_p), ("dbg_qgrads", C.c_void_p),
+        ("lr", C.c_float * 3), ("eps", C.c_float * 3), ("beta1", C.c_float), ("beta2", C.c_float),
+        ("first_step", C.c_int), ("pad0", C.c_int),
     ]
 
 
@@ -167,7 +180,9 @@ class NativeFitter:
             bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)),
             1 if optimizer == "adan" else 0, self.betas[2] if optimizer == "adan" else 0.0,
             *[(p(getattr(self, nm)) if optimizer == "adan" else None)
-              for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")])
+              for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")], None)
+        self.quant = None        # _TrainQuant once enable_quantize() ran
+        self.opt_start = 0       # iteration at which the optimizer / StepLR of the gaussians was (re)created
         self._state_ref = C.byref(self.state)
         self._lr3 = (C.c_float * 3)()
         self._steps_fn = self.lib.gi2d_train_steps
@@ -201,7 +216,7 @@ class NativeFitter:
 
     def current_lr(self) -> float:
         """StepLR(step_size=lr_step, gamma=lr_gamma), stepped once per iteration after the optimizer."""
-        return self.lr * self.lr_gamma ** (self.iteration // self.lr_step)
+        return self.lr * self.lr_gamma ** ((self.iteration - self.opt_start) // self.lr_step)
 
     def train(self, iterations: int) -> None:
         """Run `iterations` training iterations (asynchronous: only kernel launches).  One C-ABI call per stretch
@@ -213,8 +228,15 @@ class NativeFitter:
             while left > 0:
                 lr = self.current_lr()
                 self._lr3[0] = self._lr3[1] = self._lr3[2] = lr
-                count = min(left, self.lr_step - self.iteration % self.lr_step, self.max_call)
-                rc = self._steps_fn(self._state_ref, self._lr3, b1, b2, self.eps, self.iteration + 1, count, st)
+                done = self.iteration - self.opt_start
+                count = min(left, self.lr_step - done % self.lr_step, self.max_call)
+                if self.quant is not None:  # the quantiser optimizers have their own StepLR (step 10000, gamma 0.5)
+                    qdone = self.iteration - self.quant_start
+                    count = min(count, self.q_lr_step - qdone % self.q_lr_step)
+                    qlr = self.q_lr * self.q_lr_gamma ** (qdone // self.q_lr_step)
+                    self.quant.lr[0] = self.quant.lr[1] = self.quant.lr[2] = qlr
+                    self.quant.first_step = qdone + 1
+                rc = self._steps_fn(self._state_ref, self._lr3, b1, b2, self.eps, done + 1, count, st)
                 if rc != 0:
                     self._check(rc, "gi2d_train_steps")
                 self.iteration += count
@@ -240,6 +262,9 @@ class NativeFitter:
         """Raises if any step since the last check overflowed a tile bucket (sticky flag status[2])."""
         now, sticky = self.status[1:3].tolist()
         self.status[2] = 0
+        if sticky & 2:
+            raise RuntimeError("more variances tie with an extreme of the log-quantiser range than the parking list "
+                               "holds; results invalid")
         if now or sticky:
             raise RuntimeError("a tile bucket overflowed (> 256 gaussians per (tile, id mod 4)); results invalid")
 
@@ -250,7 +275,7 @@ class NativeFitter:
         n_best, step = self.best_info.tolist()
         if step == 0:
             return None, 0, 0
-        sse = float(self.best_sse[(self.iteration + 1) & 1].item())
+        sse = float(self.best_sse[(self.iteration - self.opt_start + 1) & 1].item())
         return 10 * math.log10(1.0 / max(sse / (3.0 * self.h * self.w), 1e-12)), step, n_best
 
     def load_best(self):
@@ -263,6 +288,8 @@ class NativeFitter:
         self._feat[:n_best] = self.best_feat[:n_best]
         if self.per_point_bound:
             self._bound[:n_best] = self.best_bound[:n_best]
+        if self.quant is not None:  # the reference's state dict carries the quantisers' scale / beta
+            self.qparams.copy_(self.best_qparams)
         self._set_n(n_best)
         return psnr
 
@@ -313,6 +340,119 @@ class NativeFitter:
             self._bound[n0:n1] = torch.tensor([low_pass, 0.0, low_pass], device=self.dev)
         self._set_n(n1)
         return k
+
+    # ------------------------------------------------------------------ quantisation-aware phase (train_quantize.py)
+    def enable_quantize(self, xy_bit: int = 12, cov_bit: int = 10, color_bit: int = 6, lr: float = 1e-3,
+                        lr_step: int = 10000, lr_gamma: float = 0.5, debug_grads: bool = False,
+                        defer_capacity: int = 1024) -> None:
+        """What train_quantize.py does when its warm-up ends (:131-142, with training_setup(lr, update_optimizer=True,
+        quantize=True), models/gaussianimage_covariance.py:105-147): the gaussians' Adam is recreated with the current
+        learning rate (moments and step count start over, StepLR restarts), the best-PSNR tracking starts over, and
+        three quantisers with their own Adam optimizers (lr 1e-3, StepLR 10000 / 0.5; eps 1e-8 for the positions,
+        1e-15 for covariance and colour) are put in front of the projection.  Their scale / beta are initialised from
+        the current parameters (UniformQuantizer._init_data on the first forward).  From here on train() runs
+        train_iter_quantize iterations and render() is forward_quantize.  Call load_best() first to continue from the
+        best warm-up model as the reference does."""
+        assert self.kind == "covariance" and self.optimizer == "adam", "train_quantize.py uses the covariance model"
+        from . import quantize as qz
+        self.lr = self.current_lr()
+        self.opt_start = self.quant_start = self.iteration
+        self.eps = 1e-15  # training_setup: torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        for t in self._rows()[4:10]:
+            t.zero_()
+        if self.track_best:
+            self.best_sse.fill_(float("inf"))
+            self.best_info.zero_()
+        self.q_bits = (int(xy_bit), int(cov_bit), int(color_bit))
+        self.q_lr, self.q_lr_step, self.q_lr_gamma = float(lr), int(lr_step), float(lr_gamma)
+        dev, n = self.dev, self.n
+        f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        cov = self.chol + self.bound
+        px = qz._init_params(qz.make_spec([qz.LSQ] * 2, [0] * 2, [2 ** xy_bit - 1] * 2), self.xyz)
+        pc = qz._init_params(qz.make_spec([qz.LSQ], [0], [2 ** cov_bit - 1]), cov[:, 1:2].contiguous())
+        pf = qz._init_params(qz.make_spec([qz.LSQ] * 3, [0] * 3, [2 ** color_bit - 1] * 3), self.feat)
+        self.qparams = torch.cat([px[:, 0], px[:, 1], pc[0, :2], pf[:, 0], pf[:, 1]]).contiguous()
+        self.qm, self.qv, self.qrange = f32(12), f32(12), f32(4)
+        self.qfeat = f32(self.cap, 3)
+        self.qpartial = f32(((self.cap + 63) // 64 + 1) * 24)
+        self.qdefer = torch.zeros(1 + 2 * defer_capacity, dtype=torch.int32, device=dev)
+        self.best_qparams = self.qparams.clone()
+        self.dbg_qgrads = f32(16) if debug_grads else None
+        p = lambda t: t.data_ptr()
+        q = _TrainQuant(int(xy_bit), int(cov_bit), int(color_bit), int(defer_capacity), p(self.qparams), p(self.qm),
+                        p(self.qv), p(self.qrange), p(self.qfeat), p(self.qpartial), p(self.qdefer),
+                        p(self.best_qparams), p(self.dbg_qgrads) if debug_grads else None)
+        q.eps[0], q.eps[1], q.eps[2] = 1e-8, 1e-15, 1e-15
+        q.beta1, q.beta2 = 0.9, 0.999
+        q.first_step = 1
+        self.quant = q
+        self.state.quant = C.addressof(q)
+
+    def quantizers(self):
+        """The three quantisers as modules of gaussianimage_plus_amd.quantize carrying the trained scale / beta
+        (the objects GaussianImage_Covariance keeps as xyz_quantizer / cholesky_quantizer / features_dc_quantizer)."""
+        from . import quantize as qz
+        xy_bit, cov_bit, color_bit = self.q_bits
+        qp = self.qparams
+        xyq = qz.UniformQuantizer(signed=False, bits=xy_bit, learned=True, num_channels=2).to(self.dev)
+        xyq.scale.data, xyq.beta.data, xyq.init_state = qp[0:2].clone(), qp[2:4].clone(), 1
+        cq = qz.HybirdQuant(signed=False, bits=cov_bit, cov_bits=cov_bit, learned=True, weight=1.0).to(self.dev)
+        cq.cov_quantizer.scale.data, cq.cov_quantizer.beta.data = qp[4:5].clone(), qp[5:6].clone()
+        cq.init_state = cq.cov_quantizer.init_state = 1
+        fq = qz.UniformQuantizer(signed=False, bits=color_bit, learned=True, num_channels=3).to(self.dev)
+        fq.scale.data, fq.beta.data, fq.init_state = qp[6:9].clone(), qp[9:12].clone(), 1
+        return xyq, cq, fq
+
+    def compress_wo_ec(self) -> Dict[str, torch.Tensor]:
+        """models/gaussianimage_covariance.py:412-443: integer codes of every attribute; gaussians whose covariance
+        is not positive definite AFTER quantisation are dropped from the encoding (and from the model)."""
+        assert self.quant is not None
+        xyq, cq, fq = self.quantizers()
+        with torch.no_grad():
+            means, quant_means = xyq.compress(self.xyz)
+            cov, quant_cov = cq.compress(self.chol + self.bound)
+            colors, color_index = fq.compress(self.feat)
+            valid = positive_definite_mask(cov)
+            to_prune = self.n - int(valid.sum().item())
+            if to_prune:
+                means, quant_means, quant_cov, color_index = means[valid], quant_means[valid], quant_cov[valid], \
+                    color_index[valid]
+                keep = self.n - to_prune
+                for t in self._rows():
+                    t[:keep] = t[:self.n][valid]
+                self._set_n(keep)
+        self._codec = (xyq, cq, fq)
+        return {"xyz": means, "feature_dc_index": color_index, "quant_cholesky_elements": quant_cov,
+                "quant_means": quant_means}
+
+    def decompress_wo_ec(self, encoding: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """models/gaussianimage_covariance.py:445-467: render from the codes; returns clamp(out, 0, 1) as [H, W, 3]."""
+        from .gsplat.project_gaussians_2d_covariance import project_gaussians_2d_covariance
+        from .gsplat.rasterize_sum_plus import rasterize_gaussians_plus
+        _, cq, fq = self._codec
+        with torch.no_grad():
+            means = encoding["xyz"]
+            cov = cq.decompress(encoding["quant_cholesky_elements"])
+            colors = fq.decompress(encoding["feature_dc_index"])
+            tile_bounds = (self.tx, self.ty, 1)
+            xys, depths, radii, conics, nth = project_gaussians_2d_covariance(
+                means, cov, self.h, self.w, tile_bounds, clip_coe=self.state.clip_coe,
+                radius_clip=self.state.radius_clip)
+            opacity = torch.ones(means.shape[0], 1, device=self.dev)
+            out = rasterize_gaussians_plus(xys, depths, radii, conics, nth, colors, opacity, self.h, self.w, 16, 16,
+                                           radius_clip=self.state.radius_clip)
+        return out.clamp(0, 1)
+
+    def analysis_wo_ec(self, encoding: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        """models/gaussianimage_covariance.py:469-509, lsq branches: fixed-length code sizes plus the quantisers' side
+        information, in bits per pixel."""
+        xy_bit, cov_bit, color_bit = self.q_bits
+        hw = self.h * self.w
+        chol_bits = encoding["quant_cholesky_elements"].numel() * ((cov_bit + cov_bit * 2) / 3) + 32 * 3 * 2
+        feat_bits = encoding["feature_dc_index"].numel() * color_bit + 32 * 3 * 2
+        pos_bits = encoding["xyz"].numel() * xy_bit + 32 * 2 * 2
+        return {"bpp": (pos_bits + chol_bits + feat_bits) / hw, "position_bpp": pos_bits / hw,
+                "cholesky_bpp": chol_bits / hw, "feature_dc_bpp": feat_bits / hw}
 
     def fit_schedule(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
                      max_points: Optional[int] = None, log=None, chunk: Optional[int] = None):

@@ -378,7 +378,40 @@ typedef struct gi2d_train_state {
     int optimizer;
     float beta3;
     float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
+    /* quantisation-aware iterations (NULL = off): see gi2d_train_quant below */
+    const struct gi2d_train_quant *quant;
 } gi2d_train_state;
+
+/* Quantisation-aware fitting (covariance model, kind 1, Adam): GaussianImage_Covariance.
+ * train_iter_quantize / forward_quantize (models/gaussianimage_covariance.py:219-247,384-410) after
+ * train_quantize.py's warm-up -- positions through a 2-channel LSQ quantiser (xy_bits), covariance rows through
+ * HybirdQuant (log quantiser on the variances, LSQ on the covariance, both cov_bits), colours through a 3-channel LSQ
+ * quantiser (color_bits) ahead of the projection, all with straight-through rounding; the twelve learned quantiser
+ * values are trained by their own Adam optimizers (lr/eps per quantiser: xy, covariance, colour).  An iteration is
+ * four launches: quantise+project+fill, the tile pass, reduce + projection backward + quantiser backward + Adam on
+ * the gaussians, and a one-workgroup kernel that closes the whole-array reductions (v_scale / v_beta of the LSQ
+ * channels, the gradient that reaches the extremes of the log range, the range of the next iteration).
+ *   qparams f32[12]  xy scale[2], xy beta[2], cov scale, cov beta, colour scale[3], colour beta[3]   updated in place
+ *   qm, qv  f32[12]  their Adam moments
+ *   range   f32[4]   scratch: log range of the variances (maintained by the calls)
+ *   qfeat   f32[N,3] dequantised colours of the last render
+ *   partial f32[(ceil(N/64) + 1) * 24] scratch;  defer i32[1 + 2*defer_capacity] scratch, zero-initialised by the
+ *           caller: variances that tie with an extreme of the log range wait here for the global sums (more than
+ *           defer_capacity of them in one step sets bit 1 of status[2])
+ *   best_qparams f32[12] or NULL: snapshot of qparams taken with the best-model snapshot
+ *   dbg_qgrads f32[16] or NULL: gradients of qparams (same order), then the log quantiser's v_scale, v_beta and the
+ *           per-element range gradients at the minimum / maximum (tests)
+ *   lr, eps (host) per quantiser optimizer; beta1, beta2; first_step = their 1-based Adam step of the call's first
+ *           iteration. */
+typedef struct gi2d_train_quant {
+    int xy_bits, cov_bits, color_bits, defer_capacity;
+    float *qparams, *qm, *qv, *range, *qfeat, *partial;
+    int32_t *defer;
+    float *best_qparams, *dbg_qgrads;
+    float lr[3], eps[3];
+    float beta1, beta2;
+    int first_step, pad0;
+} gi2d_train_quant;
 int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
 int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
                     float eps, int step, gi2d_stream_t stream);
