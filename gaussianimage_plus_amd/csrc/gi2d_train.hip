@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
 //   * v_scale / v_beta of the six LSQ channels -> Adam on the quantiser values;
 //   * the log quantiser's range is min()/max() of the CURRENT variances and stays in the autograd graph, so the
 //     elements that attain the extremes receive sum-type gradients.  The update kernel cannot finish those elements
-//     (their gradient needs the global sums): it parks them in a short list and the finish kernel updates them;
+//     (their gradient needs the global sums) in its main pass: it parks them in a short list for the closing step;
 //   * the log range of the NEXT iteration (min / max / tie counts of the updated variances).
 struct QuantTrain {
     float qmax_xy, qmax_cov, qmax_col;  // unsigned quantisers: qmin = 0
@@ -325,7 +325,8 @@ struct QuantTrain {
     float *range;                       // [4] min log, max log, #elements at the min, #at the max (variance channels)
     float *qfeat;                       // [N,3] dequantised colours
     float *partial;                     // [blocks][GI2D_QT_ROW]
-    int32_t *defer;                     // [1 + 2*defer_cap]: count, then (flat index into chol, gradient bits)
+    int32_t *defer;                     // [8 + 8*defer_cap]: count, then 32-byte entries (flat index into chol,
+                                        // gradient, parameter, Adam moments, bound)
     int defer_cap;
     float *best_q, *dbg_q;              // [12] snapshot of qparams / [16] gradients (tests), or null
 };
@@ -455,6 +456,150 @@ __device__ __forceinline__ void block_partial_row(float (&sums)[14], float mn, f
     }
 }
 
+// Closes the reductions of an iteration (RANGE_ONLY: just the log range, start of a call); one workgroup of any size
+// that is a multiple of 64 up to 256.
+template <bool RANGE_ONLY>
+__device__ __forceinline__ void quant_finish(int blocks, const TrainParams &P, const QuantTrain &Q,
+                                             const AdamStep &a_chol, const AdamStep &a_qxy, const AdamStep &a_qcov,
+                                             const AdamStep &a_qcol, float *__restrict__ dbg_grads,
+                                             const BestSnap &best) {
+#pragma clang fp contract(off)
+    __shared__ double lane_acc[RANGE_ONLY ? 1 : 256][15];  // 15: odd stride in 8-byte words
+    __shared__ double dred[16][16];
+    __shared__ double tot[14];
+    __shared__ float rred[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = (int)blockDim.x >> 6;
+    float mn = INFINITY, cmn = 0.f, mx = -INFINITY, cmx = 0.f;
+    // Everything that does not depend on the sums is fetched first, so the dependent load chains (parking list ->
+    // entry -> its parameter / moments / bound; quantiser values and their moments) overlap the partial-row pass.
+    int parked = 0, idx = 0, pg = 0, pq = 0;
+    float vt0 = 0.f, p_chol = 0.f, p_m = 0.f, p_v = 0.f, p_bd = 0.f;
+    float q_p = 0.f, q_m = 0.f, q_v = 0.f, lbeta = 0.f, lmax = 0.f, n_min = 0.f, n_max = 0.f;
+    bool snap = false;
+    if (!RANGE_ONLY) {
+        // the first round of parked entries is read before the count is known (slots past the count hold stale
+        // data that is never used), so count, entries, quantiser values and partial rows are ONE round of loads
+        if ((int)threadIdx.x < Q.defer_cap) {
+            const float4 *e = reinterpret_cast<const float4 *>(Q.defer + 8 + 8 * threadIdx.x);
+            const float4 e0 = e[0], e1 = e[1];
+            idx = __float_as_int(e0.x), vt0 = e0.y, p_chol = e0.z, p_m = e0.w, p_v = e1.x, p_bd = e1.y;
+        }
+        parked = min(Q.defer[0], Q.defer_cap);
+        if (threadIdx.x < 12) q_p = Q.qparams[threadIdx.x], q_m = Q.qm[threadIdx.x], q_v = Q.qv[threadIdx.x];
+        lbeta = Q.range[0], lmax = Q.range[1], n_min = Q.range[2], n_max = Q.range[3];
+        snap = best.sse != nullptr && best.info[1] == best.step;
+    }
+    // one pass over the partial rows, whole rows per lane (five 16-byte loads in flight), sums in double
+    double acc[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += (int)blockDim.x) {
+        const float4 *row = reinterpret_cast<const float4 *>(Q.partial + (size_t)b * GI2D_QT_ROW);
+        float4 r[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) r[k] = row[k];
+        const float *f = reinterpret_cast<const float *>(r);
+        if (!RANGE_ONLY) {
+#pragma unroll
+            for (int k = 0; k < 14; ++k) acc[k] += (double)f[k];
+        }
+        range_min_combine(mn, cmn, f[14], f[15]);
+        range_max_combine(mx, cmx, f[16], f[17]);
+    }
+    if (!RANGE_ONLY) {
+        // cross-lane sums through LDS in two 16-way steps (fourteen 6-step double shuffle chains cost 4 us here)
+#pragma unroll
+        for (int k = 0; k < 14; ++k) lane_acc[threadIdx.x][k] = acc[k];
+        __syncthreads();
+        const int k = threadIdx.x & 15, j = threadIdx.x >> 4, nj = (int)blockDim.x >> 4;
+        if (k < 14) {
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) part += lane_acc[j * 16 + i][k];
+            dred[j][k] = part;
+        }
+        __syncthreads();
+        if (threadIdx.x < 14) {
+            double t = dred[0][threadIdx.x];
+            for (int w = 1; w < nj; ++w) t += dred[w][threadIdx.x];
+            tot[threadIdx.x] = t;
+        }
+        __syncthreads();
+        // Adam on the twelve quantiser values: qparams = xs[2] xb[2] cs cb fs[3] fb[3]; tot = (s,b) pairs per channel
+        if (threadIdx.x < 12) {
+            const int k = threadIdx.x;
+            int ch, isb;  // channel and which of (scale, beta) this slot is
+            if (k < 4) ch = k & 1, isb = k >> 1;
+            else if (k < 6) ch = 2, isb = k - 4;
+            else ch = 3 + (k - 6) % 3, isb = (k - 6) / 3;
+            const float grad = (float)tot[2 * ch + isb];
+            const AdamStep &a = k < 4 ? a_qxy : (k < 6 ? a_qcov : a_qcol);
+            const float nv = adam(q_p, grad, q_m, q_v, a);
+            Q.qparams[k] = nv;
+            Q.qm[k] = q_m;
+            Q.qv[k] = q_v;
+            if (Q.dbg_q) Q.dbg_q[k] = grad;
+            if (snap && Q.best_q) Q.best_q[k] = nv;
+        }
+        // range gradient: scale = (max - beta)/Q is in the graph, so beta gets -v_scale/Q too and max +v_scale/Q,
+        // spread evenly over the elements that attain them
+        const double qrange = (double)Q.qmax_cov;
+        const float e_min = n_min > 0.f ? (float)((tot[13] - tot[12] / qrange) / (double)n_min) : 0.f;
+        const float e_max = n_max > 0.f ? (float)((tot[12] / qrange) / (double)n_max) : 0.f;
+        if (threadIdx.x == 0 && Q.dbg_q) {
+            Q.dbg_q[12] = (float)tot[12];
+            Q.dbg_q[13] = (float)tot[13];
+            Q.dbg_q[14] = e_min;
+            Q.dbg_q[15] = e_max;
+        }
+        for (int e = threadIdx.x; e < parked; e += (int)blockDim.x) {
+            if (e >= (int)blockDim.x) {  // beyond the prefetched first round (rare: more parked entries than lanes)
+                const float4 *en = reinterpret_cast<const float4 *>(Q.defer + 8 + 8 * e);
+                const float4 e0 = en[0], e1 = en[1];
+                idx = __float_as_int(e0.x), vt0 = e0.y, p_chol = e0.z, p_m = e0.w, p_v = e1.x, p_bd = e1.y;
+            }
+            pg = idx / 3, pq = idx - 3 * pg;
+            const float x = p_chol + p_bd, t = quant_log_of(x);
+            float vt = vt0;
+            if (t == lbeta) vt = vt + e_min;
+            if (t == lmax) vt = vt + e_max;
+            const float gxv = vt * quant_log_chain(x);
+            const float nv = adam(p_chol, gxv, p_m, p_v, a_chol);
+            P.chol[idx] = nv;
+            P.m_chol[idx] = p_m;
+            P.v_chol[idx] = p_v;
+            if (dbg_grads) dbg_grads[8 * (size_t)pg + 2 + pq] = gxv;
+            if (snap) best.chol[idx] = nv;
+            const float t2 = quant_log_of(nv + p_bd);
+            range_min_combine(mn, cmn, t2, 1.f);
+            range_max_combine(mx, cmx, t2, 1.f);
+        }
+    }
+    wave_range_reduce(mn, cmn, mx, cmx);
+    if (lane == 0) rred[wave][0] = mn, rred[wave][1] = cmn, rred[wave][2] = mx, rred[wave][3] = cmx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = rred[0][0], ac = rred[0][1], b = rred[0][2], bc = rred[0][3];
+        for (int w = 1; w < waves; ++w) {
+            range_min_combine(a, ac, rred[w][0], rred[w][1]);
+            range_max_combine(b, bc, rred[w][2], rred[w][3]);
+        }
+        Q.range[0] = a, Q.range[1] = b, Q.range[2] = ac, Q.range[3] = bc;
+        Q.defer[0] = 0;
+    }
+}
+
+// A launch of its own (one workgroup).  Running it in the last workgroup of the producing kernel instead (ticket +
+// device-scope fences) was measured and dropped: on this 8-XCD part every workgroup's release fence writes its L2
+// back, which made the update kernel 17 us slower to save a 4 us launch.
+template <bool RANGE_ONLY>
+__global__ __launch_bounds__(256) void train_quant_finish_kernel(int blocks, TrainParams P, QuantTrain Q,
+                                                                 AdamStep a_chol, AdamStep a_qxy, AdamStep a_qcov,
+                                                                 AdamStep a_qcol, float *__restrict__ dbg_grads,
+                                                                 BestSnap best) {
+    quant_finish<RANGE_ONLY>(blocks, P, Q, a_chol, a_qxy, a_qcov, a_qcol, dbg_grads, best);
+}
+
 // Range of the variance channels of the current parameters (start of a call, after the host touched them)
 __global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainParams P, QuantTrain Q) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,9 +668,10 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
             if (t == v.lbeta || t == v.lmax) {  // its gradient also needs the global sums: the finish kernel's job
                 parked[q] = true;
                 const int slot = atomicAdd(&Q.defer[0], 1);
-                if (slot < Q.defer_cap) {
-                    Q.defer[1 + 2 * slot] = 3 * g + q;
-                    Q.defer[2 + 2 * slot] = __float_as_int(vt);
+                if (slot < Q.defer_cap) {  // the entry carries its operands: one load round in the finish kernel
+                    float4 *e = reinterpret_cast<float4 *>(Q.defer + 8 + 8 * slot);
+                    e[0] = make_float4(__int_as_float(3 * g + q), vt, P.chol[3 * g + q], P.m_chol[3 * g + q]);
+                    e[1] = make_float4(P.v_chol[3 * g + q], P.bound[(size_t)P.bound_stride * g + q], 0.f, 0.f);
                 } else {
                     atomicOr(&status[2], 2);
                 }
@@ -573,105 +719,6 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
         }
     }
     block_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)blockIdx.x * GI2D_QT_ROW);
-}
-
-// One workgroup closes the reductions of an iteration (RANGE_ONLY: just the log range, start of a call).
-template <bool RANGE_ONLY>
-__global__ __launch_bounds__(256) void train_quant_finish_kernel(int blocks, TrainParams P, QuantTrain Q,
-                                                                 AdamStep a_chol, AdamStep a_qxy, AdamStep a_qcov,
-                                                                 AdamStep a_qcol, float *__restrict__ dbg_grads,
-                                                                 BestSnap best) {
-#pragma clang fp contract(off)
-    __shared__ double dred[4][14];
-    __shared__ double tot[14];
-    __shared__ float rred[4][4];
-    __shared__ float ext[2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // next range from the partial rows
-    float mn = INFINITY, cmn = 0.f, mx = -INFINITY, cmx = 0.f;
-    for (int b = threadIdx.x; b < blocks; b += 256) {
-        const float *row = Q.partial + (size_t)b * GI2D_QT_ROW;
-        range_min_combine(mn, cmn, row[14], row[15]);
-        range_max_combine(mx, cmx, row[16], row[17]);
-    }
-    if (!RANGE_ONLY) {
-        for (int k = 0; k < 14; ++k) {
-            double v = 0.0;
-            for (int b = threadIdx.x; b < blocks; b += 256) v += (double)Q.partial[(size_t)b * GI2D_QT_ROW + k];
-            v = wave_sum_d(v);
-            if (lane == 0) dred[wave][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 14) tot[threadIdx.x] = (dred[0][threadIdx.x] + dred[1][threadIdx.x]) +
-                                                 (dred[2][threadIdx.x] + dred[3][threadIdx.x]);
-        __syncthreads();
-        const bool snap = best.sse != nullptr && best.info[1] == best.step;
-        // Adam on the twelve quantiser values: qparams = xs[2] xb[2] cs cb fs[3] fb[3]; tot = (s,b) pairs per channel
-        if (threadIdx.x < 12) {
-            const int k = threadIdx.x;
-            // channel and which of (scale, beta) this slot is
-            int ch, isb;
-            if (k < 4) ch = k & 1, isb = k >> 1;
-            else if (k < 6) ch = 2, isb = k - 4;
-            else ch = 3 + (k - 6) % 3, isb = (k - 6) / 3;
-            const float grad = (float)tot[2 * ch + isb];
-            const AdamStep &a = k < 4 ? a_qxy : (k < 6 ? a_qcov : a_qcol);
-            float m = Q.qm[k], v = Q.qv[k];
-            const float nv = adam(Q.qparams[k], grad, m, v, a);
-            Q.qparams[k] = nv;
-            Q.qm[k] = m;
-            Q.qv[k] = v;
-            if (Q.dbg_q) Q.dbg_q[k] = grad;
-            if (snap && Q.best_q) Q.best_q[k] = nv;
-        }
-        // range gradient: scale = (max - beta)/Q is in the graph, so beta gets -v_scale/Q too and max +v_scale/Q,
-        // spread evenly over the elements that attain them
-        const double qrange = (double)Q.qmax_cov;
-        const float e_min = Q.range[2] > 0.f ? (float)((tot[13] - tot[12] / qrange) / (double)Q.range[2]) : 0.f;
-        const float e_max = Q.range[3] > 0.f ? (float)((tot[12] / qrange) / (double)Q.range[3]) : 0.f;
-        if (threadIdx.x == 0 && Q.dbg_q) {
-            Q.dbg_q[12] = (float)tot[12];
-            Q.dbg_q[13] = (float)tot[13];
-            Q.dbg_q[14] = e_min;
-            Q.dbg_q[15] = e_max;
-        }
-        const int parked = min(Q.defer[0], Q.defer_cap);
-        const float lbeta = Q.range[0], lmax = Q.range[1];
-        for (int e = threadIdx.x; e < parked; e += 256) {
-            const int idx = Q.defer[1 + 2 * e];
-            const float vt0 = __int_as_float(Q.defer[2 + 2 * e]);
-            const int g = idx / 3, q = idx - 3 * g;
-            const float bdq = P.bound[(size_t)P.bound_stride * g + q];
-            const float x = P.chol[idx] + bdq, t = quant_log_of(x);
-            float vt = vt0;
-            if (t == lbeta) vt = vt + e_min;
-            if (t == lmax) vt = vt + e_max;
-            const float gxv = vt * quant_log_chain(x);
-            float m = P.m_chol[idx], v = P.v_chol[idx];
-            const float nv = adam(P.chol[idx], gxv, m, v, a_chol);
-            P.chol[idx] = nv;
-            P.m_chol[idx] = m;
-            P.v_chol[idx] = v;
-            if (dbg_grads) dbg_grads[8 * (size_t)g + 2 + q] = gxv;
-            if (snap) best.chol[idx] = nv;
-            const float t2 = quant_log_of(nv + bdq);
-            range_min_combine(mn, cmn, t2, 1.f);
-            range_max_combine(mx, cmx, t2, 1.f);
-        }
-    }
-    wave_range_reduce(mn, cmn, mx, cmx);
-    if (lane == 0) rred[wave][0] = mn, rred[wave][1] = cmn, rred[wave][2] = mx, rred[wave][3] = cmx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = rred[0][0], ac = rred[0][1], b = rred[0][2], bc = rred[0][3];
-        for (int w = 1; w < 4; ++w) {
-            range_min_combine(a, ac, rred[w][0], rred[w][1]);
-            range_max_combine(b, bc, rred[w][2], rred[w][3]);
-        }
-        Q.range[0] = a, Q.range[1] = b, Q.range[2] = ac, Q.range[3] = bc;
-        Q.defer[0] = 0;
-    }
-    (void)ext;
 }
 
 }  // namespace gi2d
@@ -789,23 +836,19 @@ static int quant_of(const gi2d_train_state *s, QuantTrain &Q) {
     return GI2D_OK;
 }
 
-static BestSnap no_best() {
-    BestSnap b;
-    b.xyz = b.chol = b.feat = b.bound = b.sse = nullptr;
-    b.info = nullptr;
-    b.tile_sse = nullptr;
-    b.num_tiles = b.step = 0;
-    return b;
-}
-
-// log range of the current variances (2 launches), then activations/quantisers + projection + fill
+// log range of the current variances, then activations/quantisers + projection + fill
 static void train_launch_quant_range(const gi2d_train_state *s, const TrainParams &P, const QuantTrain &Q,
                                      hipStream_t st) {
     const int n = s->num_points, bs = per_gaussian_block(n), blocks = (n + bs - 1) / bs;
     const AdamStep z = make_adam_step(0.0, 0.9, 0.999, 0.0, 1.f, 1, false);
+    BestSnap nb;
+    nb.xyz = nb.chol = nb.feat = nb.bound = nb.sse = nullptr;
+    nb.info = nullptr;
+    nb.tile_sse = nullptr;
+    nb.num_tiles = nb.step = 0;
     hipLaunchKernelGGL(train_quant_range_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q);
     hipLaunchKernelGGL(train_quant_finish_kernel<true>, dim3(1), dim3(256), 0, st, blocks, P, Q, z, z, z, z,
-                       (float *)nullptr, no_best());
+                       (float *)nullptr, nb);
 }
 static void train_launch_project_fill_quant(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
                                             const QuantTrain &Q, int tx, int ty, hipStream_t st) {

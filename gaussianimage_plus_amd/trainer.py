@@ -375,7 +375,7 @@ class NativeFitter:
         self.qm, self.qv, self.qrange = f32(12), f32(12), f32(4)
         self.qfeat = f32(self.cap, 3)
         self.qpartial = f32(((self.cap + 63) // 64 + 1) * 24)
-        self.qdefer = torch.zeros(1 + 2 * defer_capacity, dtype=torch.int32, device=dev)
+        self.qdefer = torch.zeros(8 + 8 * defer_capacity, dtype=torch.int32, device=dev)
         self.best_qparams = self.qparams.clone()
         self.dbg_qgrads = f32(16) if debug_grads else None
         p = lambda t: t.data_ptr()

@@ -395,7 +395,7 @@ typedef struct gi2d_train_state {
  *   qm, qv  f32[12]  their Adam moments
  *   range   f32[4]   scratch: log range of the variances (maintained by the calls)
  *   qfeat   f32[N,3] dequantised colours of the last render
- *   partial f32[(ceil(N/64) + 1) * 24] scratch;  defer i32[1 + 2*defer_capacity] scratch, zero-initialised by the
+ *   partial f32[(ceil(N/64) + 1) * 24] scratch;  defer i32[8 + 8*defer_capacity] scratch (32-byte aligned), zero-initialised by the
  *           caller: variances that tie with an extreme of the log range wait here for the global sums (more than
  *           defer_capacity of them in one step sets bit 1 of status[2])
  *   best_qparams f32[12] or NULL: snapshot of qparams taken with the best-model snapshot
