@@ -71,26 +71,36 @@ def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, floa
 def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: int, lr: float = 1e-3,
                       seed: int = 3047, eval_renders: int = 10, kind: str = "cholesky", max_points: int = 0,
                       prune_iter: int = 100, grow_iter: int = 5000, eps: float = 1e-8,
-                      chunk: int = 16, optimizer: str = "adam") -> List[Dict[str, float]]:
+                      chunk: int = 16, optimizer: str = "adam", quantize: bool = False, warmup_iter: int = 6000,
+                      bits=(12, 10, 6)) -> List[Dict[str, float]]:
     """Fit the images of `gts` CONCURRENTLY on one GPU, one HIP stream each, on the fused training iteration
     (trainer.NativeFitter -> gi2d_train_step: one C-ABI call, three kernel launches, no host synchronisation per
     iteration).  One image's kernels leave most of the chip idle between their dependent phases, so
     two to four independent images per GPU raise the aggregate iteration rate by 1.4-1.8x; `chunk` iterations of
     one image are enqueued before the host turns to the next.  With `max_points` > `num_points` (covariance model)
     each image runs the adaptive loop of train.py:120-160: prune every `prune_iter`, grow every `grow_iter`, keep
-    the best model on the device and evaluate that one.  `train_s` is the wall time of the whole group."""
+    the best model on the device and evaluate that one.  `train_s` is the wall time of the whole group.
+    With `quantize` (covariance model) the loop is train_quantize.py's: plain fitting up to `warmup_iter`, then
+    quantisation-aware iterations with `bits` = (xy, covariance, colour) bit depths; the result rows then also carry
+    the size of the encoding in bits per pixel (analysis_wo_ec) and the PSNR of the decoded image."""
     from .trainer import NativeFitter
 
     dev = gts[0].device
     adaptive = kind == "covariance" and max_points > num_points
+    if quantize and kind != "covariance":
+        raise ValueError("quantisation-aware fitting is wired for the covariance model (train_quantize.py)")
     fitters = [NativeFitter(gt, num_points, kind=kind, lr=lr, seed=seed, eps=eps, optimizer=optimizer,
-                            max_points=max_points if adaptive else None, track_best=adaptive) for gt in gts]
+                            max_points=max_points if adaptive else None, track_best=adaptive or quantize)
+               for gt in gts]
     streams = [torch.cuda.Stream(device=dev) for _ in fitters] if len(fitters) > 1 else [torch.cuda.current_stream(dev)]
     torch.cuda.synchronize(dev)
     t0 = time.time()
-    runs = [f.fit_schedule(iterations, prune_iter=prune_iter, grow_iter=grow_iter, adaptive_add=adaptive,
-                           max_points=max_points if adaptive else None, chunk=chunk if len(fitters) > 1 else None)
-            for f in fitters]
+    sched_kw = dict(prune_iter=prune_iter, grow_iter=grow_iter, adaptive_add=adaptive,
+                    max_points=max_points if adaptive else None, chunk=chunk if len(fitters) > 1 else None)
+    if quantize:
+        runs = [f.fit_quantize_schedule(iterations, warmup_iter, bits=bits, **sched_kw) for f in fitters]
+    else:
+        runs = [f.fit_schedule(iterations, **sched_kw) for f in fitters]
     live = list(range(len(fitters)))
     while live:
         for i in list(live):
@@ -103,7 +113,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
     for f, st in zip(fitters, streams):
         with torch.cuda.stream(st):
             f.check_status()
-            if adaptive:
+            if adaptive or quantize:
                 f.load_best()
             t0 = time.time()
             for _ in range(eval_renders):
@@ -111,8 +121,16 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
             st.synchronize()
             eval_s = (time.time() - t0) / max(eval_renders, 1)
             mse = torch.nn.functional.mse_loss(img, f.gt).item()
-        out.append({"psnr": 10 * math.log10(1.0 / max(mse, 1e-12)), "train_s": train_s, "eval_s": eval_s,
-                    "num_gaussians": f.n, "mse": mse})
+        row = {"psnr": 10 * math.log10(1.0 / max(mse, 1e-12)), "train_s": train_s, "eval_s": eval_s,
+               "num_gaussians": f.n, "mse": mse}
+        if quantize:  # train_quantize.py:239-270 encode(): codes, decoded render, size
+            with torch.cuda.stream(st):
+                enc = f.compress_wo_ec()
+                dec = f.decompress_wo_ec(enc)
+                row.update(f.analysis_wo_ec(enc))
+                row["psnr_decoded"] = 10 * math.log10(1.0 / max(torch.nn.functional.mse_loss(dec, f.gt).item(), 1e-12))
+                row["num_gaussians"] = f.n
+        out.append(row)
     return out
 
 
@@ -215,6 +233,13 @@ def main(argv=None):
     ap.add_argument("--grow_iter", type=int, default=5000)
     ap.add_argument("--images_per_gpu", type=int, default=1,
                     help="images fitted concurrently on each GPU (one HIP stream each; native loop)")
+    ap.add_argument("--quantize", action="store_true",
+                    help="train_quantize.py's loop (covariance model): plain fitting up to --warmup_iter, then "
+                         "quantisation-aware iterations; reports bits per pixel and the PSNR of the decoded image")
+    ap.add_argument("--warmup_iter", type=int, default=6000)
+    ap.add_argument("--xy_bit", type=int, default=12)
+    ap.add_argument("--cov_bit", type=int, default=10)
+    ap.add_argument("--color_bit", type=int, default=6)
     ap.add_argument("--loop", choices=["native", "autograd"], default="native",
                     help="native: fused training iteration (gi2d_train_step); autograd: gsplat wrappers + torch Adam")
     args = ap.parse_args(argv)
@@ -238,12 +263,19 @@ def main(argv=None):
     if args.opt_type is None:
         args.opt_type = "adam" if cov else "adan"
     native_kw = dict(lr=args.lr, seed=args.seed, kind=args.model, max_points=args.max_num_points,
-                     prune_iter=args.prune_iter, grow_iter=args.grow_iter, eps=1e-15, optimizer=args.opt_type)
+                     prune_iter=args.prune_iter, grow_iter=args.grow_iter, eps=1e-15, optimizer=args.opt_type,
+                     quantize=args.quantize, warmup_iter=args.warmup_iter,
+                     bits=(args.xy_bit, args.cov_bit, args.color_bit))
+    if args.quantize and (not cov or args.loop != "native"):
+        raise SystemExit("--quantize needs --model covariance and the native loop")
 
     def report(i, img, r):
         print(f"[rank {rank}] image {i}: {img.shape[0]}x{img.shape[1]}, PSNR:{r['psnr']:.4f}, "
               f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}, "
-              f"gaussians:{int(r['num_gaussians'])}", flush=True)
+              f"gaussians:{int(r['num_gaussians'])}" +
+              (f", bpp:{r['bpp']:.4f} (position {r['position_bpp']:.4f}, cholesky {r['cholesky_bpp']:.4f}, "
+               f"feature_dc {r['feature_dc_bpp']:.4f}), decoded PSNR:{r['psnr_decoded']:.4f}" if "bpp" in r else ""),
+              flush=True)
 
     def fit_one(i, img):
         if args.loop == "native":

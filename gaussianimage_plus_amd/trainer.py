@@ -484,6 +484,31 @@ class NativeFitter:
                     log(f"iter {local}: added {added} gaussians, now {self.n}")
             yield local
 
+    def fit_quantize_schedule(self, iterations: int, warmup_iter: int, bits=(12, 10, 6), chunk: Optional[int] = None,
+                              log=None, **kw):
+        """The per-image loop of train_quantize.py:114-175 as a generator: iterations 1 .. warmup_iter-1 are the plain
+        adaptive loop (prune / grow as in fit_schedule; the growth budget still refers to `iterations`, :86), at
+        `warmup_iter` the best warm-up model becomes the live one and the quantisers are switched on, the remaining
+        iterations (up to iterations-1) are quantisation-aware; a last non-definite prune closes the loop (:175)."""
+        assert self.track_best, "the switch to quantisation-aware fitting starts from the best warm-up model"
+        warm = max(0, min(int(warmup_iter), int(iterations)) - 1)
+        start = self.iteration
+
+        sched = self.fit_schedule(warm, chunk=chunk, log=log, **kw)
+        for local in sched:
+            yield local
+        self.load_best()
+        self.enable_quantize(*bits)
+        if log:
+            log(f"iter {self.iteration - start + 1}: warm-up finished, quantisation-aware from here ({self.n} gaussians)")
+        left = max(0, int(iterations) - 1 - warm)
+        while left > 0:
+            step = min(left, int(chunk)) if chunk else left
+            self.train(step)
+            left -= step
+            yield self.iteration - start
+        self.prune_non_definite()
+
     def fit(self, iterations: int, **kw) -> None:
         """Run fit_schedule to the end (same keyword arguments)."""
         for _ in self.fit_schedule(iterations, **kw):

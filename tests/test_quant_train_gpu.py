@@ -190,3 +190,16 @@ def test_quantised_snapshot_restores_quantiser_values():
     # the snapshot holds the parameters AFTER the update of the best step (train.py:137), so its render is close to,
     # not equal to, the best PSNR seen
     assert abs(p - psnr) < 1.0, (p, psnr)
+
+
+def test_launcher_quantised_schedule():
+    """launch.fit_images_native(quantize=True): warm-up with growth, switch, encode; two images on two streams."""
+    from gaussianimage_plus_amd.launch import fit_images_native, synthetic_image
+    gts = [synthetic_image(96, 144, 20 + i).to(DEV) for i in range(2)]
+    rows = fit_images_native(gts, 1500, 500, lr=0.018, kind="covariance", max_points=2500, prune_iter=100,
+                             grow_iter=100, eps=1e-15, quantize=True, warmup_iter=300, eval_renders=2)
+    for r in rows:
+        assert r["psnr"] > 22 and abs(r["psnr_decoded"] - r["psnr"]) < 0.6, r
+        assert 1500 < r["num_gaussians"] <= 2500
+        want = qo.analysis_bits(int(r["num_gaussians"]), 96, 144)
+        assert abs(r["bpp"] - want["bpp"]) < 1e-9
