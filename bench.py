@@ -145,6 +145,7 @@ def main():
         }
         if args.train_step:
             line["train_step"] = train_step_rate(gt, n, dev)
+            line["quantized_train_step"] = quantized_train_step_rate(gt, dev)
         if args.images_per_gpu_probe:
             line["concurrent_images"] = concurrent_images_rate(n, h, w, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -220,6 +221,33 @@ def train_step_rate(gt, n, dev, iters=400):
     fit.check_status()
     return {"iters_per_s": iters / dt, "us_per_iter": dt / iters * 1e6, "num_intersects": int(fit.nth.sum().item()),
             "what": "full training iteration incl. activations, L2 loss gradient and Adam (gi2d_train_step)"}
+
+
+def quantized_train_step_rate(gt, dev, n=30000, iters=400):
+    """Extra information, not `value`: BASELINE config 5 -- covariance model, N = 30 000, quantisation-aware iteration
+    (train_quantize.py after its warm-up: LSQ / log quantisers at 12 / 10 / 6 bits in front of the projection, their
+    own Adam optimizers; 4 launches, no host sync), with the plain iteration of the same model beside it."""
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    fit = NativeFitter(gt.contiguous(), n, kind="covariance", lr=0.018, eps=1e-15, seed=3047, track_best=True)
+    fit.train(200)
+    fit.prune_non_definite()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    fit.train(iters)
+    torch.cuda.synchronize(dev)
+    plain = time.perf_counter() - t0
+    fit.load_best()
+    fit.enable_quantize(12, 10, 6)
+    fit.train(40)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    fit.train(iters)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    fit.check_status()
+    return {"iters_per_s": iters / dt, "us_per_iter": dt / iters * 1e6, "plain_us_per_iter": plain / iters * 1e6,
+            "num_points": fit.n, "bits": [12, 10, 6],
+            "what": "covariance model, quantisation-aware iteration (gi2d_train_steps with gi2d_train_quant)"}
 
 
 def cpu_baseline(xyz, L, col, op, h, w, budget_s):
