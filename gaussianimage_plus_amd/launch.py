@@ -127,7 +127,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
             with torch.cuda.stream(st):
                 enc = f.compress_wo_ec()
                 dec = f.decompress_wo_ec(enc)
-                row.update(f.analysis_wo_ec(enc))
+                row.update(f.analysis_wo_ec(enc, entropy_estimate=True))
                 row["psnr_decoded"] = 10 * math.log10(1.0 / max(torch.nn.functional.mse_loss(dec, f.gt).item(), 1e-12))
                 row["num_gaussians"] = f.n
         out.append(row)
@@ -274,7 +274,8 @@ def main(argv=None):
               f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}, "
               f"gaussians:{int(r['num_gaussians'])}" +
               (f", bpp:{r['bpp']:.4f} (position {r['position_bpp']:.4f}, cholesky {r['cholesky_bpp']:.4f}, "
-               f"feature_dc {r['feature_dc_bpp']:.4f}), decoded PSNR:{r['psnr_decoded']:.4f}" if "bpp" in r else ""),
+               f"feature_dc {r['feature_dc_bpp']:.4f}), entropy-coded estimate bpp_wc:{r['bpp_wc']:.4f}, "
+               f"decoded PSNR:{r['psnr_decoded']:.4f}" if "bpp" in r else ""),
               flush=True)
 
     def fit_one(i, img):

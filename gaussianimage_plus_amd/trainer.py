@@ -98,6 +98,26 @@ def select_new_points(render_hwc: torch.Tensor, gt_hwc: torch.Tensor, count: int
             "dropped": int(count - int(keep.sum()))}
 
 
+def quantized_gaussian_code_length_bits(codes: torch.Tensor) -> float:
+    """Size estimate standing in for utils.py:94-110 (compress_matrix_flatten_gaussian_global): the reference pushes
+    the integer codes through `constriction`'s ANS coder with a QuantizedGaussian(min, max, mean, std) model and
+    counts the compressed words.  That third-party coder is not part of this path; this returns the ideal code length
+    -sum log2 p(code) under the same model (std clamped to [1e-5, 1e10], every symbol keeping a 2^-24 floor), which an
+    ANS coder reaches to within a few 32-bit words.  Host arithmetic on a few 10^4 integers, once per image."""
+    c = codes.detach().double().flatten().cpu()
+    mean = float(c.mean())
+    std = min(max(float(c.std()), 1e-5), 1e10)
+    lo, hi = int(c.min()), int(c.max())
+    if lo == hi:
+        hi = lo + 1
+    edges = torch.arange(lo, hi + 2, dtype=torch.float64) - 0.5
+    cdf = 0.5 * (1 + torch.erf((edges - mean) / (std * math.sqrt(2.0))))
+    p = cdf[1:] - cdf[:-1]
+    p = p / p.sum()
+    p = p * (1 - p.numel() * 2.0 ** -24) + 2.0 ** -24
+    return float(-torch.log2(p[(c.long() - lo)]).sum())
+
+
 class NativeFitter:
     def __init__(self, gt_hwc: torch.Tensor, num_points: int, kind: str = "cholesky", lr: float = 1e-3,
                  betas=None, eps: float = 1e-8, lr_step: int = 20000, lr_gamma: float = 0.5,
@@ -443,7 +463,7 @@ class NativeFitter:
                                            radius_clip=self.state.radius_clip)
         return out.clamp(0, 1)
 
-    def analysis_wo_ec(self, encoding: Dict[str, torch.Tensor]) -> Dict[str, float]:
+    def analysis_wo_ec(self, encoding: Dict[str, torch.Tensor], entropy_estimate: bool = False) -> Dict[str, float]:
         """models/gaussianimage_covariance.py:469-509, lsq branches: fixed-length code sizes plus the quantisers' side
         information, in bits per pixel."""
         xy_bit, cov_bit, color_bit = self.q_bits
@@ -451,8 +471,13 @@ class NativeFitter:
         chol_bits = encoding["quant_cholesky_elements"].numel() * ((cov_bit + cov_bit * 2) / 3) + 32 * 3 * 2
         feat_bits = encoding["feature_dc_index"].numel() * color_bit + 32 * 3 * 2
         pos_bits = encoding["xyz"].numel() * xy_bit + 32 * 2 * 2
-        return {"bpp": (pos_bits + chol_bits + feat_bits) / hw, "position_bpp": pos_bits / hw,
-                "cholesky_bpp": chol_bits / hw, "feature_dc_bpp": feat_bits / hw}
+        out = {"bpp": (pos_bits + chol_bits + feat_bits) / hw, "position_bpp": pos_bits / hw,
+               "cholesky_bpp": chol_bits / hw, "feature_dc_bpp": feat_bits / hw}
+        if entropy_estimate:  # train_quantize.py:250-252 (`_wc` = with entropy coding), estimated (see above)
+            out["cholesky_bpp_wc"] = quantized_gaussian_code_length_bits(encoding["quant_cholesky_elements"]) / hw
+            out["feature_dc_bpp_wc"] = quantized_gaussian_code_length_bits(encoding["feature_dc_index"]) / hw
+            out["bpp_wc"] = out["position_bpp"] + out["cholesky_bpp_wc"] + out["feature_dc_bpp_wc"]
+        return out
 
     def fit_schedule(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
                      max_points: Optional[int] = None, log=None, chunk: Optional[int] = None):

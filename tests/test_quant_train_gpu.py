@@ -172,6 +172,11 @@ def test_quantised_fit_end_to_end_codec():
     # fixed-length size
     bits = qo.gaussian_code_length_bits(enc["feature_dc_index"].cpu().numpy())
     assert bits / (h * w) < a["feature_dc_bpp"]
+    wc = fit.analysis_wo_ec(enc, entropy_estimate=True)
+    assert abs(wc["feature_dc_bpp_wc"] * h * w - bits) < 1e-6 * bits
+    assert abs(wc["cholesky_bpp_wc"] * h * w
+               - qo.gaussian_code_length_bits(enc["quant_cholesky_elements"].cpu().numpy())) < 1e-6 * bits
+    assert wc["bpp_wc"] < wc["bpp"]
 
 
 def test_quantised_snapshot_restores_quantiser_values():
