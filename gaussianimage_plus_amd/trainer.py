@@ -392,6 +392,11 @@ class NativeFitter:
         pc = qz._init_params(qz.make_spec([qz.LSQ], [0], [2 ** cov_bit - 1]), cov[:, 1:2].contiguous())
         pf = qz._init_params(qz.make_spec([qz.LSQ] * 3, [0] * 3, [2 ** color_bit - 1] * 3), self.feat)
         self.qparams = torch.cat([px[:, 0], px[:, 1], pc[0, :2], pf[:, 0], pf[:, 1]]).contiguous()
+        scales = torch.cat([self.qparams[0:2], self.qparams[4:5], self.qparams[6:9]])
+        if not bool((torch.isfinite(self.qparams).all() & (scales > 0).all()).item()):
+            # e.g. colours still at their zero initialisation: (max - min) / qmax = 0 and every code would be 0/0
+            raise ValueError("enable_quantize: an attribute has an empty or non-finite range (scale <= 0); the "
+                             "quantisers are initialised from the data, so fit for a while first")
         self.qm, self.qv, self.qrange = f32(12), f32(12), f32(4)
         self.qfeat = f32(self.cap, 3)
         self.qpartial = f32(((self.cap + 63) // 64 + 1) * 24)

@@ -43,3 +43,23 @@ def test_size_queries_need_no_gpu():
     lib = _lib.load()
     assert lib.gi2d_sort_workspace_bytes(1000, 64) >= 4 * (1000 + 3 * 64)
     assert lib.gi2d_rasterize_backward_workspace_bytes(100, 1000) >= 1000 * 48
+
+
+def test_quant_argument_checks_need_no_gpu():
+    """Bad quantiser specs are rejected before anything is launched."""
+    import ctypes as C
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.quantize import make_spec
+    lib = _lib.load()
+    assert lib.gi2d_quant_workspace_bytes(30000) >= (30000 // 256) * 16 * 4
+    bad_kind = make_spec([7], [0], [255])
+    bad_range = make_spec([0, 1], [0, 5], [255, 5])
+    five = make_spec([0], [0], [255])
+    five.channels = 5
+    for spec in (bad_kind, bad_range, five):
+        rc = lib.gi2d_quant_compress(C.byref(spec), 4, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), None)
+        assert rc == -1, rc
+        assert b"quant" in lib.gi2d_last_error_string()
+    ok = make_spec([0, 1], [0, 0], [63, 1023])
+    assert lib.gi2d_quant_forward(C.byref(ok), 10, C.c_void_p(8), C.c_void_p(8), None, None, None, 0, None) == -2
+    assert lib.gi2d_quant_forward(C.byref(ok), 0, None, None, None, None, None, 0, None) == 0  # empty input: nothing to do
