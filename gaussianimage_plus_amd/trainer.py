@@ -313,6 +313,72 @@ class NativeFitter:
         self._set_n(n_best)
         return psnr
 
+    # ------------------------------------------------------------------ the reference's checkpoint format
+    _CHOL_KEY = {"cholesky": "_cholesky", "covariance": "_cov2d"}
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The model's tensors under the key names of the reference's nn.Module state dict
+        (models/gaussianimage_covariance.py:52-66, gaussianimage_cholesky.py:95-99, gaussianimage_rs.py:69-76; the
+        quantisers' values under xyz_quantizer / cholesky_quantizer.cov_quantizer / features_dc_quantizer once
+        enable_quantize() ran), so checkpoints move between the two implementations."""
+        sd = {"_xyz": self.xyz.clone(), "_features_dc": self.feat.clone(), "_opacity": self.opacity.clone(),
+              "background": torch.ones(3, device=self.dev), "bound": torch.tensor([[0.5, 0.5]], device=self.dev)}
+        if self.kind == "scale_rot":
+            sd["_scaling"], sd["_rotation"] = self.chol[:, :2].clone(), self.chol[:, 2:3].clone()
+        else:
+            sd[self._CHOL_KEY[self.kind]] = self.chol.clone()
+        if self.quant is not None:
+            qp = self.qparams
+            sd.update({"xyz_quantizer.scale": qp[0:2].clone(), "xyz_quantizer.beta": qp[2:4].clone(),
+                       "cholesky_quantizer.cov_quantizer.scale": qp[4:5].clone(),
+                       "cholesky_quantizer.cov_quantizer.beta": qp[5:6].clone(),
+                       "features_dc_quantizer.scale": qp[6:9].clone(), "features_dc_quantizer.beta": qp[9:12].clone()})
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], slv_bound: Optional[torch.Tensor] = None) -> None:
+        """Inverse of state_dict(); `slv_bound` is the checkpoint's per-gaussian cholesky_bound (train.py:73).  The
+        optimizer moments of the loaded rows start from zero, as in the reference after a resume."""
+        n = int(sd["_xyz"].shape[0])
+        assert n <= self.cap, f"checkpoint has {n} gaussians, this fitter was built for at most {self.cap}"
+        to = lambda t: t.detach().to(self.dev, torch.float32)
+        self._xyz[:n], self._feat[:n] = to(sd["_xyz"]), to(sd["_features_dc"])
+        if self.kind == "scale_rot":
+            self._chol[:n, :2], self._chol[:n, 2:3] = to(sd["_scaling"]), to(sd["_rotation"])
+        else:
+            self._chol[:n] = to(sd[self._CHOL_KEY[self.kind]])
+        if "_opacity" in sd:
+            self._opacity[:n] = to(sd["_opacity"]).reshape(n, 1)
+        if slv_bound is not None:
+            b = to(slv_bound).reshape(-1, 3)
+            if self.per_point_bound:
+                self._bound[:n] = b if b.shape[0] == n else b[:1].expand(n, 3)
+            else:
+                assert bool((b == b[:1]).all()), "per-gaussian bounds need a fitter built with max_points or a [N,3] bound"
+                self._bound.copy_(b[0])
+        for t in self._rows()[4:4 + (12 if self.optimizer == "adan" else 6)]:
+            t[:n] = 0.0
+        self._set_n(n)
+        if self.quant is not None and "xyz_quantizer.scale" in sd:
+            self.qparams.copy_(torch.cat([to(sd["xyz_quantizer.scale"]), to(sd["xyz_quantizer.beta"]),
+                                          to(sd["cholesky_quantizer.cov_quantizer.scale"]),
+                                          to(sd["cholesky_quantizer.cov_quantizer.beta"]),
+                                          to(sd["features_dc_quantizer.scale"]), to(sd["features_dc_quantizer.beta"])]))
+
+    def slv_bound(self) -> torch.Tensor:
+        """[N,3] additive bound per gaussian: the `slv_bound` entry of the reference's checkpoints."""
+        return (self.bound if self.per_point_bound else self.bound.reshape(1, 3).expand(self.n, 3)).clone()
+
+    def save_checkpoint(self, path: str, psnr: Optional[float] = None, ms_ssim: Optional[float] = None) -> None:
+        """train.py:173-175 / train_quantize.py:192-195: {"gs", "num_gs", "psnr", "ms-ssim", "slv_bound"}."""
+        torch.save({"gs": {k: v.cpu() for k, v in self.state_dict().items()}, "num_gs": self.n, "psnr": psnr,
+                    "ms-ssim": ms_ssim, "slv_bound": self.slv_bound().cpu()}, path)
+
+    def load_checkpoint(self, path: str) -> dict:
+        """train.py:62-77: load a checkpoint written by either implementation; returns the checkpoint dict."""
+        ck = torch.load(path, map_location="cpu")
+        self.load_state_dict(ck["gs"], ck.get("slv_bound"))
+        return ck
+
     # ------------------------------------------------------------------ prune / grow (covariance model)
     def _rows(self):
         rows = [self._xyz, self._chol, self._feat, self._opacity, self._m_xyz, self._v_xyz, self._m_chol, self._v_chol,

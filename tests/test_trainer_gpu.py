@@ -254,3 +254,36 @@ def test_native_scale_rot_model_matches_autograd_loop():
         d = (got - ref).abs()
         assert d.max().item() < 0.15 * lr * iters, f"{nm} drifted by {d.max().item()}"
         assert d.mean().item() < 2e-2 * lr * iters, nm
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    """state_dict keys / checkpoint fields are the reference's (train.py:62-77,173-175); a fitter restored from the
+    file renders the same image bit for bit."""
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    fit, gt = _cov_fitter(1500, 64, 96, max_points=2000, track_best=True)
+    fit.fit(150, prune_iter=50, grow_iter=100)
+    fit.load_best()
+    img = fit.render().clone()
+    sd = fit.state_dict()
+    assert set(sd) == {"_xyz", "_cov2d", "_features_dc", "_opacity", "background", "bound"}
+    assert sd["_xyz"].shape == (fit.n, 2) and sd["_cov2d"].shape == (fit.n, 3) and sd["_opacity"].shape == (fit.n, 1)
+    path = str(tmp_path / "gaussian_model.pth.tar")
+    fit.save_checkpoint(path, psnr=fit.psnr())
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"gs", "num_gs", "psnr", "ms-ssim", "slv_bound"} and ck["num_gs"] == fit.n
+    assert ck["slv_bound"].shape == (fit.n, 3)
+    other = NativeFitter(gt, 100, kind="covariance", lr=0.018, eps=1e-15, max_points=2000)
+    other.load_checkpoint(path)
+    assert other.n == fit.n and torch.equal(other.render(), img)
+    # quantiser values travel under the reference's module names
+    fit.enable_quantize(12, 10, 6)
+    fit.train(5)
+    sdq = fit.state_dict()
+    for k in ("xyz_quantizer.scale", "xyz_quantizer.beta", "cholesky_quantizer.cov_quantizer.scale",
+              "cholesky_quantizer.cov_quantizer.beta", "features_dc_quantizer.scale", "features_dc_quantizer.beta"):
+        assert k in sdq
+    assert sdq["features_dc_quantizer.scale"].shape == (3,) and sdq["cholesky_quantizer.cov_quantizer.beta"].shape == (1,)
+    chol = NativeFitter(gt, 300, kind="cholesky", lr=1e-3)
+    assert "_cholesky" in chol.state_dict()
+    rs = NativeFitter(gt, 300, kind="scale_rot", lr=1e-3)
+    assert {"_scaling", "_rotation"} <= set(rs.state_dict())
