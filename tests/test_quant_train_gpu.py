@@ -208,3 +208,31 @@ def test_launcher_quantised_schedule():
         assert 1500 < r["num_gaussians"] <= 2500
         want = qo.analysis_bits(int(r["num_gaussians"]), 96, 144)
         assert abs(r["bpp"] - want["bpp"]) < 1e-9
+
+
+@pytest.mark.parametrize("n,h,w", [(50, 32, 48), (33000, 192, 256)])
+def test_quantised_iteration_small_and_large_populations(n, h, w):
+    """One workgroup (n < 64) and the 256-lane workgroup layout used above 32 768 gaussians."""
+    bits = (12, 10, 6)
+    fit, gt = _fitter(n, h, w, debug_grads=True)
+    fit.train(10)
+    fit.enable_quantize(*bits, debug_grads=True)
+    lr = fit.current_lr()
+    want = _torch_quant_loop(fit, gt, 2, lr, bits)
+    fit.train(1)
+    fit.check_status()
+    g_native, g_ref = fit.dbg_grads[:n].clone(), want[4]["g"]
+    cov = want[4]["cov"].cpu().numpy()
+    L = qo.log_of(cov[:, ::2])
+    ext = np.zeros((n, 8), bool)
+    ext[:, 2:5:2] = (L == L.min()) | (L == L.max())
+    scale = g_ref.abs().max(dim=0, keepdim=True).values + 1e-20
+    err = (((g_native - g_ref).abs() / scale)[~torch.from_numpy(ext).to(DEV)]).max().item()
+    assert err < 3e-4, err
+    q_native, q_ref = fit.dbg_qgrads[:12], want[4]["q"]
+    assert ((q_native - q_ref).abs() / (q_ref.abs() + 1e-3 * q_ref.abs().max())).max().item() < 2e-2
+    fit.train(1)
+    fit.check_status()
+    for got, ref in ((fit.xyz, want[0]), (fit.chol, want[1]), (fit.feat, want[2])):
+        assert (got - ref).abs().max().item() < 0.05 * lr
+    assert (fit.qparams - want[3]).abs().max().item() < 2e-5
