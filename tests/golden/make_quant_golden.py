@@ -39,11 +39,11 @@ def _import_reference_quantize():
     return quantize
 
 
-def lsq_case(Q, out, name, x, bits, g, steps_off=None, perturb=None):
+def lsq_case(Q, out, name, x, bits, g, steps_off=None, perturb=None, signed=False):
     """UniformQuantizer(signed=False, learned=True): data init on first forward, then forward/backward; `perturb`
     moves scale/beta off their initial values so the clamp is active on both ends."""
     c = x.shape[1]
-    q = Q.UniformQuantizer(signed=False, bits=bits, learned=True, num_channels=c)
+    q = Q.UniformQuantizer(signed=signed, bits=bits, learned=True, num_channels=c)
     xin = x.clone().requires_grad_(True)
     q(xin)  # init_state 0 -> _init_data
     out[f"{name}_init_scale"] = q.scale.detach().numpy().copy()
@@ -135,6 +135,9 @@ def main():
     lsq_case(Q, out, "col6", col, 6, torch.randn(n, 3, generator=gen), perturb=(1.05, 1.5))
     # unperturbed: nothing clamps right after the data initialisation
     lsq_case(Q, out, "col6_init", col, 6, torch.randn(n, 3, generator=gen))
+    # rotation angles through a SIGNED 6-bit quantiser (models/gaussianimage_rs.py:142: the RS model's rotation_quantizer)
+    rot = torch.sigmoid(torch.randn(n, 1, generator=gen)) * 2 * 3.141592653589793
+    lsq_case(Q, out, "rot6s", rot, 6, torch.randn(n, 1, generator=gen), perturb=(1.04, 1.0), signed=True)
     # variances (two channels, one global log range), 10 bit; include a negative and a zero entry
     var = torch.rand(n, 2, generator=gen) * 40.0 + 0.3
     var[5, 0] = -2.5

@@ -18,10 +18,10 @@ def close(a, b, rtol=1e-5, atol=1e-7):
     np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("name", ["xy12", "col6", "col6_init"])
+@pytest.mark.parametrize("name", ["xy12", "col6", "col6_init", "rot6s"])
 def test_lsq_matches_reference(name):
     x, g, bits = G[f"{name}_x"], G[f"{name}_g"], int(G[f"{name}_bits"])
-    qmin, qmax = qo.qrange(bits)
+    qmin, qmax = qo.qrange(bits, signed=name.endswith("s"))  # rot6s: the RS model's signed rotation quantiser
     s0, b0 = qo.lsq_init(x, qmin, qmax)
     close(s0, G[f"{name}_init_scale"], 1e-6)
     close(b0, G[f"{name}_init_beta"], 1e-6)
@@ -34,7 +34,7 @@ def test_lsq_matches_reference(name):
     scale_terms = np.abs(g * code).sum(0) + np.abs(g * (x - b) / s).sum(0)
     assert np.all(np.abs(v_s - G[f"{name}_v_scale"]) <= 2e-5 * scale_terms)
     assert np.all(np.abs(v_b - G[f"{name}_v_beta"]) <= 2e-5 * np.abs(g).sum(0))
-    if name != "col6_init":  # the perturbed cases clamp at both ends, so the sums are not just rounding noise
+    if name in ("xy12", "col6"):  # these perturbed cases clamp at both ends: the sums are not just rounding noise
         assert np.all(np.abs(G[f"{name}_v_beta"]) > 1e-3)
     cd, cc = qo.lsq_compress(x, s, b, qmin, qmax)
     assert np.array_equal(cc, G[f"{name}_compress_code"])

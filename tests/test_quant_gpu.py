@@ -35,11 +35,12 @@ def codes_match(code, ref, raw):
     return ~bad
 
 
-@pytest.mark.parametrize("name", ["xy12", "col6", "col6_init"])
+@pytest.mark.parametrize("name", ["xy12", "col6", "col6_init", "rot6s"])
 def test_lsq_bit_exact_with_reference(name):
     from gaussianimage_plus_amd.quantize import UniformQuantizer
     x, g, bits = G[f"{name}_x"], G[f"{name}_g"], int(G[f"{name}_bits"])
-    q = UniformQuantizer(signed=False, bits=bits, learned=True, num_channels=x.shape[1]).to(DEV)
+    signed = name.endswith("s")  # rot6s: the RS model's signed rotation quantiser (models/gaussianimage_rs.py:142)
+    q = UniformQuantizer(signed=signed, bits=bits, learned=True, num_channels=x.shape[1]).to(DEV)
     q(t(x))  # data initialisation on the first call (quantize.py:126-128)
     close(q.scale, G[f"{name}_init_scale"], 1e-6)
     close(q.beta, G[f"{name}_init_beta"], 1e-6)
@@ -51,7 +52,7 @@ def test_lsq_bit_exact_with_reference(name):
     assert np.array_equal(deq.detach().cpu().numpy(), G[f"{name}_dequant"])
     (deq * t(g)).sum().backward()
     close(xin.grad, G[f"{name}_v_x"], 1e-6)
-    qmin, qmax = qo.qrange(bits)
+    qmin, qmax = qo.qrange(bits, signed=signed)
     _, v_s, v_b = qo.lsq_backward(x, G[f"{name}_scale"], G[f"{name}_beta"], qmin, qmax, g)
     terms = np.abs(g * G[f"{name}_code"]).sum(0) * 2
     assert np.all(np.abs(q.scale.grad.cpu().numpy() - v_s) <= 2e-6 * terms)
