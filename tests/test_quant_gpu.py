@@ -196,3 +196,40 @@ def test_errors_and_empty():
     q.init_state = 1
     d, _, _, c = q(torch.zeros(0, 3, device=DEV))
     assert d.shape == (0, 3) and c.shape == (0, 3)
+
+
+def test_rs_model_forward_quantize_composition():
+    """models/gaussianimage_rs.py:443-471 forward_quantize written with the package's pieces: LSQ quantisers (positions
+    12 bit, scaling 6 bit, SIGNED 6-bit rotation, colours 6 bit) in front of project_gaussians_2d_scale_rot and
+    rasterize_gaussians_sum; gradients reach every parameter and every quantiser value."""
+    import math
+    import gaussianimage_plus_amd.gsplat as gs
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.quantize import UniformQuantizer
+    n, h, w = 1200, 64, 96
+    g = torch.Generator().manual_seed(8)
+    xyz = (torch.rand(n, 2, generator=g) * torch.tensor([float(w), float(h)])).to(DEV).requires_grad_(True)
+    scaling = (torch.rand(n, 2, generator=g) * 3 + 0.5).to(DEV).requires_grad_(True)
+    rotation = torch.rand(n, 1, generator=g).to(DEV).requires_grad_(True)
+    feat = (torch.rand(n, 3, generator=g) * 0.4).to(DEV).requires_grad_(True)
+    gt = synthetic_image(h, w, 2).to(DEV)
+    xyq = UniformQuantizer(signed=False, bits=12, learned=True, num_channels=2).to(DEV)
+    sq = UniformQuantizer(signed=False, bits=6, learned=True, num_channels=2).to(DEV)
+    rq = UniformQuantizer(signed=True, bits=6, learned=True, num_channels=1).to(DEV)
+    fq = UniformQuantizer(signed=False, bits=6, learned=True, num_channels=3).to(DEV)
+    means, _, _, cxy = xyq(xyz)
+    sc, _, _, cs = sq(scaling)
+    rot, _, _, cr = rq(torch.sigmoid(rotation) * 2 * math.pi)
+    col, _, _, cc = fq(feat)
+    assert cs.max() <= 63 and cs.min() >= 0 and cr.min() >= -32 and cr.max() <= 31 and cxy.max() <= 4095
+    tb = ((w + 15) // 16, (h + 15) // 16, 1)
+    xys, depths, radii, conics, nth = gs.project_gaussians_2d_scale_rot(means, sc, rot, h, w, tb)
+    sp = torch.zeros(n, 4, device=DEV)
+    img, _, _ = gs.rasterize_gaussians_sum(xys, sp, depths, radii, conics, nth, col, torch.ones(n, 1, device=DEV), h, w,
+                                           16, 16, background=torch.ones(3, device=DEV))
+    loss = torch.nn.functional.mse_loss(img.clamp(0, 1), gt)
+    loss.backward()
+    for p in (xyz, scaling, rotation, feat, xyq.scale, xyq.beta, sq.scale, sq.beta, rq.scale, rq.beta, fq.scale, fq.beta):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    # dequantised values sit on the grid code * scale + beta (bit for bit)
+    assert torch.equal(sc.detach(), cs * sq.scale.detach() + sq.beta.detach())
