@@ -14,7 +14,8 @@ from helpers import synth_cholesky, synth_gt  # noqa: E402
 from gaussianimage_plus_amd import _lib  # noqa: E402
 from gaussianimage_plus_amd.hotpath import HotPath  # noqa: E402
 
-n, h, w = int(sys.argv[1]) if len(sys.argv) > 1 else 50000, 512, 768
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+h, w = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 768)
 dev = torch.device("cuda:0")
 xyz, L, col, op = synth_cholesky(n, h, w, 3047)
 hp = HotPath(n, h, w, device=dev)
