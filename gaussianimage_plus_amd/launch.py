@@ -72,12 +72,13 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
                       seed: int = 3047, eval_renders: int = 10, kind: str = "cholesky", max_points: int = 0,
                       prune_iter: int = 100, grow_iter: int = 5000, eps: float = 1e-8,
                       chunk: int = 16, optimizer: str = "adam", quantize: bool = False, warmup_iter: int = 6000,
-                      bits=(12, 10, 6)) -> List[Dict[str, float]]:
+                      bits=(12, 10, 6), threaded: bool = False) -> List[Dict[str, float]]:
     """Fit the images of `gts` CONCURRENTLY on one GPU, one HIP stream each, on the fused training iteration
     (trainer.NativeFitter -> gi2d_train_step: one C-ABI call, three kernel launches, no host synchronisation per
     iteration).  One image's kernels leave most of the chip idle between their dependent phases, so
-    two to four independent images per GPU raise the aggregate iteration rate by 1.4-1.8x; `chunk` iterations of
-    one image are enqueued before the host turns to the next.  With `max_points` > `num_points` (covariance model)
+    two to four independent images per GPU raise the aggregate iteration rate by 1.4-3.6x (the smaller the model,
+    the more); `chunk` iterations of one image are enqueued before the host turns to the next, or, with `threaded`,
+    every image has its own host thread (the C-ABI calls release the GIL).  With `max_points` > `num_points` (covariance model)
     each image runs the adaptive loop of train.py:120-160: prune every `prune_iter`, grow every `grow_iter`, keep
     the best model on the device and evaluate that one.  `train_s` is the wall time of the whole group.
     With `quantize` (covariance model) the loop is train_quantize.py's: plain fitting up to `warmup_iter`, then
@@ -96,17 +97,41 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
     torch.cuda.synchronize(dev)
     t0 = time.time()
     sched_kw = dict(prune_iter=prune_iter, grow_iter=grow_iter, adaptive_add=adaptive,
-                    max_points=max_points if adaptive else None, chunk=chunk if len(fitters) > 1 else None)
+                    max_points=max_points if adaptive else None,
+                    chunk=chunk if (len(fitters) > 1 and not threaded) else None)
     if quantize:
         runs = [f.fit_quantize_schedule(iterations, warmup_iter, bits=bits, **sched_kw) for f in fitters]
     else:
         runs = [f.fit_schedule(iterations, **sched_kw) for f in fitters]
-    live = list(range(len(fitters)))
-    while live:
-        for i in list(live):
-            with torch.cuda.stream(streams[i]):
-                if next(runs[i], None) is None:
-                    live.remove(i)
+    if threaded and len(fitters) > 1:
+        # one host thread per image: the C-ABI calls release the GIL, so the launches of different images are issued
+        # in parallel instead of round-robin from one thread (which becomes the limit beyond ~4 small images)
+        import threading
+
+        errors: List[BaseException] = []
+
+        def drive(i):
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(streams[i]):
+                    for _ in runs[i]:
+                        pass
+            except BaseException as e:  # surfaced on the main thread below
+                errors.append(e)
+
+        workers = [threading.Thread(target=drive, args=(i,)) for i in range(len(fitters))]
+        for t in workers:
+            t.start()
+        for t in workers:
+            t.join()
+        if errors:
+            raise errors[0]
+    else:
+        live = list(range(len(fitters)))
+        while live:
+            for i in list(live):
+                with torch.cuda.stream(streams[i]):
+                    if next(runs[i], None) is None:
+                        live.remove(i)
     torch.cuda.synchronize(dev)
     train_s = time.time() - t0
     out = []
@@ -232,7 +257,9 @@ def main(argv=None):
     ap.add_argument("--prune_iter", type=int, default=100)
     ap.add_argument("--grow_iter", type=int, default=5000)
     ap.add_argument("--images_per_gpu", type=int, default=1,
-                    help="images fitted concurrently on each GPU (one HIP stream each; native loop)")
+                    help="images fitted concurrently on each GPU (one HIP stream and one host thread each; native loop)")
+    ap.add_argument("--single_host_thread", action="store_true",
+                    help="issue the concurrent images' launches round-robin from one host thread instead")
     ap.add_argument("--quantize", action="store_true",
                     help="train_quantize.py's loop (covariance model): plain fitting up to --warmup_iter, then "
                          "quantisation-aware iterations; reports bits per pixel and the PSNR of the decoded image")
@@ -287,7 +314,8 @@ def main(argv=None):
         return r
 
     def fit_group(idx, imgs):
-        res = fit_images_native([im.to(dev) for im in imgs], args.num_points, args.iterations, **native_kw)
+        res = fit_images_native([im.to(dev) for im in imgs], args.num_points, args.iterations,
+                                threaded=not args.single_host_thread, **native_kw)
         for i, im, r in zip(idx, imgs, res):
             report(i, im, r)
         return res
