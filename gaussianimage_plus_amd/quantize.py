@@ -24,6 +24,29 @@ from . import _lib
 
 LSQ, LOG = 0, 1
 
+# what `from quantize import *` gives the reference's model files (quantize.py has no __all__; these are its public
+# names that are part of this path)
+__all__ = ["myabs", "mysign", "grad_scale", "ste", "FakeQuantizationHalf", "UniformQuantizer", "LogQuantizer",
+           "VectorQuantizer", "HybirdQuant"]
+
+
+# The four one-line tensor helpers of quantize.py:11-24, for code that composes its own quantiser in torch.  The
+# quantiser classes below do not use them: their rounding / straight-through logic lives in the HIP operators.
+def myabs(x):
+    return torch.where(x == 0, x, torch.abs(x))
+
+
+def mysign(x):
+    return torch.where(x == 0, torch.ones_like(x), torch.sign(x))
+
+
+def grad_scale(x, scale):
+    return (x - x * scale).detach() + x * scale
+
+
+def ste(x):
+    return (x.round() - x).detach() + x
+
 
 class _QuantSpec(C.Structure):
     """struct gi2d_quant_spec (include/gi2d.h)."""
