@@ -30,22 +30,28 @@ __all__ = ["myabs", "mysign", "grad_scale", "ste", "FakeQuantizationHalf", "Unif
            "VectorQuantizer", "HybirdQuant"]
 
 
-# The four one-line tensor helpers of quantize.py:11-24, for code that composes its own quantiser in torch.  The
-# quantiser classes below do not use them: their rounding / straight-through logic lives in the HIP operators.
+# Torch-level counterparts of the four small tensor helpers at quantize.py:11-24, for code that composes its own
+# quantiser in torch.  The quantiser classes below do not use them: rounding and the straight-through gradient live in
+# the HIP operators.
 def myabs(x):
-    return torch.where(x == 0, x, torch.abs(x))
+    """|x| that leaves exact zeros (and their sign bit) untouched."""
+    return torch.abs(x).where(x != 0, x)
 
 
 def mysign(x):
-    return torch.where(x == 0, torch.ones_like(x), torch.sign(x))
+    """sign(x) with sign(0) = +1."""
+    return torch.sign(x) + (x == 0).to(x.dtype)
 
 
 def grad_scale(x, scale):
-    return (x - x * scale).detach() + x * scale
+    """Value of x, gradient multiplied by `scale` (LSQ's step-size gradient scaling)."""
+    scaled = x * scale
+    return scaled + (x - scaled).detach()
 
 
 def ste(x):
-    return (x.round() - x).detach() + x
+    """Round half to even in the forward pass, identity gradient."""
+    return x + (torch.round(x) - x).detach()
 
 
 class _QuantSpec(C.Structure):
