@@ -24,6 +24,10 @@ import torch
 import torch.distributed as dist
 
 
+# per-image results of the quantised loop that ride along in the same five-float-style all-reduce
+CODEC_KEYS = ("bpp", "position_bpp", "cholesky_bpp", "feature_dc_bpp", "bpp_wc", "psnr_decoded")
+
+
 def partition(num_items: int, rank: int, world_size: int) -> List[int]:
     """Round-robin shard of image indices: Kodak-24 -> 24/12/6/3 images per rank at 1/2/4/8 GPUs."""
     return list(range(rank, num_items, world_size))
@@ -32,15 +36,18 @@ def partition(num_items: int, rank: int, world_size: int) -> List[int]:
 def reduce_metrics(local: Dict[str, float], device="cpu") -> Dict[str, float]:
     """Sum the per-rank totals (psnr, train seconds, eval seconds, gaussians, images) across ranks with one
     all-reduce and return the averages the reference logs."""
-    keys = ["psnr", "train_s", "eval_s", "num_gaussians", "count"]
+    keys = ["psnr", "train_s", "eval_s", "num_gaussians", "count"] + list(CODEC_KEYS)
     t = torch.tensor([float(local.get(k, 0.0)) for k in keys], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     tot = dict(zip(keys, t.tolist()))
     n = max(tot["count"], 1.0)
-    return {"images": int(tot["count"]), "avg_psnr": tot["psnr"] / n, "avg_train_s": tot["train_s"] / n,
-            "avg_eval_s": tot["eval_s"] / n, "avg_num_gaussians": tot["num_gaussians"] / n,
-            "sum_train_s": tot["train_s"]}
+    out = {"images": int(tot["count"]), "avg_psnr": tot["psnr"] / n, "avg_train_s": tot["train_s"] / n,
+           "avg_eval_s": tot["eval_s"] / n, "avg_num_gaussians": tot["num_gaussians"] / n,
+           "sum_train_s": tot["train_s"]}
+    for k in CODEC_KEYS:  # train_quantize.py:411-420 averages the sizes over the images too
+        out["avg_" + k] = tot[k] / n
+    return out
 
 
 def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, float]], rank: int, world_size: int,
@@ -57,8 +64,8 @@ def run_sharded(items: Sequence, fit_one: Callable[[int, object], Dict[str, floa
         shared = fit_group is not None and group > 1
         for k, (i, r) in enumerate(zip(idx, res)):
             rows.append((i, r))
-            for key in ("psnr", "eval_s", "num_gaussians"):
-                local[key] += float(r.get(key, 0.0))
+            for key in ("psnr", "eval_s", "num_gaussians") + CODEC_KEYS:
+                local[key] = local.get(key, 0.0) + float(r.get(key, 0.0))
             if not shared or k == 0:
                 local["train_s"] += float(r.get("train_s", 0.0))
             local["count"] += 1
@@ -329,8 +336,9 @@ def main(argv=None):
     if rank == 0:
         print(f"Average: {args.width}x{args.height}, PSNR:{out['avg_psnr']:.4f}, Training:{out['avg_train_s']:.4f}s, "
               f"Eval:{out['avg_eval_s']:.8f}s, FPS:{1.0 / max(out['avg_eval_s'], 1e-12):.4f}, "
-              f"images:{out['images']}, gpus:{world}, wall:{wall:.2f}s, images/sec:{out['images'] / wall:.4f}",
-              flush=True)
+              f"images:{out['images']}, gpus:{world}, wall:{wall:.2f}s, images/sec:{out['images'] / wall:.4f}" +
+              (f", bpp:{out['avg_bpp']:.4f}, bpp_wc (estimate):{out['avg_bpp_wc']:.4f}, "
+               f"decoded PSNR:{out['avg_psnr_decoded']:.4f}" if args.quantize else ""), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -83,3 +83,18 @@ def test_grouped_images_share_their_wall_time():
     assert out["images"] == 5 and abs(out["sum_train_s"] - 6.0) < 1e-12  # three groups of 2.0 s
     assert abs(out["avg_psnr"] - 32.0) < 1e-12
     assert [i for i, _ in out["rows"]] == [0, 1, 2, 3, 4]
+
+
+def test_codec_metrics_are_averaged_with_the_rest():
+    """Rows of the quantised loop carry sizes and the decoded PSNR; they ride in the same reduction."""
+    items = list(range(4))
+
+    def fit_one(i, item):
+        return {"psnr": 30.0 + i, "train_s": 1.0, "eval_s": 0.01, "num_gaussians": 100, "bpp": 0.5 + 0.1 * i,
+                "bpp_wc": 0.4, "psnr_decoded": 29.0 + i, "position_bpp": 0.2, "cholesky_bpp": 0.2, "feature_dc_bpp": 0.1}
+
+    out = run_sharded(items, fit_one, 0, 1)
+    assert abs(out["avg_bpp"] - 0.65) < 1e-12 and abs(out["avg_psnr_decoded"] - 30.5) < 1e-12
+    assert abs(out["avg_bpp_wc"] - 0.4) < 1e-12
+    plain = run_sharded(items, lambda i, it: {"psnr": 30.0, "train_s": 1.0, "eval_s": 0.01, "num_gaussians": 1}, 0, 1)
+    assert plain["avg_bpp"] == 0.0  # rows without a codec report nothing
