@@ -112,6 +112,78 @@ __device__ __forceinline__ float adam(float p, float g, float &m, float &v, cons
     return p - a.step_size * (m / denom);             // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// Whole-row accesses of the [N,2] / [N,3] parameter and moment arrays: one 8- or 12-byte memory instruction per row
+// instead of one per float (the arrays may alias as far as the compiler knows, which keeps it from merging them).
+struct Row3 {
+    float a, b, c;
+};
+__device__ __forceinline__ Row3 load_row3(const float *p, int g) { return *reinterpret_cast<const Row3 *>(p + 3 * (size_t)g); }
+__device__ __forceinline__ void store_row3(float *p, int g, float a, float b, float c) {
+    Row3 r;
+    r.a = a, r.b = b, r.c = c;
+    *reinterpret_cast<Row3 *>(p + 3 * (size_t)g) = r;
+}
+__device__ __forceinline__ float2 load_row2(const float *p, int g) { return reinterpret_cast<const float2 *>(p)[g]; }
+__device__ __forceinline__ void store_row2(float *p, int g, float a, float b) {
+    reinterpret_cast<float2 *>(p)[g] = make_float2(a, b);
+}
+
+// torch.optim.Adam on one gaussian's (xyz, chol, feat) rows; every row is read and written whole.
+__device__ __forceinline__ void adam_rows(const TrainParams &P, int g, float gx, float gy, const float (&gp)[3],
+                                          const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
+                                          const AdamStep &a_feat) {
+    const float2 x = load_row2(P.xyz, g);
+    float2 mx = load_row2(P.m_xyz, g), vx = load_row2(P.v_xyz, g);
+    const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
+    Row3 mc = load_row3(P.m_chol, g), vc = load_row3(P.v_chol, g), mf = load_row3(P.m_feat, g), vf = load_row3(P.v_feat, g);
+    const float nx = adam(x.x, gx, mx.x, vx.x, a_xyz), ny = adam(x.y, gy, mx.y, vx.y, a_xyz);
+    const float c0 = adam(c.a, gp[0], mc.a, vc.a, a_chol), c1 = adam(c.b, gp[1], mc.b, vc.b, a_chol),
+                c2 = adam(c.c, gp[2], mc.c, vc.c, a_chol);
+    const float f0 = adam(f.a, gf[0], mf.a, vf.a, a_feat), f1 = adam(f.b, gf[1], mf.b, vf.b, a_feat),
+                f2 = adam(f.c, gf[2], mf.c, vf.c, a_feat);
+    store_row2(P.xyz, g, nx, ny);
+    store_row2(P.m_xyz, g, mx.x, mx.y);
+    store_row2(P.v_xyz, g, vx.x, vx.y);
+    store_row3(P.chol, g, c0, c1, c2);
+    store_row3(P.m_chol, g, mc.a, mc.b, mc.c);
+    store_row3(P.v_chol, g, vc.a, vc.b, vc.c);
+    store_row3(P.feat, g, f0, f1, f2);
+    store_row3(P.m_feat, g, mf.a, mf.b, mf.c);
+    store_row3(P.v_feat, g, vf.a, vf.b, vf.c);
+}
+
+__device__ __forceinline__ float adan(float p, float g, float &m, float &n, float &d, float &pg, const AdamStep &a);
+// Adan on one gaussian's rows, every row read and written whole (five state arrays per parameter group).
+__device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx, float gy, const float (&gp)[3],
+                                          const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
+                                          const AdamStep &a_feat) {
+    const float2 x = load_row2(P.xyz, g);
+    float2 m = load_row2(P.m_xyz, g), v = load_row2(P.v_xyz, g), d = load_row2(P.d_xyz, g), pg = load_row2(P.pg_xyz, g);
+    const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
+    Row3 mc = load_row3(P.m_chol, g), vc = load_row3(P.v_chol, g), dc = load_row3(P.d_chol, g), pc = load_row3(P.pg_chol, g);
+    Row3 mf = load_row3(P.m_feat, g), vf = load_row3(P.v_feat, g), df = load_row3(P.d_feat, g), pf = load_row3(P.pg_feat, g);
+    const float nx = adan(x.x, gx, m.x, v.x, d.x, pg.x, a_xyz), ny = adan(x.y, gy, m.y, v.y, d.y, pg.y, a_xyz);
+    const float c0 = adan(c.a, gp[0], mc.a, vc.a, dc.a, pc.a, a_chol), c1 = adan(c.b, gp[1], mc.b, vc.b, dc.b, pc.b, a_chol),
+                c2 = adan(c.c, gp[2], mc.c, vc.c, dc.c, pc.c, a_chol);
+    const float f0 = adan(f.a, gf[0], mf.a, vf.a, df.a, pf.a, a_feat), f1 = adan(f.b, gf[1], mf.b, vf.b, df.b, pf.b, a_feat),
+                f2 = adan(f.c, gf[2], mf.c, vf.c, df.c, pf.c, a_feat);
+    store_row2(P.xyz, g, nx, ny);
+    store_row2(P.m_xyz, g, m.x, m.y);
+    store_row2(P.v_xyz, g, v.x, v.y);
+    store_row2(P.d_xyz, g, d.x, d.y);
+    store_row2(P.pg_xyz, g, pg.x, pg.y);
+    store_row3(P.chol, g, c0, c1, c2);
+    store_row3(P.m_chol, g, mc.a, mc.b, mc.c);
+    store_row3(P.v_chol, g, vc.a, vc.b, vc.c);
+    store_row3(P.d_chol, g, dc.a, dc.b, dc.c);
+    store_row3(P.pg_chol, g, pc.a, pc.b, pc.c);
+    store_row3(P.feat, g, f0, f1, f2);
+    store_row3(P.m_feat, g, mf.a, mf.b, mf.c);
+    store_row3(P.v_feat, g, vf.a, vf.b, vf.c);
+    store_row3(P.d_feat, g, df.a, df.b, df.c);
+    store_row3(P.pg_feat, g, pf.a, pf.b, pf.c);
+}
+
 // What the update kernel needs to start the NEXT iteration itself (FILL_NEXT): the freshly updated parameters
 // are still in registers, so their activation + projection + bucket fill ride along and the next iteration
 // begins with its tile pass -- one launch and one parameter round trip less per iteration.
@@ -228,42 +300,9 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         d[7] = gf[2];
     }
     if (ADAN) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float m = P.m_xyz[2 * g + q], v = P.v_xyz[2 * g + q], d = P.d_xyz[2 * g + q], pg = P.pg_xyz[2 * g + q];
-            P.xyz[2 * g + q] = adan(P.xyz[2 * g + q], q ? gy : gx, m, v, d, pg, a_xyz);
-            P.m_xyz[2 * g + q] = m, P.v_xyz[2 * g + q] = v, P.d_xyz[2 * g + q] = d, P.pg_xyz[2 * g + q] = pg;
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float m = P.m_chol[3 * g + q], v = P.v_chol[3 * g + q], d = P.d_chol[3 * g + q], pg = P.pg_chol[3 * g + q];
-            P.chol[3 * g + q] = adan(P.chol[3 * g + q], gp[q], m, v, d, pg, a_chol);
-            P.m_chol[3 * g + q] = m, P.v_chol[3 * g + q] = v, P.d_chol[3 * g + q] = d, P.pg_chol[3 * g + q] = pg;
-            float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q], df = P.d_feat[3 * g + q], pf = P.pg_feat[3 * g + q];
-            P.feat[3 * g + q] = adan(P.feat[3 * g + q], gf[q], mf, vf, df, pf, a_feat);
-            P.m_feat[3 * g + q] = mf, P.v_feat[3 * g + q] = vf, P.d_feat[3 * g + q] = df, P.pg_feat[3 * g + q] = pf;
-        }
+        adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
     } else {
-        {
-            float m0 = P.m_xyz[2 * g], m1 = P.m_xyz[2 * g + 1], v0 = P.v_xyz[2 * g], v1 = P.v_xyz[2 * g + 1];
-            P.xyz[2 * g] = adam(P.xyz[2 * g], gx, m0, v0, a_xyz);
-            P.xyz[2 * g + 1] = adam(P.xyz[2 * g + 1], gy, m1, v1, a_xyz);
-            P.m_xyz[2 * g] = m0;
-            P.m_xyz[2 * g + 1] = m1;
-            P.v_xyz[2 * g] = v0;
-            P.v_xyz[2 * g + 1] = v1;
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float m = P.m_chol[3 * g + q], v = P.v_chol[3 * g + q];
-            P.chol[3 * g + q] = adam(P.chol[3 * g + q], gp[q], m, v, a_chol);
-            P.m_chol[3 * g + q] = m;
-            P.v_chol[3 * g + q] = v;
-            float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q];
-            P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
-            P.m_feat[3 * g + q] = mf;
-            P.v_feat[3 * g + q] = vf;
-        }
+        adam_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
@@ -681,31 +720,37 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
             float *d = dbg_grads + 8 * (size_t)g;
             d[0] = gx, d[1] = gy, d[2] = gp[0], d[3] = gp[1], d[4] = gp[2], d[5] = gf[0], d[6] = gf[1], d[7] = gf[2];
         }
-        {
-            float m0 = P.m_xyz[2 * g], m1 = P.m_xyz[2 * g + 1], v0 = P.v_xyz[2 * g], v1 = P.v_xyz[2 * g + 1];
-            P.xyz[2 * g] = adam(P.xyz[2 * g], gx, m0, v0, a_xyz);
-            P.xyz[2 * g + 1] = adam(P.xyz[2 * g + 1], gy, m1, v1, a_xyz);
-            P.m_xyz[2 * g] = m0, P.m_xyz[2 * g + 1] = m1, P.v_xyz[2 * g] = v0, P.v_xyz[2 * g + 1] = v1;
-        }
+        // Adam on whole rows; a parked variance keeps its value and moments (the finish kernel updates it)
         const float *bd = P.bound + (size_t)P.bound_stride * g;
+        {
+            const float2 x = load_row2(P.xyz, g);
+            float2 m_xy = load_row2(P.m_xyz, g), v_xy = load_row2(P.v_xyz, g);
+            const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
+            Row3 mc = load_row3(P.m_chol, g), vc = load_row3(P.v_chol, g), mf = load_row3(P.m_feat, g),
+                 vf = load_row3(P.v_feat, g);
+            const float nx = adam(x.x, gx, m_xy.x, v_xy.x, a_xyz), ny = adam(x.y, gy, m_xy.y, v_xy.y, a_xyz);
+            float cn[3] = {c.a, c.b, c.c}, cm[3] = {mc.a, mc.b, mc.c}, cv[3] = {vc.a, vc.b, vc.c};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (!parked[q]) {
-                float m = P.m_chol[3 * g + q], vv = P.v_chol[3 * g + q];
-                const float nv = adam(P.chol[3 * g + q], gp[q], m, vv, a_chol);
-                P.chol[3 * g + q] = nv;
-                P.m_chol[3 * g + q] = m;
-                P.v_chol[3 * g + q] = vv;
+            for (int q = 0; q < 3; ++q) {
+                if (parked[q]) continue;
+                cn[q] = adam(cn[q], gp[q], cm[q], cv[q], a_chol);
                 if (q != 1) {  // this variance's place in the NEXT iteration's log range
-                    const float t = quant_log_of(nv + bd[q]);
+                    const float t = quant_log_of(cn[q] + bd[q]);
                     range_min_combine(mn, cmn, t, 1.f);
                     range_max_combine(mx, cmx, t, 1.f);
                 }
             }
-            float mf = P.m_feat[3 * g + q], vf = P.v_feat[3 * g + q];
-            P.feat[3 * g + q] = adam(P.feat[3 * g + q], gf[q], mf, vf, a_feat);
-            P.m_feat[3 * g + q] = mf;
-            P.v_feat[3 * g + q] = vf;
+            const float f0 = adam(f.a, gf[0], mf.a, vf.a, a_feat), f1 = adam(f.b, gf[1], mf.b, vf.b, a_feat),
+                        f2 = adam(f.c, gf[2], mf.c, vf.c, a_feat);
+            store_row2(P.xyz, g, nx, ny);
+            store_row2(P.m_xyz, g, m_xy.x, m_xy.y);
+            store_row2(P.v_xyz, g, v_xy.x, v_xy.y);
+            store_row3(P.chol, g, cn[0], cn[1], cn[2]);
+            store_row3(P.m_chol, g, cm[0], cm[1], cm[2]);
+            store_row3(P.v_chol, g, cv[0], cv[1], cv[2]);
+            store_row3(P.feat, g, f0, f1, f2);
+            store_row3(P.m_feat, g, mf.a, mf.b, mf.c);
+            store_row3(P.v_feat, g, vf.a, vf.b, vf.c);
         }
         if (snapshot) {
             best.xyz[2 * g] = P.xyz[2 * g];
