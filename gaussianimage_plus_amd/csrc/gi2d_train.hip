@@ -41,22 +41,39 @@ struct BestSnap {
     int num_tiles, step;
 };
 
+// Whole-row accesses of the [N,2] / [N,3] parameter and moment arrays: one 8- or 12-byte memory instruction per row
+// instead of one per float (the arrays may alias as far as the compiler knows, which keeps it from merging them).
+struct Row3 {
+    float a, b, c;
+};
+__device__ __forceinline__ Row3 load_row3(const float *p, int g) { return *reinterpret_cast<const Row3 *>(p + 3 * (size_t)g); }
+__device__ __forceinline__ void store_row3(float *p, int g, float a, float b, float c) {
+    Row3 r;
+    r.a = a, r.b = b, r.c = c;
+    *reinterpret_cast<Row3 *>(p + 3 * (size_t)g) = r;
+}
+__device__ __forceinline__ float2 load_row2(const float *p, int g) { return reinterpret_cast<const float2 *>(p)[g]; }
+__device__ __forceinline__ void store_row2(float *p, int g, float a, float b) {
+    reinterpret_cast<float2 *>(p)[g] = make_float2(a, b);
+}
+
 template <int KIND>
 __device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &mean, float (&par)[3]) {
-    const float x = P.xyz[2 * g], y = P.xyz[2 * g + 1];
+    const float2 xy = load_row2(P.xyz, g);
+    const float x = xy.x, y = xy.y;
     if (KIND == kCholesky)
         mean = make_float2(tanhf(x), tanhf(y));  // get_xyz
     else
         mean = make_float2(x, y);
     const float *bd = P.bound + (size_t)P.bound_stride * g;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) par[q] = P.chol[3 * g + q] + bd[q];  // get_cholesky_elements / get_cov2d_elements
+    const Row3 raw = load_row3(P.chol, g);
+    par[0] = raw.a + bd[0], par[1] = raw.b + bd[1], par[2] = raw.c + bd[2];  // get_cholesky_elements / get_cov2d_elements
     if (KIND == kScaleRot) {
         // models/gaussianimage_rs.py:166-172: scaling = |_scaling + bound|, rotation = sigmoid(_rotation) * 2 pi;
         // `chol` holds (_scaling.x, _scaling.y, _rotation), `bound` (0.5, 0.5, unused)
         par[0] = fabsf(par[0]);
         par[1] = fabsf(par[1]);
-        par[2] = (1.f / (1.f + __expf(-P.chol[3 * g + 2]))) * 6.283185307179586f;
+        par[2] = (1.f / (1.f + __expf(-raw.c))) * 6.283185307179586f;
     }
 }
 // p1 argument of the projection routines: the rotation of the scale-rot model sits in par[2]
@@ -110,22 +127,6 @@ __device__ __forceinline__ float adam(float p, float g, float &m, float &v, cons
     v = v * a.b2 + a.one_minus_b2 * (g * g);          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     return p - a.step_size * (m / denom);             // param.addcdiv_(exp_avg, denom, value=-step_size)
-}
-
-// Whole-row accesses of the [N,2] / [N,3] parameter and moment arrays: one 8- or 12-byte memory instruction per row
-// instead of one per float (the arrays may alias as far as the compiler knows, which keeps it from merging them).
-struct Row3 {
-    float a, b, c;
-};
-__device__ __forceinline__ Row3 load_row3(const float *p, int g) { return *reinterpret_cast<const Row3 *>(p + 3 * (size_t)g); }
-__device__ __forceinline__ void store_row3(float *p, int g, float a, float b, float c) {
-    Row3 r;
-    r.a = a, r.b = b, r.c = c;
-    *reinterpret_cast<Row3 *>(p + 3 * (size_t)g) = r;
-}
-__device__ __forceinline__ float2 load_row2(const float *p, int g) { return reinterpret_cast<const float2 *>(p)[g]; }
-__device__ __forceinline__ void store_row2(float *p, int g, float a, float b) {
-    reinterpret_cast<float2 *>(p)[g] = make_float2(a, b);
 }
 
 // torch.optim.Adam on one gaussian's (xyz, chol, feat) rows; every row is read and written whole.
@@ -394,16 +395,17 @@ struct QuantRow {
 __device__ __forceinline__ void quantise_row(const TrainParams &P, const QuantTrain &Q, const QuantVals &v, int g,
                                              QuantRow &r) {
     const float *bd = P.bound + (size_t)P.bound_stride * g;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) r.xy[q] = quant_eval<GI2D_QUANT_LSQ>(P.xyz[2 * g + q], v.xs[q], v.xb[q], 0.f, Q.qmax_xy);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) r.covx[q] = P.chol[3 * g + q] + bd[q];
+    const float2 xy = load_row2(P.xyz, g);
+    r.xy[0] = quant_eval<GI2D_QUANT_LSQ>(xy.x, v.xs[0], v.xb[0], 0.f, Q.qmax_xy);
+    r.xy[1] = quant_eval<GI2D_QUANT_LSQ>(xy.y, v.xs[1], v.xb[1], 0.f, Q.qmax_xy);
+    const Row3 raw = load_row3(P.chol, g), col = load_row3(P.feat, g);
+    r.covx[0] = raw.a + bd[0], r.covx[1] = raw.b + bd[1], r.covx[2] = raw.c + bd[2];
     r.cov[0] = quant_eval<GI2D_QUANT_LOG>(r.covx[0], v.lscale, v.lbeta, 0.f, Q.qmax_cov);
     r.cov[1] = quant_eval<GI2D_QUANT_LSQ>(r.covx[1], v.cs, v.cb, 0.f, Q.qmax_cov);
     r.cov[2] = quant_eval<GI2D_QUANT_LOG>(r.covx[2], v.lscale, v.lbeta, 0.f, Q.qmax_cov);
+    const float cin[3] = {col.a, col.b, col.c};
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-        r.col[q] = quant_eval<GI2D_QUANT_LSQ>(P.feat[3 * g + q], v.fs[q], v.fb[q], 0.f, Q.qmax_col);
+    for (int q = 0; q < 3; ++q) r.col[q] = quant_eval<GI2D_QUANT_LSQ>(cin[q], v.fs[q], v.fb[q], 0.f, Q.qmax_col);
 }
 
 __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
