@@ -43,8 +43,13 @@ struct BestSnap {
 
 // Whole-row accesses of the [N,2] / [N,3] parameter and moment arrays: one 8- or 12-byte memory instruction per row
 // instead of one per float (the arrays may alias as far as the compiler knows, which keeps it from merging them).
-struct Row3 {
+// The row types are may_alias: the same memory is also read and written as plain floats (snapshot copies, parked
+// entries), and without the attribute type-based alias analysis may move such a float access across a row access.
+struct __attribute__((may_alias)) Row3 {
     float a, b, c;
+};
+struct __attribute__((may_alias, aligned(8))) Row2 {
+    float x, y;
 };
 __device__ __forceinline__ Row3 load_row3(const float *p, int g) { return *reinterpret_cast<const Row3 *>(p + 3 * (size_t)g); }
 __device__ __forceinline__ void store_row3(float *p, int g, float a, float b, float c) {
@@ -52,21 +57,23 @@ __device__ __forceinline__ void store_row3(float *p, int g, float a, float b, fl
     r.a = a, r.b = b, r.c = c;
     *reinterpret_cast<Row3 *>(p + 3 * (size_t)g) = r;
 }
-__device__ __forceinline__ float2 load_row2(const float *p, int g) { return reinterpret_cast<const float2 *>(p)[g]; }
+__device__ __forceinline__ float2 load_row2(const float *p, int g) {
+    const Row2 r = reinterpret_cast<const Row2 *>(p)[g];
+    return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ void store_row2(float *p, int g, float a, float b) {
-    reinterpret_cast<float2 *>(p)[g] = make_float2(a, b);
+    Row2 r;
+    r.x = a, r.y = b;
+    reinterpret_cast<Row2 *>(p)[g] = r;
 }
 
+// Activations of one gaussian from its raw parameter rows (already in registers)
 template <int KIND>
-__device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &mean, float (&par)[3]) {
-    const float2 xy = load_row2(P.xyz, g);
-    const float x = xy.x, y = xy.y;
+__device__ __forceinline__ void activate_rows(float2 xy, Row3 raw, const float *bd, float2 &mean, float (&par)[3]) {
     if (KIND == kCholesky)
-        mean = make_float2(tanhf(x), tanhf(y));  // get_xyz
+        mean = make_float2(tanhf(xy.x), tanhf(xy.y));  // get_xyz
     else
-        mean = make_float2(x, y);
-    const float *bd = P.bound + (size_t)P.bound_stride * g;
-    const Row3 raw = load_row3(P.chol, g);
+        mean = xy;
     par[0] = raw.a + bd[0], par[1] = raw.b + bd[1], par[2] = raw.c + bd[2];  // get_cholesky_elements / get_cov2d_elements
     if (KIND == kScaleRot) {
         // models/gaussianimage_rs.py:166-172: scaling = |_scaling + bound|, rotation = sigmoid(_rotation) * 2 pi;
@@ -75,6 +82,10 @@ __device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &me
         par[1] = fabsf(par[1]);
         par[2] = (1.f / (1.f + __expf(-raw.c))) * 6.283185307179586f;
     }
+}
+template <int KIND>
+__device__ __forceinline__ void activate(const TrainParams &P, int g, float2 &mean, float (&par)[3]) {
+    activate_rows<KIND>(load_row2(P.xyz, g), load_row3(P.chol, g), P.bound + (size_t)P.bound_stride * g, mean, par);
 }
 // p1 argument of the projection routines: the rotation of the scale-rot model sits in par[2]
 template <int KIND>
@@ -132,7 +143,7 @@ __device__ __forceinline__ float adam(float p, float g, float &m, float &v, cons
 // torch.optim.Adam on one gaussian's (xyz, chol, feat) rows; every row is read and written whole.
 __device__ __forceinline__ void adam_rows(const TrainParams &P, int g, float gx, float gy, const float (&gp)[3],
                                           const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
-                                          const AdamStep &a_feat) {
+                                          const AdamStep &a_feat, float2 &new_xy, Row3 &new_chol) {
     const float2 x = load_row2(P.xyz, g);
     float2 mx = load_row2(P.m_xyz, g), vx = load_row2(P.v_xyz, g);
     const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
@@ -142,6 +153,8 @@ __device__ __forceinline__ void adam_rows(const TrainParams &P, int g, float gx,
                 c2 = adam(c.c, gp[2], mc.c, vc.c, a_chol);
     const float f0 = adam(f.a, gf[0], mf.a, vf.a, a_feat), f1 = adam(f.b, gf[1], mf.b, vf.b, a_feat),
                 f2 = adam(f.c, gf[2], mf.c, vf.c, a_feat);
+    new_xy = make_float2(nx, ny);
+    new_chol.a = c0, new_chol.b = c1, new_chol.c = c2;
     store_row2(P.xyz, g, nx, ny);
     store_row2(P.m_xyz, g, mx.x, mx.y);
     store_row2(P.v_xyz, g, vx.x, vx.y);
@@ -157,7 +170,7 @@ __device__ __forceinline__ float adan(float p, float g, float &m, float &n, floa
 // Adan on one gaussian's rows, every row read and written whole (five state arrays per parameter group).
 __device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx, float gy, const float (&gp)[3],
                                           const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
-                                          const AdamStep &a_feat) {
+                                          const AdamStep &a_feat, float2 &new_xy, Row3 &new_chol) {
     const float2 x = load_row2(P.xyz, g);
     float2 m = load_row2(P.m_xyz, g), v = load_row2(P.v_xyz, g), d = load_row2(P.d_xyz, g), pg = load_row2(P.pg_xyz, g);
     const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
@@ -168,6 +181,8 @@ __device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx,
                 c2 = adan(c.c, gp[2], mc.c, vc.c, dc.c, pc.c, a_chol);
     const float f0 = adan(f.a, gf[0], mf.a, vf.a, df.a, pf.a, a_feat), f1 = adan(f.b, gf[1], mf.b, vf.b, df.b, pf.b, a_feat),
                 f2 = adan(f.c, gf[2], mf.c, vf.c, df.c, pf.c, a_feat);
+    new_xy = make_float2(nx, ny);
+    new_chol.a = c0, new_chol.b = c1, new_chol.c = c2;
     store_row2(P.xyz, g, nx, ny);
     store_row2(P.m_xyz, g, m.x, m.y);
     store_row2(P.v_xyz, g, v.x, v.y);
@@ -300,10 +315,12 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         d[6] = gf[1];
         d[7] = gf[2];
     }
+    float2 new_xy;
+    Row3 new_chol;
     if (ADAN) {
-        adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
+        adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
     } else {
-        adam_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
+        adam_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
@@ -312,9 +329,14 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
             next.status[1] = 0;
             next.status[3] = 0;
         }
+        // From the rows just written, still in registers (no store -> load round trip).  The empty asm makes them
+        // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
+        // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
+        // would no longer be bitwise equal to the same iterations issued one by one (1-ulp differences, measured).
+        asm volatile("" : "+v"(new_xy.x), "+v"(new_xy.y), "+v"(new_chol.a), "+v"(new_chol.b), "+v"(new_chol.c));
         float2 mean2;
         float par2[3];
-        activate<KIND>(P, g, mean2, par2);
+        activate_rows<KIND>(new_xy, new_chol, P.bound + (size_t)P.bound_stride * g, mean2, par2);
         const ProjOut o =
             project_one<KIND>(0, next.clip_coe, &mean2, par2, rot_of<KIND>(par2), img_w, img_h, tiles_x, tiles_y,
                               radius_clip);
