@@ -141,29 +141,39 @@ __device__ __forceinline__ float adam(float p, float g, float &m, float &v, cons
 }
 
 // torch.optim.Adam on one gaussian's (xyz, chol, feat) rows; every row is read and written whole.
-__device__ __forceinline__ void adam_rows(const TrainParams &P, int g, float gx, float gy, const float (&gp)[3],
-                                          const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
-                                          const AdamStep &a_feat, float2 &new_xy, Row3 &new_chol) {
-    const float2 x = load_row2(P.xyz, g);
-    float2 mx = load_row2(P.m_xyz, g), vx = load_row2(P.v_xyz, g);
-    const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
-    Row3 mc = load_row3(P.m_chol, g), vc = load_row3(P.v_chol, g), mf = load_row3(P.m_feat, g), vf = load_row3(P.v_feat, g);
-    const float nx = adam(x.x, gx, mx.x, vx.x, a_xyz), ny = adam(x.y, gy, mx.y, vx.y, a_xyz);
-    const float c0 = adam(c.a, gp[0], mc.a, vc.a, a_chol), c1 = adam(c.b, gp[1], mc.b, vc.b, a_chol),
-                c2 = adam(c.c, gp[2], mc.c, vc.c, a_chol);
-    const float f0 = adam(f.a, gf[0], mf.a, vf.a, a_feat), f1 = adam(f.b, gf[1], mf.b, vf.b, a_feat),
-                f2 = adam(f.c, gf[2], mf.c, vf.c, a_feat);
+struct AdamRows {
+    float2 x, mx, vx;
+    Row3 c, f, mc, vc, mf, vf;
+};
+// All nine rows of one gaussian.  The update kernel issues these loads before its gradient gather, so they are in
+// flight during the gather's dependent memory rounds instead of forming one more round after it.
+__device__ __forceinline__ AdamRows adam_load_rows(const TrainParams &P, int g) {
+    AdamRows r;
+    r.x = load_row2(P.xyz, g), r.mx = load_row2(P.m_xyz, g), r.vx = load_row2(P.v_xyz, g);
+    r.c = load_row3(P.chol, g), r.f = load_row3(P.feat, g);
+    r.mc = load_row3(P.m_chol, g), r.vc = load_row3(P.v_chol, g), r.mf = load_row3(P.m_feat, g), r.vf = load_row3(P.v_feat, g);
+    return r;
+}
+__device__ __forceinline__ void adam_rows(const TrainParams &P, int g, AdamRows r, float gx, float gy,
+                                          const float (&gp)[3], const float (&gf)[3], const AdamStep &a_xyz,
+                                          const AdamStep &a_chol, const AdamStep &a_feat, float2 &new_xy,
+                                          Row3 &new_chol) {
+    const float nx = adam(r.x.x, gx, r.mx.x, r.vx.x, a_xyz), ny = adam(r.x.y, gy, r.mx.y, r.vx.y, a_xyz);
+    const float c0 = adam(r.c.a, gp[0], r.mc.a, r.vc.a, a_chol), c1 = adam(r.c.b, gp[1], r.mc.b, r.vc.b, a_chol),
+                c2 = adam(r.c.c, gp[2], r.mc.c, r.vc.c, a_chol);
+    const float f0 = adam(r.f.a, gf[0], r.mf.a, r.vf.a, a_feat), f1 = adam(r.f.b, gf[1], r.mf.b, r.vf.b, a_feat),
+                f2 = adam(r.f.c, gf[2], r.mf.c, r.vf.c, a_feat);
     new_xy = make_float2(nx, ny);
     new_chol.a = c0, new_chol.b = c1, new_chol.c = c2;
     store_row2(P.xyz, g, nx, ny);
-    store_row2(P.m_xyz, g, mx.x, mx.y);
-    store_row2(P.v_xyz, g, vx.x, vx.y);
+    store_row2(P.m_xyz, g, r.mx.x, r.mx.y);
+    store_row2(P.v_xyz, g, r.vx.x, r.vx.y);
     store_row3(P.chol, g, c0, c1, c2);
-    store_row3(P.m_chol, g, mc.a, mc.b, mc.c);
-    store_row3(P.v_chol, g, vc.a, vc.b, vc.c);
+    store_row3(P.m_chol, g, r.mc.a, r.mc.b, r.mc.c);
+    store_row3(P.v_chol, g, r.vc.a, r.vc.b, r.vc.c);
     store_row3(P.feat, g, f0, f1, f2);
-    store_row3(P.m_feat, g, mf.a, mf.b, mf.c);
-    store_row3(P.v_feat, g, vf.a, vf.b, vf.c);
+    store_row3(P.m_feat, g, r.mf.a, r.mf.b, r.mf.c);
+    store_row3(P.v_feat, g, r.vf.a, r.vf.b, r.vf.c);
 }
 
 __device__ __forceinline__ float adan(float p, float g, float &m, float &n, float &d, float &pg, const AdamStep &a);
@@ -270,6 +280,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         return;
     }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    AdamRows rows;
+    if (!ADAN && g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
     reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
@@ -277,7 +289,10 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (g >= n) return;
     float2 mean;
     float par[3];
-    activate<KIND>(P, g, mean, par);
+    if (ADAN)
+        activate<KIND>(P, g, mean, par);
+    else
+        activate_rows<KIND>(rows.x, rows.c, P.bound + (size_t)P.bound_stride * g, mean, par);
     ProjGrad r;
     r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
     r.v_mean = make_float2(0.f, 0.f);
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (ADAN) {
         adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
     } else {
-        adam_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
+        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
