@@ -82,7 +82,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[dev_index])  # this rank's own GPU, stated rather than guessed
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -152,7 +155,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(xyz, L, col, op, h, w, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

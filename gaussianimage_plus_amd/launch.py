@@ -331,7 +331,7 @@ def main(argv=None):
     group = args.images_per_gpu if args.loop == "native" else 1
     out = run_sharded(images, fit_one, rank, world, device=dev, group=group, fit_group=fit_group)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
     wall = time.time() - t0
     if rank == 0:
         print(f"Average: {args.width}x{args.height}, PSNR:{out['avg_psnr']:.4f}, Training:{out['avg_train_s']:.4f}s, "
