@@ -586,7 +586,7 @@ static int reduce_project_impl(int kind, int n, const float *p0, const float *p1
     np.cursors = w.cursors;
     np.buckets = w.buckets;
     const int bs = per_gaussian_block(n);
-    np.tile_order = (next && bs == 256) ? w.tile_order : nullptr;
+    np.tile_order = (next && n > 32768) ? w.tile_order : nullptr;
     const dim3 grid((n + bs - 1) / bs + (np.tile_order ? 1 : 0)), block(bs);
 #define GI2D_LAUNCH_RP(K, F)                                                                                        \
     hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, (float2 *)xys, radii, \

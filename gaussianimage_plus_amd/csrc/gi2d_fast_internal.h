@@ -26,7 +26,10 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // Workgroup size of the one-lane-per-gaussian kernels (project+fill, reduce+project backward, optimizer update):
 // single waves spread a small population over many CUs and shorten the dependent atomic / load chains
 // (N=2500: project+fill 10.9 -> 5.5 us, reduce 7.4 -> 4.7 us; neutral to slightly worse beyond ~30k gaussians).
-static inline int per_gaussian_block(int n) { return n <= 32768 ? 64 : 256; }
+#ifndef GI2D_PG_BIG
+#define GI2D_PG_BIG 256
+#endif
+static inline int per_gaussian_block(int n) { return n <= 32768 ? 64 : GI2D_PG_BIG; }
 struct FastWs {
     int32_t *cursors;      // [T * SUB]          zero between calls
     int32_t *buckets;      // [T * C]            unsorted ids per (tile, sub)
