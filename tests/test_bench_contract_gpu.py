@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "24", "--warmup", "4",
-           "--num-points", "3000", "--height", "96", "--width", "144", "--cpu-seconds", "0.5"]
+           "--num-points", "3000", "--height", "96", "--width", "144", "--cpu-seconds", "1.5", "--images", "2",
+           "--image-iterations", "200", "--images-per-gpu", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -31,10 +32,36 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert r["traffic"] is None  # the committed counters are for the default workload, not this one
+    assert r["traffic_source"].startswith("none:")
+    assert d["metric"].endswith("144x96")
+    im = d["images_per_s"]
+    assert im["unit"] == "images/s" and im["images"] == 2 and im["iterations_per_image"] == 200 and im["value"] > 0
+    assert abs(im["value"] - im["images"] / im["wall_s"]) <= 1e-9 * im["value"]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
+    assert c["config1_train_loop"]["value"] > 0 and "N=2500" in c["config1_train_loop"]["sample"]
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks (here both on the one GPU of
+    the box, rendezvous over gloo) and relays rank 0's line, which must say n_gpus = 2 and carry the whole-job rate."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4",
+           "--num-points", "3000", "--height", "96", "--width", "144", "--images", "2", "--image-iterations", "100",
+           "--images-per-gpu", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GI2D_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert d["images_per_s"]["images"] == 2 and "rank i mod 2" in d["images_per_s"]["workload"]
 
 
 def test_launcher_cli_runs_both_loops_and_reports_the_average_line():
