@@ -64,7 +64,11 @@ def test_projection_forward_matches_golden(C, oracle, golden_dir):
         assert n(depths).max() == 0 and n(depths).min() == 0
         # integer outputs: exact, except gaussians whose radius sits on a ceil() boundary
         same = (n(radii) == g["radii"]) & (n(nth) == g["num_tiles_hit"])
-        assert same.mean() > 0.995, f"{name}: radii/num_tiles_hit differ on {(~same).sum()} gaussians"
+        # Same operations in the same order with IEEE divide / sqrt and no contraction: the integers must agree
+        # exactly.  Only the scale-rot covariance goes through sin/cos (device vs libm, last-ulp differences), which
+        # can move a radius that sits on a ceil() edge: at most one gaussian in a thousand.
+        print(f"{name}: radii / num_tiles_hit differ on {int((~same).sum())} of {same.size} gaussians")
+        assert int((~same).sum()) <= (max(1, same.size // 1000) if kind == "scale_rot" else 0), name
         keep = same & (g["radii"] > 0)
         check_close(name + " xys", n(xys)[keep], g["xys"][keep], np.abs(g["xys"][keep]) + 1, rtol=RTOL)
         # conic entries cancel against each other (and scale-rot goes through device sin/cos): the yardstick
@@ -124,7 +128,7 @@ def test_compute_cov2d_bounds(C, oracle):
     co, ro = oracle.compute_cov2d_bounds(cov3, 3.0)
     assert radii.shape == (100, 1)
     check_close("conics", n(conics), co, np.abs(co), rtol=2 * RTOL)
-    assert (n(radii) == ro).mean() >= 0.99
+    assert np.array_equal(n(radii), ro)
 
 
 # ------------------------------------------------------------------------------- binning (bit-exact)
@@ -283,7 +287,9 @@ def test_full_path_at_baseline_sizes(C, oracle, npts, h, w):
 
     xys, depths, radii, conics, nth = C.project_gaussians_2d_forward(npts, 3.0, t(xyz), t(L), h, w, tb, 0.01, 1.0, False)
     same = (n(radii) == ref["radii"]) & (n(nth) == ref["num_tiles_hit"])
-    assert same.mean() > 0.9995
+    print(f"N={npts}: radii / num_tiles_hit differ on {int((~same).sum())} gaussians")
+    assert same.all()  # Cholesky projection: integer outputs bit-exact (no transcendental on the way)
+    assert np.array_equal(n(xys), ref["xys"]) and np.array_equal(n(conics), ref["conics"])
     # binning + rasterizer on the ORACLE's projection so that index work can be compared exactly
     xys_t, conics_t, radii_t = t(ref["xys"]), t(ref["conics"]), t(ref["radii"])
     cum, total = C.cumsum_tiles_hit(t(ref["num_tiles_hit"]))

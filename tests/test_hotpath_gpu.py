@@ -182,7 +182,8 @@ def test_scale_rot_kind_at_config5_size(oracle):
     po = oracle.project_gaussians_2d_scale_rot_forward(n, 3.0, mean_px, scales, rot, h, w, tb, 0.01, 1.0)
     d_xys, d_conics, d_radii, d_nth = [t.cpu().numpy() for t in (res[0][5], res[0][6], res[0][7], res[0][8])]
     same = (d_radii == po[2]) & (d_nth == po[4])
-    assert same.mean() > 0.999
+    print(f"scale-rot N={n}: radii / num_tiles_hit differ on {int((~same).sum())} gaussians (device sin/cos vs libm)")
+    assert int((~same).sum()) <= n // 1000
     cs = np.abs(po[3][same]).max(axis=-1, keepdims=True)
     check_close("rs conics", d_conics[same], po[3][same], cs, rtol=4e-5)
     m, cum = oracle.compute_cumulative_intersects(d_nth)
