@@ -12,16 +12,21 @@ def cases(golden_dir):
     return sorted(glob.glob(os.path.join(golden_dir, "case_*.npz")))
 
 
-def test_reference_crosscheck_record_is_clean(golden_dir):
-    """tests/golden/make_golden.py compared the oracle's helpers with the reference's own CPU code
-    (gsplat/gsplat/_torch_impl.py) in the dev container; the committed record must show zero mismatches."""
-    rep = json.load(open(os.path.join(golden_dir, "ref_crosscheck.json")))
-    assert rep["compute_cov2d_bounds"]["radius_mismatch"] == 0 and rep["compute_cov2d_bounds"]["conic_max_rel"] < 1e-6
-    assert rep["get_tile_bbox"]["num_tiles_hit_mismatch"] == 0
-    assert rep["map_gaussian_to_intersects"]["isect_mismatch"] == 0 and rep["map_gaussian_to_intersects"]["gid_mismatch"] == 0
-    assert rep["sort_vs_torch_stable_sort"]["key_mismatch"] == 0 and rep["sort_vs_torch_stable_sort"]["gid_mismatch"] == 0
-    assert rep["get_tile_bin_edges"]["mismatch"] == 0
-    assert rep["cholesky_bwd_known_answer"]["max_abs_err_vs_reference_formula"] < 1e-6
+def test_cholesky_backward_known_answer(oracle):
+    """SURVEY fact 4, hand-derived (tests/golden/make_golden.py::cholesky_known_answer): L = (2, 1, 3), v_conic =
+    (1, 0, 0) -> v_cov2d = (-100, 40, -4)/1296 and, with the off-diagonal counted twice as backward2d.cu:39-41 does,
+    v_L = (-320, 152, -24)/1296 (the true gradient would be (-360, 72, -24)/1296).  The comparisons of the oracle's
+    helpers with the reference's own Python code are in tests/test_ref_vectors_cpu.py, against stored arrays."""
+    L = np.array([[2., 1., 3.]], np.float32)
+    xy = np.zeros((1, 2), np.float32)
+    tb = oracle.tile_bounds(64, 64)
+    xys, depths, radii, conics, nth = oracle.project_gaussians_2d_forward(1, 3.0, xy, L, 64, 64, tb, 0.01, 1.0)
+    np.testing.assert_allclose(conics[0], np.array([10., -2., 4.]) / 36., rtol=1e-6)
+    v_cov2d, v_mean, v_L = oracle.project_gaussians_2d_backward(
+        1, xy, L, 64, 64, radii, conics, np.array([[0.25, -0.5]], np.float32), None, np.array([[1., 0., 0.]], np.float32))
+    np.testing.assert_allclose(v_L[0], np.array([-320., 152., -24.]) / 1296., rtol=1e-6)
+    np.testing.assert_allclose(v_cov2d[0], np.array([-100., 40., -4.]) / 1296., rtol=1e-6)
+    np.testing.assert_allclose(v_mean[0], [8.0, -16.0], rtol=1e-7)
 
 
 def test_call_shape_record(golden_dir):
