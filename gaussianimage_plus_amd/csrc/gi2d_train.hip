@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
 //   * the log range of the NEXT iteration (min / max / tie counts of the updated variances).
 struct QuantTrain {
     float qmax_xy, qmax_cov, qmax_col;  // unsigned quantisers: qmin = 0
+    float qmin_rot, qmax_rot;           // rotation-scale model: the SIGNED rotation quantiser
     float *qparams;                     // [12] xy scale[2], xy beta[2], cov scale, cov beta, colour scale[3], colour beta[3]
     float *qm, *qv;                     // [12] Adam moments of qparams
     float *range;                       // [4] min log, max log, #elements at the min, #at the max (variance channels)
@@ -805,6 +806,214 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     block_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)blockIdx.x * GI2D_QT_ROW);
 }
 
+
+// =====================================================================================================================
+// Quantisation-aware iteration of the rotation-scale model (BASELINE config 5): GaussianImage_RS.forward_quantize /
+// train_iter_quantize (models/gaussianimage_rs.py:443-485) with the quantiser set of training_setup (:131-163): four
+// LSQ+ UniformQuantizers -- positions 12 bit unsigned (2 channels), the RAW `_scaling` 6 bit unsigned (2 channels; as
+// written, forward_quantize feeds the dequantised raw scaling to the projection without |. + bound|, :451-453),
+// rotation = sigmoid(_rotation) * 2 pi 6 bit SIGNED (1 channel), colours 6 bit unsigned (3 channels).  Every range is a
+// learned (scale, beta) pair, so there is no data-dependent range and nothing to park: the update kernel leaves 16
+// partial sums per workgroup and a one-workgroup kernel closes them with Adam on the 16 quantiser values
+//   qparams = xy scale[2], xy beta[2], scaling scale[2], scaling beta[2], rotation scale, beta, colour scale[3], beta[3]
+// (optimizer groups as the model file creates them: positions eps 1e-8; scaling + rotation together, eps 1e-15;
+// colours eps 1e-15 -- stepped every iteration like GaussianImage_Covariance.optimizer_step does, :235-247 there).
+#define GI2D_QT_RS_SUMS 16
+struct QuantValsRS {
+    float xs[2], xb[2], ss[2], sb[2], rs, rb, fs[3], fb[3];
+};
+__device__ __forceinline__ QuantValsRS load_quant_rs(const QuantTrain &Q) {
+    QuantValsRS v;
+    const float4 *q4 = reinterpret_cast<const float4 *>(Q.qparams);  // 64-byte aligned by contract
+    const float4 a = q4[0], b = q4[1], c = q4[2], d = q4[3];
+    v.xs[0] = a.x, v.xs[1] = a.y, v.xb[0] = a.z, v.xb[1] = a.w;
+    v.ss[0] = b.x, v.ss[1] = b.y, v.sb[0] = b.z, v.sb[1] = b.w;
+    v.rs = c.x, v.rb = c.y, v.fs[0] = c.z, v.fs[1] = c.w;
+    v.fs[2] = d.x, v.fb[0] = d.y, v.fb[1] = d.z, v.fb[2] = d.w;
+    return v;
+}
+struct QuantRowRS {
+    QuantEval xy[2], sc[2], rot, col[3];
+    float sig;  // sigmoid(_rotation)
+};
+__device__ __forceinline__ void quantise_row_rs(const QuantTrain &Q, const QuantValsRS &v, float2 xy, Row3 raw,
+                                                Row3 col, QuantRowRS &r) {
+#pragma clang fp contract(off)
+    r.xy[0] = quant_eval<GI2D_QUANT_LSQ>(xy.x, v.xs[0], v.xb[0], 0.f, Q.qmax_xy);
+    r.xy[1] = quant_eval<GI2D_QUANT_LSQ>(xy.y, v.xs[1], v.xb[1], 0.f, Q.qmax_xy);
+    r.sc[0] = quant_eval<GI2D_QUANT_LSQ>(raw.a, v.ss[0], v.sb[0], 0.f, Q.qmax_cov);
+    r.sc[1] = quant_eval<GI2D_QUANT_LSQ>(raw.b, v.ss[1], v.sb[1], 0.f, Q.qmax_cov);
+    r.sig = 1.f / (1.f + expf(-raw.c));                                   // get_rotation: torch.sigmoid(_rotation)
+    r.rot = quant_eval<GI2D_QUANT_LSQ>(r.sig * 2.f * 3.14159265358979323846f, v.rs, v.rb, Q.qmin_rot, Q.qmax_rot);
+    const float cin[3] = {col.a, col.b, col.c};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.col[q] = quant_eval<GI2D_QUANT_LSQ>(cin[q], v.fs[q], v.fb[q], 0.f, Q.qmax_col);
+}
+
+__global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
+    int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
+    float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
+    int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors, int32_t *__restrict__ buckets,
+    int32_t *__restrict__ status) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) {
+        status[0] = 0;
+        status[1] = 0;
+        status[3] = 0;
+    }
+    if (g >= n) return;
+    const QuantValsRS v = load_quant_rs(Q);
+    QuantRowRS r;
+    quantise_row_rs(Q, v, load_row2(P.xyz, g), load_row3(P.chol, g), load_row3(P.feat, g), r);
+    const float2 mean = make_float2(r.xy[0].dequant, r.xy[1].dequant);
+    const float par[3] = {r.sc[0].dequant, r.sc[1].dequant, r.rot.dequant};
+    store_row3(Q.qfeat, g, r.col[0].dequant, r.col[1].dequant, r.col[2].dequant);
+    const ProjOut o =
+        project_one<kScaleRot>(0, clip_coe, &mean, par, &par[2], img_w, img_h, tiles_x, tiles_y, radius_clip);
+    xys[g] = o.xy;
+    radii[g] = o.radius;
+    conics[3 * g] = o.k0;
+    conics[3 * g + 1] = o.k1;
+    conics[3 * g + 2] = o.k2;
+    num_tiles_hit[g] = o.tiles_hit;
+    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
+        int mnx, mny, mxx, mxy;
+        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
+    }
+}
+
+__global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
+    int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
+    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
+    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
+#pragma clang fp contract(off)
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    AdamRows rows;
+    if (g < n) rows = adam_load_rows(P, g);
+    const bool snapshot = best_decision(best, n, g);
+    float acc[11];
+    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
+               partial_big, acc);
+    float sums[GI2D_QT_RS_SUMS];
+#pragma unroll
+    for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = 0.f;
+    if (g < n) {
+        const QuantValsRS v = load_quant_rs(Q);
+        QuantRowRS qr;
+        quantise_row_rs(Q, v, rows.x, rows.c, rows.f, qr);
+        const float par[3] = {qr.sc[0].dequant, qr.sc[1].dequant, qr.rot.dequant};
+        ProjGrad r;
+        r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
+        r.v_mean = make_float2(0.f, 0.f);
+        if (radii[g] > 0) {
+            const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
+            const float vc[3] = {acc[2], acc[3], acc[4]};
+            r = project_bwd_one<kScaleRot>(0, par, &par[2], img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
+        }
+        // quantiser backward; sums = (v_scale, v_beta) of xy.x, xy.y, scaling.x, scaling.y, rotation, colour r, g, b
+        const float gx = quant_grad<GI2D_QUANT_LSQ>(qr.xy[0], r.v_mean.x, v.xs[0], sums[0], sums[1]);
+        const float gy = quant_grad<GI2D_QUANT_LSQ>(qr.xy[1], r.v_mean.y, v.xs[1], sums[2], sums[3]);
+        float gp[3];
+        gp[0] = quant_grad<GI2D_QUANT_LSQ>(qr.sc[0], r.o0, v.ss[0], sums[4], sums[5]);
+        gp[1] = quant_grad<GI2D_QUANT_LSQ>(qr.sc[1], r.o1, v.ss[1], sums[6], sums[7]);
+        const float g_act = quant_grad<GI2D_QUANT_LSQ>(qr.rot, r.o2, v.rs, sums[8], sums[9]);
+        gp[2] = (g_act * (2.f * 3.14159265358979323846f)) * (qr.sig * (1.f - qr.sig));  // through * 2 pi, then sigmoid
+        float gf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            gf[q] = quant_grad<GI2D_QUANT_LSQ>(qr.col[q], acc[5 + q], v.fs[q], sums[10 + 2 * q], sums[11 + 2 * q]);
+        if (dbg_grads) {
+            float *d = dbg_grads + 8 * (size_t)g;
+            d[0] = gx, d[1] = gy, d[2] = gp[0], d[3] = gp[1], d[4] = gp[2], d[5] = gf[0], d[6] = gf[1], d[7] = gf[2];
+        }
+        float2 new_xy;
+        Row3 new_chol;
+        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
+        if (snapshot) {
+            best.xyz[2 * g] = P.xyz[2 * g];
+            best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                best.chol[3 * g + q] = P.chol[3 * g + q];
+                best.feat[3 * g + q] = P.feat[3 * g + q];
+                if (best.bound) best.bound[3 * g + q] = P.bound[(size_t)P.bound_stride * g + q];
+            }
+        }
+    }
+    // this workgroup's partial row (fixed order: wave sums, then waves in order)
+    __shared__ float red[4][GI2D_QT_RS_SUMS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = (int)blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = wave_sum(sums[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) red[wave][k] = sums[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < GI2D_QT_RS_SUMS) {
+        float t = red[0][threadIdx.x];
+        for (int w = 1; w < waves; ++w) t += red[w][threadIdx.x];
+        Q.partial[(size_t)blockIdx.x * GI2D_QT_ROW + threadIdx.x] = t;
+    }
+}
+
+// One workgroup: sums the partial rows in double (fixed order) and runs Adam on the 16 quantiser values.
+__global__ __launch_bounds__(256) void train_quant_finish_rs_kernel(int blocks, QuantTrain Q, AdamStep a_qxy,
+                                                                    AdamStep a_qcov, AdamStep a_qcol, BestSnap best) {
+#pragma clang fp contract(off)
+    __shared__ double lane_acc[256][GI2D_QT_RS_SUMS + 1];  // odd stride in 8-byte words
+    __shared__ double dred[16][GI2D_QT_RS_SUMS];
+    float q_p = 0.f, q_m = 0.f, q_v = 0.f;
+    if (threadIdx.x < GI2D_QT_RS_SUMS)
+        q_p = Q.qparams[threadIdx.x], q_m = Q.qm[threadIdx.x], q_v = Q.qv[threadIdx.x];
+    const bool snap = best.sse != nullptr && best.info[1] == best.step;
+    double acc[GI2D_QT_RS_SUMS];
+#pragma unroll
+    for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += (int)blockDim.x) {
+        const float4 *row = reinterpret_cast<const float4 *>(Q.partial + (size_t)b * GI2D_QT_ROW);
+        float4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = row[k];
+        const float *f = reinterpret_cast<const float *>(r);
+#pragma unroll
+        for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) acc[k] += (double)f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) lane_acc[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    const int k = threadIdx.x & 15, j = threadIdx.x >> 4;
+    {
+        double part = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part += lane_acc[j * 16 + i][k];
+        dred[j][k] = part;
+    }
+    __syncthreads();
+    if (threadIdx.x < GI2D_QT_RS_SUMS) {
+        const int q = threadIdx.x;
+        // slot q of qparams -> (channel, scale or beta): xs xs xb xb | ss ss sb sb | rs rb | fs fs fs fb fb fb
+        int ch, isb;
+        if (q < 4) ch = q & 1, isb = q >> 1;
+        else if (q < 8) ch = 2 + (q & 1), isb = (q - 4) >> 1;
+        else if (q < 10) ch = 4, isb = q - 8;
+        else ch = 5 + (q - 10) % 3, isb = (q - 10) / 3;
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += dred[w][2 * ch + isb];
+        const float grad = (float)t;
+        const AdamStep &a = q < 4 ? a_qxy : (q < 10 ? a_qcov : a_qcol);
+        const float nv = adam(q_p, grad, q_m, q_v, a);
+        Q.qparams[q] = nv;
+        Q.qm[q] = q_m;
+        Q.qv[q] = q_v;
+        if (Q.dbg_q) Q.dbg_q[q] = grad;
+        if (snap && Q.best_q) Q.best_q[q] = nv;
+    }
+}
+
 }  // namespace gi2d
 
 using namespace gi2d;
@@ -894,16 +1103,21 @@ static AdamStep make_adam_step(double lr, double beta1, double beta2, double bet
 
 static int quant_of(const gi2d_train_state *s, QuantTrain &Q) {
     const gi2d_train_quant *q = s->quant;
-    if (s->kind != 1 || s->optimizer != 0) {
-        set_error("train: quantisation is wired for the covariance model with Adam (train_quantize.py)");
+    if ((s->kind != 1 && s->kind != 2) || s->optimizer != 0) {
+        set_error("train: quantisation is wired for the covariance and the rotation-scale model with Adam "
+                  "(train_quantize.py; models/gaussianimage_rs.py:131-163)");
         return GI2D_ERR_UNSUPPORTED;
     }
+    const bool rs = s->kind == 2;
     if (q->xy_bits < 1 || q->xy_bits > 16 || q->cov_bits < 1 || q->cov_bits > 16 || q->color_bits < 1 ||
-        q->color_bits > 16 || !q->qparams || !q->qm || !q->qv || !q->range || !q->qfeat || !q->partial || !q->defer ||
-        q->defer_capacity < 2) {
+        q->color_bits > 16 || !q->qparams || !q->qm || !q->qv || !q->qfeat || !q->partial ||
+        (!rs && (!q->range || !q->defer || q->defer_capacity < 2)) || (rs && (q->rot_bits < 2 || q->rot_bits > 16)) ||
+        (rs && ((uintptr_t)q->qparams & 15))) {
         set_error("train: bad quantisation state");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
+    Q.qmin_rot = rs ? -(float)(1 << (q->rot_bits - 1)) : 0.f;
+    Q.qmax_rot = rs ? (float)((1 << (q->rot_bits - 1)) - 1) : 0.f;
     Q.qmax_xy = (float)((1 << q->xy_bits) - 1);
     Q.qmax_cov = (float)((1 << q->cov_bits) - 1);
     Q.qmax_col = (float)((1 << q->color_bits) - 1);
@@ -942,6 +1156,14 @@ static void train_launch_project_fill_quant(const gi2d_train_state *s, const Fas
                        s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
 }
 
+static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
+                                               const QuantTrain &Q, int tx, int ty, hipStream_t st) {
+    const int n = s->num_points, bs = per_gaussian_block(n);
+    hipLaunchKernelGGL(train_project_fill_quant_rs_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P,
+                       Q, (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
+                       s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+}
+
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
 int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
     int tx, ty;
@@ -956,8 +1178,12 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
         QuantTrain Q;
         rc = quant_of(s, Q);
         if (rc != GI2D_OK) return rc;
-        train_launch_quant_range(s, P, Q, st);
-        train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
+        if (s->kind == 2) {  // GaussianImage_RS.forward_quantize (models/gaussianimage_rs.py:443-471)
+            train_launch_project_fill_quant_rs(s, w, P, Q, tx, ty, st);
+        } else {
+            train_launch_quant_range(s, P, Q, st);
+            train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
+        }
         return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
                                            s->radii, s->conics, Q.qfeat, s->opacity, nullptr, s->workspace,
                                            s->workspace_bytes, s->status, nullptr, nullptr, s->out_img, st_);
@@ -1016,6 +1242,31 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
             return GI2D_ERR_INVALID_ARGUMENT;
         }
         const int bs = per_gaussian_block(n), blocks = (n + bs - 1) / bs;
+        if (s->kind == 2) {
+            for (int it = 0; it < count; ++it) {
+                const int step = first_step + it, qstep = q->first_step + it;
+                train_launch_project_fill_quant_rs(s, w, P, Q, tx, ty, st);
+                rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
+                                                          s->xys, s->radii, s->conics, Q.qfeat, s->opacity, nullptr,
+                                                          nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
+                                                          s->workspace_bytes, s->status, s->out_img, st_);
+                if (rc != GI2D_OK) return rc;
+                AdamStep a[3], aq[3];
+                for (int k = 0; k < 3; ++k) {
+                    a[k] = make_adam_step(lr[k], beta1, beta2, 0.0, eps, step, false);
+                    aq[k] = make_adam_step(q->lr[k], q->beta1, q->beta2, 0.0, q->eps[k], qstep, false);
+                }
+                best.step = step;
+                hipLaunchKernelGGL(train_reduce_update_quant_rs_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
+                                   (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
+                                   s->radius_clip, (const int32_t *)w.gids_sorted, (const int2 *)w.tile_bins,
+                                   (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
+                                   (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best);
+                hipLaunchKernelGGL(train_quant_finish_rs_kernel, dim3(1), dim3(256), 0, st, blocks, Q, aq[0], aq[1],
+                                   aq[2], best);
+            }
+            return check_launch("train steps (quantised, rotation-scale)");
+        }
         train_launch_quant_range(s, P, Q, st);
         for (int it = 0; it < count; ++it) {
             const int step = first_step + it, qstep = q->first_step + it;

@@ -95,8 +95,9 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
 
     dev = gts[0].device
     adaptive = kind == "covariance" and max_points > num_points
-    if quantize and kind != "covariance":
-        raise ValueError("quantisation-aware fitting is wired for the covariance model (train_quantize.py)")
+    if quantize and kind == "cholesky":
+        raise ValueError("quantisation-aware fitting is wired for the covariance model (train_quantize.py) and the "
+                         "rotation-scale model (models/gaussianimage_rs.py:131-163)")
     fitters = [NativeFitter(gt, num_points, kind=kind, lr=lr, seed=seed, eps=eps, optimizer=optimizer,
                             max_points=max_points if adaptive else None, track_best=adaptive or quantize)
                for gt in gts]
@@ -148,10 +149,10 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
             if adaptive or quantize:
                 f.load_best()
             t0 = time.time()
-            for _ in range(eval_renders):
+            for _ in range(max(int(eval_renders), 1)):  # at least one render: the PSNR below needs it
                 img = f.render()
             st.synchronize()
-            eval_s = (time.time() - t0) / max(eval_renders, 1)
+            eval_s = (time.time() - t0) / max(int(eval_renders), 1)
             mse = torch.nn.functional.mse_loss(img, f.gt).item()
         row = {"psnr": 10 * math.log10(1.0 / max(mse, 1e-12)), "train_s": train_s, "eval_s": eval_s,
                "num_gaussians": f.n, "mse": mse}
@@ -268,11 +269,14 @@ def main(argv=None):
     ap.add_argument("--single_host_thread", action="store_true",
                     help="issue the concurrent images' launches round-robin from one host thread instead")
     ap.add_argument("--quantize", action="store_true",
-                    help="train_quantize.py's loop (covariance model): plain fitting up to --warmup_iter, then "
-                         "quantisation-aware iterations; reports bits per pixel and the PSNR of the decoded image")
+                    help="train_quantize.py's loop (covariance model, or scale_rot with that model's quantiser set): "
+                         "plain fitting up to --warmup_iter, then quantisation-aware iterations; reports bits per pixel "
+                         "and the PSNR of the decoded image")
     ap.add_argument("--warmup_iter", type=int, default=6000)
     ap.add_argument("--xy_bit", type=int, default=12)
-    ap.add_argument("--cov_bit", type=int, default=10)
+    ap.add_argument("--cov_bit", type=int, default=None,
+                    help="covariance model: HybirdQuant bits (default 10); scale_rot: bits of the scaling quantiser "
+                         "(default 6, models/gaussianimage_rs.py:142)")
     ap.add_argument("--color_bit", type=int, default=6)
     ap.add_argument("--loop", choices=["native", "autograd"], default="native",
                     help="native: fused training iteration (gi2d_train_step); autograd: gsplat wrappers + torch Adam")
@@ -296,20 +300,29 @@ def main(argv=None):
         args.lr = 0.018 if cov else 0.001
     if args.opt_type is None:
         args.opt_type = "adam" if cov else "adan"
+    if args.cov_bit is None:
+        args.cov_bit = 10 if cov else 6
+    if args.quantize and args.model != "cholesky" and args.opt_type != "adam":
+        args.opt_type = "adam"  # training_setup(quantize=True) rebuilds the optimizer as Adam; run the warm-up on it too
+    # eps as the reference passes it: 1e-15 only for the covariance model's grouped Adam
+    # (models/gaussianimage_covariance.py:98); Adan(self.parameters(), lr) and the plain Adam keep the 1e-8 default
+    # (optimizer.py:69, models/gaussianimage_rs.py:111, models/gaussianimage_cholesky.py:113,129)
+    eps = 1e-15 if (cov and args.opt_type == "adam") else 1e-8
     native_kw = dict(lr=args.lr, seed=args.seed, kind=args.model, max_points=args.max_num_points,
-                     prune_iter=args.prune_iter, grow_iter=args.grow_iter, eps=1e-15, optimizer=args.opt_type,
+                     prune_iter=args.prune_iter, grow_iter=args.grow_iter, eps=eps, optimizer=args.opt_type,
                      quantize=args.quantize, warmup_iter=args.warmup_iter,
                      bits=(args.xy_bit, args.cov_bit, args.color_bit))
-    if args.quantize and (not cov or args.loop != "native"):
-        raise SystemExit("--quantize needs --model covariance and the native loop")
+    if args.quantize and (args.model == "cholesky" or args.loop != "native"):
+        raise SystemExit("--quantize needs --model covariance or scale_rot and the native loop")
 
     def report(i, img, r):
         print(f"[rank {rank}] image {i}: {img.shape[0]}x{img.shape[1]}, PSNR:{r['psnr']:.4f}, "
               f"Training:{r['train_s']:.4f}s, Eval:{r['eval_s']:.8f}s, FPS:{1.0 / r['eval_s']:.4f}, "
               f"gaussians:{int(r['num_gaussians'])}" +
               (f", bpp:{r['bpp']:.4f} (position {r['position_bpp']:.4f}, cholesky {r['cholesky_bpp']:.4f}, "
-               f"feature_dc {r['feature_dc_bpp']:.4f}), entropy-coded estimate bpp_wc:{r['bpp_wc']:.4f}, "
-               f"decoded PSNR:{r['psnr_decoded']:.4f}" if "bpp" in r else ""),
+               f"feature_dc {r['feature_dc_bpp']:.4f})" +
+               (f", entropy-coded estimate bpp_wc:{r['bpp_wc']:.4f}" if "bpp_wc" in r else "") +
+               f", decoded PSNR:{r['psnr_decoded']:.4f}" if "bpp" in r else ""),
               flush=True)
 
     def fit_one(i, img):
@@ -334,7 +347,9 @@ def main(argv=None):
         dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
     wall = time.time() - t0
     if rank == 0:
-        print(f"Average: {args.width}x{args.height}, PSNR:{out['avg_psnr']:.4f}, Training:{out['avg_train_s']:.4f}s, "
+        sizes = sorted({(int(im.shape[1]), int(im.shape[0])) for im in images})
+        size = f"{sizes[0][0]}x{sizes[0][1]}" if len(sizes) == 1 else f"{len(sizes)} image sizes"
+        print(f"Average: {size}, PSNR:{out['avg_psnr']:.4f}, Training:{out['avg_train_s']:.4f}s, "
               f"Eval:{out['avg_eval_s']:.8f}s, FPS:{1.0 / max(out['avg_eval_s'], 1e-12):.4f}, "
               f"images:{out['images']}, gpus:{world}, wall:{wall:.2f}s, images/sec:{out['images'] / wall:.4f}" +
               (f", bpp:{out['avg_bpp']:.4f}, bpp_wc (estimate):{out['avg_bpp_wc']:.4f}, "

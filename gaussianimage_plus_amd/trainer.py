@@ -65,7 +65,7 @@ class _TrainQuant(C.Structure):
         ("qfeat", C.c_void_p), ("partial", C.c_void_p), ("defer", C.c_void_p),
         ("best_qparams", C.c_void_p), ("dbg_qgrads", C.c_void_p),
         ("lr", C.c_float * 3), ("eps", C.c_float * 3), ("beta1", C.c_float), ("beta2", C.c_float),
-        ("first_step", C.c_int), ("pad0", C.c_int),
+        ("first_step", C.c_int), ("rot_bits", C.c_int),
     ]
 
 
@@ -327,7 +327,14 @@ class NativeFitter:
             sd["_scaling"], sd["_rotation"] = self.chol[:, :2].clone(), self.chol[:, 2:3].clone()
         else:
             sd[self._CHOL_KEY[self.kind]] = self.chol.clone()
-        if self.quant is not None:
+        if self.quant is not None and self.kind == "scale_rot":
+            qp = self.qparams
+            sd.update({"xyz_quantizer.scale": qp[0:2].clone(), "xyz_quantizer.beta": qp[2:4].clone(),
+                       "scaling_quantizer.scale": qp[4:6].clone(), "scaling_quantizer.beta": qp[6:8].clone(),
+                       "rotation_quantizer.scale": qp[8:9].clone(), "rotation_quantizer.beta": qp[9:10].clone(),
+                       "features_dc_quantizer.scale": qp[10:13].clone(),
+                       "features_dc_quantizer.beta": qp[13:16].clone()})
+        elif self.quant is not None:
             qp = self.qparams
             sd.update({"xyz_quantizer.scale": qp[0:2].clone(), "xyz_quantizer.beta": qp[2:4].clone(),
                        "cholesky_quantizer.cov_quantizer.scale": qp[4:5].clone(),
@@ -358,7 +365,12 @@ class NativeFitter:
         for t in self._rows()[4:4 + (12 if self.optimizer == "adan" else 6)]:
             t[:n] = 0.0
         self._set_n(n)
-        if self.quant is not None and "xyz_quantizer.scale" in sd:
+        if self.quant is not None and "scaling_quantizer.scale" in sd:
+            self.qparams.copy_(torch.cat([to(sd[k + e]) for k, e in (
+                ("xyz_quantizer", ".scale"), ("xyz_quantizer", ".beta"), ("scaling_quantizer", ".scale"),
+                ("scaling_quantizer", ".beta"), ("rotation_quantizer", ".scale"), ("rotation_quantizer", ".beta"),
+                ("features_dc_quantizer", ".scale"), ("features_dc_quantizer", ".beta"))]))
+        elif self.quant is not None and "xyz_quantizer.scale" in sd:
             self.qparams.copy_(torch.cat([to(sd["xyz_quantizer.scale"]), to(sd["xyz_quantizer.beta"]),
                                           to(sd["cholesky_quantizer.cov_quantizer.scale"]),
                                           to(sd["cholesky_quantizer.cov_quantizer.beta"]),
@@ -428,19 +440,31 @@ class NativeFitter:
         return k
 
     # ------------------------------------------------------------------ quantisation-aware phase (train_quantize.py)
-    def enable_quantize(self, xy_bit: int = 12, cov_bit: int = 10, color_bit: int = 6, lr: float = 1e-3,
+    def enable_quantize(self, xy_bit: int = 12, cov_bit: Optional[int] = None, color_bit: int = 6, lr: float = 1e-3,
                         lr_step: int = 10000, lr_gamma: float = 0.5, debug_grads: bool = False,
-                        defer_capacity: int = 1024) -> None:
+                        defer_capacity: int = 1024, rot_bit: int = 6) -> None:
         """What train_quantize.py does when its warm-up ends (:131-142, with training_setup(lr, update_optimizer=True,
-        quantize=True), models/gaussianimage_covariance.py:105-147): the gaussians' Adam is recreated with the current
-        learning rate (moments and step count start over, StepLR restarts), the best-PSNR tracking starts over, and
-        three quantisers with their own Adam optimizers (lr 1e-3, StepLR 10000 / 0.5; eps 1e-8 for the positions,
-        1e-15 for covariance and colour) are put in front of the projection.  Their scale / beta are initialised from
-        the current parameters (UniformQuantizer._init_data on the first forward).  From here on train() runs
-        train_iter_quantize iterations and render() is forward_quantize.  Call load_best() first to continue from the
-        best warm-up model as the reference does."""
-        assert self.kind == "covariance" and self.optimizer == "adam", "train_quantize.py uses the covariance model"
+        quantize=True), models/gaussianimage_covariance.py:105-147 / models/gaussianimage_rs.py:114-163): the gaussians'
+        Adam is recreated with the current learning rate and eps 1e-15 (moments and step count start over, StepLR
+        restarts), the best-PSNR tracking starts over, and the model's quantisers with their own Adam optimizers
+        (lr 1e-3, StepLR 10000 / 0.5) are put in front of the projection:
+          covariance model  -- positions LSQ `xy_bit` (eps 1e-8), covariance rows HybirdQuant `cov_bit` (default 10),
+                               colours LSQ `color_bit` (both eps 1e-15): 12 learned values;
+          rotation-scale    -- positions LSQ `xy_bit` (eps 1e-8), the raw `_scaling` LSQ `cov_bit` (default 6) and
+                               sigmoid(_rotation) * 2 pi LSQ SIGNED `rot_bit` (one optimizer, eps 1e-15), colours LSQ
+                               `color_bit` (eps 1e-15): 16 learned values.  The model file creates these optimizers but
+                               its train_iter_quantize never steps them (:473-485); here they are stepped every
+                               iteration as GaussianImage_Covariance.optimizer_step does -- pass lr=0.0 for the
+                               behaviour as written (Adam with lr 0 leaves the values untouched).
+        Scale / beta are initialised from the current parameters (UniformQuantizer._init_data on the first forward).
+        From here on train() runs train_iter_quantize iterations and render() is forward_quantize.  Call load_best()
+        first to continue from the best warm-up model as the reference does."""
+        assert self.kind in ("covariance", "scale_rot") and self.optimizer == "adam", \
+            "quantisation-aware fitting: covariance (train_quantize.py) or rotation-scale model, Adam"
         from . import quantize as qz
+        rs = self.kind == "scale_rot"
+        if cov_bit is None:
+            cov_bit = 6 if rs else 10
         self.lr = self.current_lr()
         self.opt_start = self.quant_start = self.iteration
         self.eps = 1e-15  # training_setup: torch.optim.Adam(l, lr=0.0, eps=1e-15)
@@ -450,20 +474,30 @@ class NativeFitter:
             self.best_sse.fill_(float("inf"))
             self.best_info.zero_()
         self.q_bits = (int(xy_bit), int(cov_bit), int(color_bit))
+        self.q_rot_bit = int(rot_bit)
         self.q_lr, self.q_lr_step, self.q_lr_gamma = float(lr), int(lr_step), float(lr_gamma)
         dev, n = self.dev, self.n
         f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        cov = self.chol + self.bound
         px = qz._init_params(qz.make_spec([qz.LSQ] * 2, [0] * 2, [2 ** xy_bit - 1] * 2), self.xyz)
-        pc = qz._init_params(qz.make_spec([qz.LSQ], [0], [2 ** cov_bit - 1]), cov[:, 1:2].contiguous())
         pf = qz._init_params(qz.make_spec([qz.LSQ] * 3, [0] * 3, [2 ** color_bit - 1] * 3), self.feat)
-        self.qparams = torch.cat([px[:, 0], px[:, 1], pc[0, :2], pf[:, 0], pf[:, 1]]).contiguous()
-        scales = torch.cat([self.qparams[0:2], self.qparams[4:5], self.qparams[6:9]])
+        if rs:
+            ps = qz._init_params(qz.make_spec([qz.LSQ] * 2, [0] * 2, [2 ** cov_bit - 1] * 2),
+                                 self.chol[:, :2].contiguous())
+            rot = (torch.sigmoid(self.chol[:, 2:3]) * (2 * math.pi)).contiguous()
+            pr = qz._init_params(qz.make_spec([qz.LSQ], [-2 ** (rot_bit - 1)], [2 ** (rot_bit - 1) - 1]), rot)
+            self.qparams = torch.cat([px[:, 0], px[:, 1], ps[:, 0], ps[:, 1], pr[0, :2], pf[:, 0], pf[:, 1]]).contiguous()
+            scales = torch.cat([self.qparams[0:2], self.qparams[4:6], self.qparams[8:9], self.qparams[10:13]])
+        else:
+            cov = self.chol + self.bound
+            pc = qz._init_params(qz.make_spec([qz.LSQ], [0], [2 ** cov_bit - 1]), cov[:, 1:2].contiguous())
+            self.qparams = torch.cat([px[:, 0], px[:, 1], pc[0, :2], pf[:, 0], pf[:, 1]]).contiguous()
+            scales = torch.cat([self.qparams[0:2], self.qparams[4:5], self.qparams[6:9]])
+        nq = int(self.qparams.numel())
         if not bool((torch.isfinite(self.qparams).all() & (scales > 0).all()).item()):
             # e.g. colours still at their zero initialisation: (max - min) / qmax = 0 and every code would be 0/0
             raise ValueError("enable_quantize: an attribute has an empty or non-finite range (scale <= 0); the "
                              "quantisers are initialised from the data, so fit for a while first")
-        self.qm, self.qv, self.qrange = f32(12), f32(12), f32(4)
+        self.qm, self.qv, self.qrange = f32(nq), f32(nq), f32(4)
         self.qfeat = f32(self.cap, 3)
         self.qpartial = f32(((self.cap + 63) // 64 + 1) * 24)
         self.qdefer = torch.zeros(8 + 8 * defer_capacity, dtype=torch.int32, device=dev)
@@ -476,28 +510,38 @@ class NativeFitter:
         q.eps[0], q.eps[1], q.eps[2] = 1e-8, 1e-15, 1e-15
         q.beta1, q.beta2 = 0.9, 0.999
         q.first_step = 1
+        q.rot_bits = int(rot_bit)
         self.quant = q
         self.state.quant = C.addressof(q)
 
     def quantizers(self):
-        """The three quantisers as modules of gaussianimage_plus_amd.quantize carrying the trained scale / beta
-        (the objects GaussianImage_Covariance keeps as xyz_quantizer / cholesky_quantizer / features_dc_quantizer)."""
+        """The model's quantisers as modules of gaussianimage_plus_amd.quantize carrying the trained scale / beta:
+        (xyz_quantizer, cholesky_quantizer, features_dc_quantizer) for the covariance model,
+        (xyz_quantizer, scaling_quantizer, rotation_quantizer, features_dc_quantizer) for the rotation-scale model."""
         from . import quantize as qz
         xy_bit, cov_bit, color_bit = self.q_bits
         qp = self.qparams
-        xyq = qz.UniformQuantizer(signed=False, bits=xy_bit, learned=True, num_channels=2).to(self.dev)
-        xyq.scale.data, xyq.beta.data, xyq.init_state = qp[0:2].clone(), qp[2:4].clone(), 1
+
+        def lsq(bits, channels, scale, beta, signed=False):
+            m = qz.UniformQuantizer(signed=signed, bits=bits, learned=True, num_channels=channels).to(self.dev)
+            m.scale.data, m.beta.data, m.init_state = scale.clone(), beta.clone(), 1
+            return m
+
+        xyq = lsq(xy_bit, 2, qp[0:2], qp[2:4])
+        if self.kind == "scale_rot":
+            return (xyq, lsq(cov_bit, 2, qp[4:6], qp[6:8]), lsq(self.q_rot_bit, 1, qp[8:9], qp[9:10], signed=True),
+                    lsq(color_bit, 3, qp[10:13], qp[13:16]))
         cq = qz.HybirdQuant(signed=False, bits=cov_bit, cov_bits=cov_bit, learned=True, weight=1.0).to(self.dev)
         cq.cov_quantizer.scale.data, cq.cov_quantizer.beta.data = qp[4:5].clone(), qp[5:6].clone()
         cq.init_state = cq.cov_quantizer.init_state = 1
-        fq = qz.UniformQuantizer(signed=False, bits=color_bit, learned=True, num_channels=3).to(self.dev)
-        fq.scale.data, fq.beta.data, fq.init_state = qp[6:9].clone(), qp[9:12].clone(), 1
-        return xyq, cq, fq
+        return xyq, cq, lsq(color_bit, 3, qp[6:9], qp[9:12])
 
     def compress_wo_ec(self) -> Dict[str, torch.Tensor]:
         """models/gaussianimage_covariance.py:412-443: integer codes of every attribute; gaussians whose covariance
         is not positive definite AFTER quantisation are dropped from the encoding (and from the model)."""
         assert self.quant is not None
+        if self.kind == "scale_rot":
+            return self._compress_wo_ec_rs()
         xyq, cq, fq = self.quantizers()
         with torch.no_grad():
             means, quant_means = xyq.compress(self.xyz)
@@ -518,6 +562,8 @@ class NativeFitter:
 
     def decompress_wo_ec(self, encoding: Dict[str, torch.Tensor]) -> torch.Tensor:
         """models/gaussianimage_covariance.py:445-467: render from the codes; returns clamp(out, 0, 1) as [H, W, 3]."""
+        if self.kind == "scale_rot":
+            return self._decompress_wo_ec_rs(encoding)
         from .gsplat.project_gaussians_2d_covariance import project_gaussians_2d_covariance
         from .gsplat.rasterize_sum_plus import rasterize_gaussians_plus
         _, cq, fq = self._codec
@@ -539,6 +585,16 @@ class NativeFitter:
         information, in bits per pixel."""
         xy_bit, cov_bit, color_bit = self.q_bits
         hw = self.h * self.w
+        if self.kind == "scale_rot":
+            # models/gaussianimage_rs.py:514-560 with the lsq colour quantiser: fixed-length codes + 32-bit scale / beta
+            # per channel (the model file's colour term reads a VectorQuantizer's codebook and ceil(log2(max index));
+            # with the LSQ quantiser its side information is scale + beta and its code length `color_bit`)
+            pos = encoding["xyz"].numel() * xy_bit + 32 * 2 * 2
+            sc = encoding["quant_scaling"].numel() * cov_bit + 32 * 2 * 2
+            ro = encoding["quant_rotation"].numel() * self.q_rot_bit + 32 * 1 * 2
+            fe = encoding["feature_dc_index"].numel() * color_bit + 32 * 3 * 2
+            return {"bpp": (pos + sc + ro + fe) / hw, "position_bpp": pos / hw, "cholesky_bpp": (sc + ro) / hw,
+                    "feature_dc_bpp": fe / hw, "scaling_bpp": sc / hw, "rotation_bpp": ro / hw}
         chol_bits = encoding["quant_cholesky_elements"].numel() * ((cov_bit + cov_bit * 2) / 3) + 32 * 3 * 2
         feat_bits = encoding["feature_dc_index"].numel() * color_bit + 32 * 3 * 2
         pos_bits = encoding["xyz"].numel() * xy_bit + 32 * 2 * 2
@@ -550,14 +606,55 @@ class NativeFitter:
             out["bpp_wc"] = out["position_bpp"] + out["cholesky_bpp_wc"] + out["feature_dc_bpp_wc"]
         return out
 
+    # ------------------------------------------------------------------ rotation-scale codec
+    def _compress_wo_ec_rs(self) -> Dict[str, torch.Tensor]:
+        """models/gaussianimage_rs.py:486-495 by intent: integer codes of every attribute.  (As written the model file
+        stores the DEQUANTISED scaling / rotation under "quant_scaling" / "quant_rotation" -- it keeps the first return
+        of UniformQuantizer.compress -- and decompress_wo_ec then applies scale and beta a second time, :503-505; the
+        codes are what its 6-bit size accounting, :531-532, and a decoder need.)"""
+        xyq, sq, rq, fq = self.quantizers()
+        with torch.no_grad():
+            means, quant_means = xyq.compress(self.xyz)
+            _, quant_scaling = sq.compress(self.chol[:, :2].contiguous())
+            _, quant_rotation = rq.compress((torch.sigmoid(self.chol[:, 2:3]) * (2 * math.pi)).contiguous())
+            _, color_index = fq.compress(self.feat)
+        self._codec = (xyq, sq, rq, fq)
+        return {"xyz": means, "quant_means": quant_means, "quant_scaling": quant_scaling,
+                "quant_rotation": quant_rotation, "feature_dc_index": color_index}
+
+    def _decompress_wo_ec_rs(self, encoding: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Render from the codes with the arithmetic the quantisation-aware iterations trained (forward_quantize,
+        models/gaussianimage_rs.py:443-471: dequantised raw scaling straight into the projection; the model file's
+        decompress_wo_ec adds |. + bound| on top, :504, which forward_quantize does not)."""
+        from .gsplat.project_gaussians_2d_scale_rot import project_gaussians_2d_scale_rot
+        from .gsplat.rasterize_sum import rasterize_gaussians_sum
+        _, sq, rq, fq = self._codec
+        with torch.no_grad():
+            means = encoding["xyz"]
+            scaling = sq.decompress(encoding["quant_scaling"])
+            rotation = rq.decompress(encoding["quant_rotation"])
+            colors = fq.decompress(encoding["feature_dc_index"])
+            n = means.shape[0]
+            tile_bounds = (self.tx, self.ty, 1)
+            xys, depths, radii, conics, nth = project_gaussians_2d_scale_rot(
+                means, scaling, rotation, self.h, self.w, tile_bounds, radius_clip=self.state.radius_clip)
+            sp = torch.zeros(n, 4, device=self.dev)
+            out, _, _ = rasterize_gaussians_sum(xys, sp, depths, radii, conics, nth, colors,
+                                                torch.ones(n, 1, device=self.dev), self.h, self.w, 16, 16)
+        return out.clamp(0, 1)
+
     def fit_schedule(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
-                     max_points: Optional[int] = None, log=None, chunk: Optional[int] = None):
+                     max_points: Optional[int] = None, log=None, chunk: Optional[int] = None,
+                     total_iterations: Optional[int] = None):
         """The per-image loop of train.py:120-160 as a generator: train, prune every `prune_iter`, grow every
         `grow_iter` (not at the very end).  Iterations between two such events are issued back to back without
         touching the host; with `chunk` the generator yields after at most that many iterations, so a caller can
-        interleave several fitters on several HIP streams (launch.py)."""
+        interleave several fitters on several HIP streams (launch.py).  `total_iterations`: the run's total count, which
+        the growth budget refers to (train.py:91 `iter == self.iterations - grow_iter`), when this call covers only a
+        part of it (fit_quantize_schedule's warm-up); default = `iterations`."""
         start = self.iteration
         end = start + int(iterations)
+        total = int(iterations) if total_iterations is None else int(total_iterations)
         adaptive = self.kind == "covariance"
         while self.iteration < end:
             local = self.iteration - start
@@ -574,8 +671,8 @@ class NativeFitter:
                 pruned = self.prune_non_definite()
                 if pruned and log:
                     log(f"iter {local}: pruned {pruned} non-definite, {self.n} left")
-            if adaptive and adaptive_add and local % grow_iter == 0 and local < iterations:
-                added = self.add_sample_positions(local, iterations, grow_iter, max_points)
+            if adaptive and adaptive_add and local % grow_iter == 0 and local < total:
+                added = self.add_sample_positions(local, total, grow_iter, max_points)
                 if log:
                     log(f"iter {local}: added {added} gaussians, now {self.n}")
             yield local
@@ -583,17 +680,22 @@ class NativeFitter:
     def fit_quantize_schedule(self, iterations: int, warmup_iter: int, bits=(12, 10, 6), chunk: Optional[int] = None,
                               log=None, **kw):
         """The per-image loop of train_quantize.py:114-175 as a generator: iterations 1 .. warmup_iter-1 are the plain
-        adaptive loop (prune / grow as in fit_schedule; the growth budget still refers to `iterations`, :86), at
-        `warmup_iter` the best warm-up model becomes the live one and the quantisers are switched on, the remaining
-        iterations (up to iterations-1) are quantisation-aware; a last non-definite prune closes the loop (:175)."""
+        adaptive loop (prune / grow as in fit_schedule while `iter < warmup_iter`, :159,171; the growth budget refers to
+        the run's total `iterations`, :86), at `warmup_iter` the best warm-up model becomes the live one and the
+        quantisers are switched on, the remaining iterations (up to iterations-1) are quantisation-aware; a last
+        non-definite prune closes the loop (:175).  train_quantize.py prunes BEFORE it snapshots the best model
+        (:158-168), so its warm-up snapshot never holds a non-definite gaussian; the on-device snapshot here is taken
+        inside the update kernel, i.e. before the prune, so the restored model is pruned once more at the switch."""
         assert self.track_best, "the switch to quantisation-aware fitting starts from the best warm-up model"
         warm = max(0, min(int(warmup_iter), int(iterations)) - 1)
         start = self.iteration
 
-        sched = self.fit_schedule(warm, chunk=chunk, log=log, **kw)
+        # every multiple of prune_iter / grow_iter below warmup_iter is <= warm, so the warm-up call sees them all
+        sched = self.fit_schedule(warm, chunk=chunk, log=log, total_iterations=int(iterations), **kw)
         for local in sched:
             yield local
         self.load_best()
+        self.prune_non_definite()
         self.enable_quantize(*bits)
         if log:
             log(f"iter {self.iteration - start + 1}: warm-up finished, quantisation-aware from here ({self.n} gaussians)")

@@ -382,7 +382,7 @@ typedef struct gi2d_train_state {
     const struct gi2d_train_quant *quant;
 } gi2d_train_state;
 
-/* Quantisation-aware fitting (covariance model, kind 1, Adam): GaussianImage_Covariance.
+/* Quantisation-aware fitting.  Covariance model (kind 1, Adam): GaussianImage_Covariance.
  * train_iter_quantize / forward_quantize (models/gaussianimage_covariance.py:219-247,384-410) after
  * train_quantize.py's warm-up -- positions through a 2-channel LSQ quantiser (xy_bits), covariance rows through
  * HybirdQuant (log quantiser on the variances, LSQ on the covariance, both cov_bits), colours through a 3-channel LSQ
@@ -402,7 +402,14 @@ typedef struct gi2d_train_state {
  *   dbg_qgrads f32[16] or NULL: gradients of qparams (same order), then the log quantiser's v_scale, v_beta and the
  *           per-element range gradients at the minimum / maximum (tests)
  *   lr, eps (host) per quantiser optimizer; beta1, beta2; first_step = their 1-based Adam step of the call's first
- *           iteration. */
+ *           iteration.
+ * Rotation-scale model (kind 2, Adam; GaussianImage_RS.forward_quantize / train_iter_quantize,
+ * models/gaussianimage_rs.py:131-163,443-485 -- BASELINE config 5): four LSQ quantisers -- positions xy_bits unsigned,
+ * the raw `_scaling` cov_bits unsigned, sigmoid(_rotation) * 2 pi rot_bits SIGNED, colours color_bits unsigned -- so
+ *   qparams, qm, qv f32[16] (64-byte aligned): xy scale[2], xy beta[2], scaling scale[2], scaling beta[2], rotation
+ *           scale, rotation beta, colour scale[3], colour beta[3]; best_qparams f32[16]; dbg_qgrads f32[16];
+ *   lr / eps [3] = positions, scaling + rotation (one optimizer in the model file), colours;
+ *   range and defer are unused (may be NULL); an iteration is four launches as above. */
 typedef struct gi2d_train_quant {
     int xy_bits, cov_bits, color_bits, defer_capacity;
     float *qparams, *qm, *qv, *range, *qfeat, *partial;
@@ -410,7 +417,8 @@ typedef struct gi2d_train_quant {
     float *best_qparams, *dbg_qgrads;
     float lr[3], eps[3];
     float beta1, beta2;
-    int first_step, pad0;
+    int first_step;
+    int rot_bits; /* kind 2 only: bit depth of the SIGNED rotation quantiser (models/gaussianimage_rs.py:143) */
 } gi2d_train_quant;
 int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
 int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,

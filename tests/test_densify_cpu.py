@@ -51,3 +51,73 @@ def test_select_new_points_matches_plain_numpy_statement():
     assert np.array_equal(got["cov2d"].numpy(), cov[keep])
     assert got["feat"].shape == (int(keep.sum()), 3) and float(got["feat"].abs().sum()) == 0.0
     assert got["dropped"] == k - int(keep.sum())
+
+
+def _reference_quantize_events(iterations, warmup_iter, prune_iter, grow_iter, n0, max_points):
+    """train_quantize.py:124-175 as a plain loop over `iter`, recording what happens when (growth adds its whole
+    budget: no non-PD draws in this statement)."""
+    ev, n = [], n0
+    for it in range(1, iterations):
+        ev_it = []
+        if it == warmup_iter:
+            ev_it.append(("switch", n))
+        if it % prune_iter == 0 and it < warmup_iter:
+            ev_it.append(("prune", n))
+        if it % grow_iter == 0 and it < warmup_iter:
+            k = max(0, max_points - n) if it == iterations - grow_iter else max(0, min(1000, max_points - n))
+            if k:
+                n += k
+                ev_it.append(("grow", k))
+        ev += [(it,) + e for e in ev_it]
+    ev.append((iterations - 1, "prune", n))
+    return ev
+
+
+class _ScheduleProbe:
+    """The host logic of NativeFitter.fit_schedule / fit_quantize_schedule with the device calls replaced by a log."""
+    kind, track_best, cap = "covariance", True, 10 ** 9
+
+    def __init__(self, n0):
+        from gaussianimage_plus_amd.trainer import NativeFitter
+        self.iteration, self.n, self.events, self.switched_at = 0, n0, [], None
+        self.fit_schedule = NativeFitter.fit_schedule.__get__(self)
+        self.fit_quantize_schedule = NativeFitter.fit_quantize_schedule.__get__(self)
+
+    def train(self, k):
+        self.iteration += int(k)
+
+    def prune_non_definite(self):
+        self.events.append((self.iteration, "prune", self.n))
+        return 0
+
+    def add_sample_positions(self, iteration, iterations, grow_iter, max_points=None):
+        k = growth_budget(iteration, iterations, grow_iter, self.n, max_points)
+        if k:
+            self.n += k
+            self.events.append((self.iteration, "grow", k))
+        return k
+
+    def load_best(self):
+        pass
+
+    def enable_quantize(self, *bits):
+        self.events.append((self.iteration + 1, "switch", self.n))
+
+
+@__import__("pytest").mark.parametrize("iterations,warmup,prune,grow", [(10000, 6000, 1000, 5000), (50000, 6000, 100, 5000),
+                                                                      (3000, 2000, 100, 500), (1200, 1000, 100, 1000)])
+def test_quantize_schedule_follows_train_quantize(iterations, warmup, prune, grow):
+    """Events of fit_quantize_schedule == train_quantize.py's loop, including the case iterations - grow_iter <
+    warmup_iter, where the LAST growth step (whole remaining budget) falls inside the warm-up, and a growth / prune
+    check at iteration warmup_iter - 1."""
+    want = _reference_quantize_events(iterations, warmup, prune, grow, 2500, 20000)
+    probe = _ScheduleProbe(2500)
+    for _ in probe.fit_quantize_schedule(iterations, warmup, prune_iter=prune, grow_iter=grow, max_points=20000):
+        pass
+    got = probe.events
+    # the port prunes the restored best model once more at the switch (its snapshot is taken before the prune)
+    extra = [e for e in got if e[1] == "prune" and e[0] == warmup - 1 and (warmup - 1) % prune != 0]
+    assert len(extra) == 1
+    got = [e for e in got if e not in extra]
+    assert sorted(got) == sorted(want)
+    assert probe.iteration == iterations - 1
