@@ -1,16 +1,16 @@
 // Fused fast path of the 2D-Gaussian hot path (what the rasterize wrappers and bench.py run).
 //
 // Same results as the reference-shaped ops (gi2d_project / gi2d_binning / gi2d_raster), restructured
-// around what actually costs time on MI355X at these sizes -- kernel boundaries and the serial
-// dependent-load chains at the head of every tile workgroup -- rather than HBM bytes:
+// around what actually costs time on MI355X at these sizes -- kernel boundaries, device-scope atomics and the
+// serial dependent-load chains at the head of every tile workgroup -- rather than HBM bytes:
 //
-//   fill     one lane per gaussian drops its id into fixed-capacity per-tile buckets (returning int
-//            atomics on 4 sub-cursors per tile).  No count pass, no scan, no keys, no sort launch;
-//            optionally fused with the projection itself (project_fill).
-//   forward  one workgroup per tile: ranks the bucket's ids in LDS (ascending id == the stable key
-//            sort of the reference pipeline), gathers each gaussian ONCE, writes the tile-sorted
-//            48-byte records ("packed list") + ids + tile_bins for the backward, resets the bucket
-//            cursors for the next call, and rasterizes (same code as the plain forward).
+//   fill     one lane per gaussian compares its tile box with the box it was binned with last time and appends its
+//            id only to the rows of tiles it has ENTERED (persistent tile lists: gi2d_fast_internal.h).  No count
+//            pass, no scan, no keys, no sort launch; fused with the projection itself (project_fill).
+//   forward  one workgroup per tile: validates its row against the current boxes, orders it by ascending id in LDS
+//            (== the stable key sort of the reference pipeline; a ballot scan when nothing was appended), gathers
+//            each gaussian ONCE, writes the tile-sorted 48-byte records ("packed list") + tile_bins for the
+//            backward, and rasterizes (same code as the plain forward).
 //   backward one workgroup per tile reads the packed records with coalesced 16-byte loads (no
 //            gather), runs the strip items, and stores each (tile, gaussian) partial straight into
 //            a gaussian-major row (gaussians on <= 16 tiles), so that
@@ -21,9 +21,9 @@
 //            workgroup pass -- what a loop runs when the pixel gradient is given or is the L2-loss gradient
 //            of the pixel just rendered: two launches per step.
 //
-// Capacity contract: at most GI2D_FAST_CSUB (256) ids per (tile, sub-bucket), i.e. up to 1024 candidates per tile
-// of which the 256 lowest ids are rasterized (forward.cu:553).  A fuller bucket sets
-// status[1] and the caller must fall back to the exact path (gi2d_bin_gaussians + plain ops).
+// Capacity contract: at most GI2D_FAST_C (1024) candidates per tile row, of which the 256 lowest ids are
+// rasterized (forward.cu:553).  A fuller row sets status[1] and the caller must fall back to the exact path
+// (gi2d_bin_gaussians + plain ops) and re-initialise the workspace.
 #include <hip/hip_ext.h>
 
 #include "gi2d_fused_core.h"
@@ -33,37 +33,26 @@ namespace gi2d {
 // ----------------------------------------------------------------------------------------- fill
 __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__restrict__ xys,
                                                         const int32_t *__restrict__ radii, int tiles_x,
-                                                        int tiles_y, float radius_clip,
-                                                        int32_t *__restrict__ cursors,
-                                                        int32_t *__restrict__ buckets,
+                                                        int tiles_y, float radius_clip, int2 *__restrict__ prev_box,
+                                                        int32_t *__restrict__ lists, float *__restrict__ meta,
                                                         int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) {
-        status[0] = 0;
-        status[1] = 0;
-        status[3] = 0;  // status[2] is sticky (any overflow since the caller last cleared it)
-    }
+    begin_binning(g, status, meta, radius_clip);
     if (g >= n) return;
-    const int rad = radii[g];
-    if (rad <= 0 || (float)rad < radius_clip) return;  // forward.cu:161; culled gaussians own no slot
-    const float2 c = xys[g];
-    int mnx, mny, mxx, mxy;
-    tile_bbox(c.x, c.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-    fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
+    int mnx, mny, mxx, mxy;  // forward.cu:161: culled gaussians are in no tile
+    const bool member = bin_box(xys[g], radii[g], radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+    fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, prev_box, lists);
 }
 
-// projection of gaussian g + its bucket fill (g == 0 also resets the per-call status words)
+// projection of gaussian g + its binning step (g == 0 also resets the per-call status words)
 template <int KIND>
 __device__ __forceinline__ void project_fill_one(
     int g, int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip, float2 *xys,
     float *__restrict__ depths, int32_t *radii, float *conics, int32_t *__restrict__ num_tiles_hit,
-    int32_t *__restrict__ cursors, int32_t *__restrict__ buckets, int32_t *__restrict__ status) {
-    if (g == 0) {
-        status[0] = 0;
-        status[1] = 0;
-        status[3] = 0;  // status[2] is sticky (any overflow since the caller last cleared it)
-    }
+    int2 *__restrict__ prev_box, int32_t *__restrict__ lists, float *__restrict__ meta,
+    int32_t *__restrict__ status) {
+    begin_binning(g, status, meta, radius_clip);
     if (g >= n) return;
     const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
     xys[g] = o.xy;
@@ -73,13 +62,7 @@ __device__ __forceinline__ void project_fill_one(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    // same membership rule as fast_fill_kernel / map_gaussian_to_intersects; the rasterizer's radius_clip
-    // equals the projection's on this path
-    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
-        int mnx, mny, mxx, mxy;  // the binning box always uses the INT radius (forward.cu:166)
-        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
-    }
+    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
 }
 
 template <int KIND>
@@ -87,90 +70,52 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
     int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
     float2 *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
-    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors,
-    int32_t *__restrict__ buckets, int32_t *__restrict__ status) {
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box,
+    int32_t *__restrict__ lists, float *__restrict__ meta, int32_t *__restrict__ status) {
     project_fill_one<KIND>(blockIdx.x * blockDim.x + threadIdx.x, n, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x,
-                           tiles_y, radius_clip, xys, depths, radii, conics, num_tiles_hit, cursors, buckets, status);
+                           tiles_y, radius_clip, xys, depths, radii, conics, num_tiles_hit, prev_box, lists, meta, status);
 }
 
 // -------------------------------------------------------------------------------------- forward
 struct FastFwdLds {
     FwdLds f;
 };
-static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id sort buffer overlays the pair buffers");
+static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id buffer of the list head overlays the pair buffers");
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, const float *__restrict__ background, int32_t *__restrict__ cursors,
-    const int32_t *__restrict__ buckets, int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins,
-    GaussRec *__restrict__ packed, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
-    int32_t *__restrict__ status, float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
-    float *__restrict__ out_img) {
+    const float *__restrict__ opacities, const float *__restrict__ background, const float *__restrict__ meta,
+    int32_t *__restrict__ lists, int2 *__restrict__ tile_bins, GaussRec *__restrict__ packed,
+    float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
+    float *__restrict__ final_Ts, int32_t *__restrict__ final_idx, float *__restrict__ out_img) {
     __shared__ FastFwdLds sm;
-    int *ids = reinterpret_cast<int *>(sm.f.pairbuf);  // id sort buffer: dead before the pair buffers are first written
+    __shared__ int grp[32];
+    int *ids = reinterpret_cast<int *>(sm.f.pairbuf);  // id buffer of the head: dead before the pair buffers are first written
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
-    // every lane reads the four cursors itself (one broadcast transaction each): no LDS hop, no barrier
-    int cnt4[GI2D_FAST_SUB];
-#pragma unroll
-    for (int q = 0; q < GI2D_FAST_SUB; ++q) cnt4[q] = cursors[(tile * GI2D_FAST_SUB + q) * GI2D_CURSOR_STRIDE];
-    if (tid == 0) {
-        fwd_stage_dummy(sm.f);
-        if (cnt4[0] > GI2D_FAST_CSUB || cnt4[1] > GI2D_FAST_CSUB || cnt4[2] > GI2D_FAST_CSUB ||
-            cnt4[3] > GI2D_FAST_CSUB) {
-            atomicOr(&status[1], 1);
-            atomicOr(&status[2], 1);
-        }
-    }
-    const int c0 = min(cnt4[0], GI2D_FAST_CSUB), c1 = c0 + min(cnt4[1], GI2D_FAST_CSUB),
-              c2 = c1 + min(cnt4[2], GI2D_FAST_CSUB), L = c2 + min(cnt4[3], GI2D_FAST_CSUB);
-    if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
-    // my (up to GI2D_FAST_EPT) bucket entries
-    int my_id[GI2D_FAST_EPT];
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        const int e = tid + 256 * u;
-        my_id[u] = -1;
-        if (e < L) {
-            const int sub = (e >= c0) + (e >= c1) + (e >= c2);
-            const int off = e - (sub == 0 ? 0 : (sub == 1 ? c0 : (sub == 2 ? c1 : c2)));
-            my_id[u] = buckets[(tile * GI2D_FAST_SUB + sub) * GI2D_FAST_CSUB + off];
-            ids[e] = my_id[u];
-        }
-    }
-    __syncthreads();
-    // every lane has read the cursors: ready them for the next call
-    if (tid < GI2D_FAST_SUB) cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;
+    if (tid == 0) fwd_stage_dummy(sm.f);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        if (my_id[u] < 0) continue;
-        const int g = my_id[u];
-        // issue the gathers first; the rank loop below runs under their latency
-        GaussRec r = load_gaussian(g, xys, conics, colors, opacities);
-        const int rad = radii[g];
-        int rank = 0;
-        for (int j = 0; j < L; ++j) rank += (ids[j] < g) ? 1 : 0;
-        gids_sorted[tile * GI2D_FAST_C + rank] = g;
-        const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
-        const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
-        if (rank < GI2D_TILE_LIST_CAP) {
-            const unsigned mask = cull_word(r, tx0, ty0, img_h);
-            fwd_stage_entry(sm.f, rank, r, mask);
-            float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
-            dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
-            dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
-            dst[2] = make_float4(r.cb, __int_as_float(slot), __int_as_float(g), __int_as_float((int)mask));
-        } else if (slot >= 0) {
-            // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
-            partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
-            partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
-        }
-    }
+    const int L = tile_list_head(
+        ids, grp, tile, tx, ty, tiles_x, tiles_y, meta, xys, radii, conics, colors, opacities, lists, tile_bins,
+        status, [&](int rank, int g, const GaussRec &r, const TileBox &b) {
+            const int slot = partial_slot(g, b.mnx, b.mny, b.mxx, b.mxy, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
+            if (rank < GI2D_TILE_LIST_CAP) {
+                const unsigned mask = cull_word(r, tx0, ty0, img_h);
+                fwd_stage_entry(sm.f, rank, r, mask);
+                float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
+                dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
+                dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
+                dst[2] = make_float4(r.cb, __int_as_float(slot), __int_as_float(g), __int_as_float((int)mask));
+            } else if (slot >= 0) {
+                // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
+                partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
+                partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
+            }
+        });
     __syncthreads();
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     // "No intersection at all" (image = background) is a global property no single tile can decide: every
@@ -178,10 +123,10 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     // it; a contended atomic here would serialise all workgroups), and the host entry may append a tiny
     // fix-up kernel for that corner case.
     if (final_idx)
-        fwd_rasterize_staged<true>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
+        fwd_rasterize_staged<true>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, false, background,
                                    final_Ts, final_idx, out_img);
     else
-        fwd_rasterize_staged<false>(sm.f, len, tile * GI2D_FAST_C, tx, ty, img_w, img_h, false, background,
+        fwd_rasterize_staged<false>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, false, background,
                                     final_Ts, final_idx, out_img);
     if (tid == 0 && L > 0) status[0] = 1;
 }
@@ -232,9 +177,17 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
 }
 
-__global__ __launch_bounds__(256) void iota_kernel(int n, int32_t *__restrict__ out) {
+// Empty state of a workspace: every tile row empty, no gaussian binned, identity tile order.
+__global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n, int32_t *__restrict__ lists,
+                                                           int32_t *__restrict__ tile_order,
+                                                           int2 *__restrict__ prev_box) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = i;
+    if (i < num_tiles) {
+        lists[(size_t)i * GI2D_FAST_LROW] = 0;
+        lists[(size_t)i * GI2D_FAST_LROW + 1] = 0;
+        tile_order[i] = i;
+    }
+    if (i < n) prev_box[i] = make_int2(0, 0);
 }
 
 // ----------------------------------------------------------------- forward + backward in one pass
@@ -242,15 +195,13 @@ template <int MODE>
 __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, int32_t *__restrict__ cursors, const int32_t *__restrict__ buckets,
-    int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g,
-    float4 *__restrict__ partial_big, int32_t *__restrict__ status, float *__restrict__ out_img,
-    const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse,
-    const int32_t *__restrict__ tile_order) {
+    const float *__restrict__ opacities, const float *__restrict__ meta, int32_t *__restrict__ lists,
+    int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
+    int32_t *__restrict__ status, float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale,
+    float *__restrict__ tile_sse, const int32_t *__restrict__ tile_order) {
     __shared__ FusedLds sm;
-    fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, xys, radii, conics, colors, opacities, cursors,
-                     buckets, gids_sorted, tile_bins, partial_g, partial_big, status, out_img, vsrc, grad_scale,
-                     tile_sse);
+    fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, xys, radii, conics, colors, opacities,
+                     meta, lists, tile_bins, partial_g, partial_big, status, out_img, vsrc, grad_scale, tile_sse);
 }
 
 // --------------------------------------------------------------------------------------- reduce
@@ -273,7 +224,9 @@ struct NextProject {
     float clip_coe;
     const float2 *means2d;
     float *depths;
-    int32_t *num_tiles_hit, *cursors, *buckets, *status;
+    int32_t *num_tiles_hit, *lists, *status;
+    int2 *prev_box;
+    float *meta;
     int32_t *tile_order;  // non-null: one extra workgroup re-balances the next tile pass (large populations only,
                           // where this kernel is long enough to hide it)
 };
@@ -308,7 +261,7 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     store_proj_grad(g, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
     if (FILL_NEXT)
         project_fill_one<KIND>(g, n, next.clip_coe, next.means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip,
-                               xys, next.depths, radii, conics, next.num_tiles_hit, next.cursors, next.buckets,
+                               xys, next.depths, radii, conics, next.num_tiles_hit, next.prev_box, next.lists, next.meta,
                                next.status);
 }
 
@@ -317,7 +270,8 @@ static int check_ws(const char *what, void *ws, size_t ws_bytes, int n, int tile
         set_error("fast path: negative size");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
-    if ((long long)tiles_x * tiles_y * GI2D_FAST_C > 0x7fffffffLL || (long long)n * GI2D_FAST_S > 0x7fffffffLL) {
+    if ((long long)tiles_x * tiles_y * GI2D_FAST_LROW > 0x7fffffffLL || (long long)n * GI2D_FAST_S > 0x7fffffffLL ||
+        tiles_x > 0xffff || tiles_y > 0xffff) {
         set_error("fast path: problem too large for 32-bit slot indices");
         return GI2D_ERR_UNSUPPORTED;
     }
@@ -395,21 +349,17 @@ int gi2d_timer_elapsed_us(void *timer, float *us) {
 size_t gi2d_fast_workspace_bytes(int n, int tiles_x, int tiles_y) {
     return carve_fast(nullptr, n, tiles_x * tiles_y).bytes;
 }
-int gi2d_fast_tile_capacity(void) { return GI2D_FAST_CSUB; }
+int gi2d_fast_tile_capacity(void) { return GI2D_FAST_C; }
 
 int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y, gi2d_stream_t st) {
     int rc = check_ws("fast workspace init: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
-    const size_t t = (size_t)tiles_x * tiles_y;
-    if (t == 0) return GI2D_OK;
-    hipError_t e = hipMemsetAsync(w.cursors, 0, t * GI2D_FAST_SUB * GI2D_CURSOR_STRIDE * sizeof(int32_t), (hipStream_t)st);
-    if (e != hipSuccess) {
-        set_error(hipGetErrorString(e));
-        return (int)e;
-    }
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)st, (int)t,
-                       w.tile_order);
+    const int t = tiles_x * tiles_y;
+    const int work = t > n ? t : n;
+    if (work == 0) return GI2D_OK;
+    hipLaunchKernelGGL(fast_ws_init_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)st, t, n,
+                       w.lists, w.tile_order, w.prev_box);
     return check_launch("fast workspace init");
 }
 
@@ -424,8 +374,8 @@ int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, int tiles_x, in
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int fbs = per_gaussian_block(n);
     hipLaunchKernelGGL(fast_fill_kernel, dim3((n + fbs - 1) / fbs > 0 ? (n + fbs - 1) / fbs : 1), dim3(fbs), 0,
-                       (hipStream_t)st, n, (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.cursors,
-                       w.buckets, status);
+                       (hipStream_t)st, n, (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.prev_box,
+                       w.lists, w.meta, status);
     return check_launch("fast bin");
 }
 
@@ -446,7 +396,7 @@ int gi2d_fast_project_bin(int kind, int n, float clip_coe, const float *means2d,
 #define GI2D_LAUNCH_PF(K)                                                                                       \
     hipLaunchKernelGGL(fast_project_fill_kernel<K>, grid, block, 0, (hipStream_t)st, n, clip_coe,              \
                        (const float2 *)means2d, p0, p1, (float)w_, (float)h, tiles_x, tiles_y, radius_clip,    \
-                       (float2 *)xys, depths, radii, conics, nth, w.cursors, w.buckets, status)
+                       (float2 *)xys, depths, radii, conics, nth, w.prev_box, w.lists, w.meta, status)
     if (kind == 0)
         GI2D_LAUNCH_PF(kCholesky);
     else if (kind == 1)
@@ -476,8 +426,8 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
     }
     FastWs w = carve_fast(ws, n, (int)t);
     hipLaunchKernelGGL(fast_fwd_kernel, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
-                       (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, background, w.cursors,
-                       w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.packed, w.partial_g, w.partial_big, status,
+                       (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, background,
+                       (const float *)w.meta, w.lists, (int2 *)w.tile_bins, w.packed, w.partial_g, w.partial_big, status,
                        final_Ts, final_idx, out_img);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
@@ -507,13 +457,13 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
     float *no_sse = nullptr;
     if (v_output)
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors,
-                          (const int32_t *)w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big,
+                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, (const float *)w.meta, w.lists,
+                          (int2 *)w.tile_bins, w.partial_g, w.partial_big,
                           status, out_img, v_output, 0.f, no_sse, (const int32_t *)w.tile_order);
     else
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, w.cursors,
-                          (const int32_t *)w.buckets, w.gids_sorted, (int2 *)w.tile_bins, w.partial_g, w.partial_big,
+                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, (const float *)w.meta, w.lists,
+                          (int2 *)w.tile_bins, w.partial_g, w.partial_big,
                           status, out_img, target, grad_scale, tile_sse, (const int32_t *)w.tile_order);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
@@ -583,8 +533,9 @@ static int reduce_project_impl(int kind, int n, const float *p0, const float *p1
     np.depths = nullptr;
     np.num_tiles_hit = np.status = np.tile_order = nullptr;
     if (next) np = *next;
-    np.cursors = w.cursors;
-    np.buckets = w.buckets;
+    np.lists = w.lists;
+    np.prev_box = w.prev_box;
+    np.meta = w.meta;
     const int bs = per_gaussian_block(n);
     np.tile_order = (next && n > 32768) ? w.tile_order : nullptr;
     const dim3 grid((n + bs - 1) / bs + (np.tile_order ? 1 : 0)), block(bs);
@@ -640,7 +591,9 @@ int gi2d_fast_reduce_project_backward_project_bin(int kind, int n, float clip_co
     np.depths = depths;
     np.num_tiles_hit = nth;
     np.status = status;
-    np.cursors = np.buckets = nullptr;
+    np.lists = nullptr;
+    np.prev_box = nullptr;
+    np.meta = nullptr;
     return reduce_project_impl(kind, n, p0, p1, h, w_, xys, radii, conics, tiles_x, tiles_y, radius_clip, ws, ws_bytes,
                                v_xy, v_conic, v_rgb, v_opacity, v_abs_xy, v_cov2d, v_mean2d, v_p0, v_p1, &np, st);
 }

@@ -7,39 +7,54 @@
 namespace gi2d {
 
 
-#define GI2D_FAST_SUB 4
-#define GI2D_FAST_CSUB 256
-#define GI2D_FAST_C (GI2D_FAST_SUB * GI2D_FAST_CSUB) /* list slots per tile */
-#define GI2D_FAST_EPT (GI2D_FAST_C / 256)            /* bucket entries per lane of the 256-lane tile workgroup */
+// Tile lists of the fused fast path are PERSISTENT: row t of `lists` holds
+//     { count, sorted_len, 14 words of padding | ids[GI2D_FAST_C] }        (the header is one 64-byte line)
+// ids[0 .. sorted_len) are the tile's members as of the last tile pass, ascending; ids[sorted_len .. count) were
+// appended since (any order).  `prev_box[g]` is the tile box gaussian g was binned with.  A binning step
+// (fill_diff) compares each gaussian's new box with that box and appends the gaussian only to the tiles it has
+// ENTERED (returning atomics on the row header): from one iteration of a fit to the next nearly every box is unchanged,
+// so a step issues a few hundred atomics instead of one per (gaussian, tile) -- 111 k at N = 50 000, which cost
+// ~6 us per step: the device-scope atomic rate, not their latency, was the bound (tools/ubench/atomic_scope.hip).  The
+// tile pass tests every entry against the CURRENT box of its gaussian (exactly the membership rule of
+// map_gaussian_to_intersects, forward.cu:161-166), drops those that left, merges the appended ones into the
+// ascending order and writes the row back only where it changed.  Invariant between a binning step and the tile
+// pass that follows it: row t holds exactly {g : t in prev_box[g]} plus entries of gaussians that have left t, no id
+// twice.  Results are those of a from-scratch binning for ANY change of the inputs (a workspace that saw other inputs
+// before only costs more appends); gi2d_fast_workspace_init empties all rows and boxes, and must be called when
+// gaussian ids are renumbered (pruning / compaction) or after an overflow.
+#define GI2D_FAST_C 1024                             /* list slots per tile */
+#define GI2D_FAST_HDR 16                             /* header words in front of a row's ids */
+#define GI2D_FAST_LROW (GI2D_FAST_C + GI2D_FAST_HDR) /* words per row */
+#define GI2D_FAST_EPT (GI2D_FAST_C / 256)            /* list entries per lane of the 256-lane tile workgroup */
 #define GI2D_FAST_S 16                               /* gaussian-major partial rows per gaussian */
 #ifndef GI2D_FILL_BATCH
-#define GI2D_FILL_BATCH 16                           /* bucket atomics a lane keeps in flight */
+#define GI2D_FILL_BATCH 16                           /* row-header atomics a lane keeps in flight */
 #endif
 #ifndef GI2D_REDUCE_BATCH
 #define GI2D_REDUCE_BATCH 8                          /* partial rows a lane loads before it starts adding */
 #endif
 #define GI2D_BIG_TILES_F 32
 #define GI2D_FAST_ROW 4 /* float4 per partial row: 48 bytes of data padded to one 64-byte line */
-#define GI2D_CURSOR_STRIDE 16 /* ints between cursors: one 64-byte line each, so atomics on different cursors never share a line */
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // Workgroup size of the one-lane-per-gaussian kernels (project+fill, reduce+project backward, optimizer update):
-// single waves spread a small population over many CUs and shorten the dependent atomic / load chains
+// single waves spread a small population over many CUs and shorten the dependent load chains
 // (N=2500: project+fill 10.9 -> 5.5 us, reduce 7.4 -> 4.7 us; neutral to slightly worse beyond ~30k gaussians).
 #ifndef GI2D_PG_BIG
 #define GI2D_PG_BIG 256
 #endif
 static inline int per_gaussian_block(int n) { return n <= 32768 ? 64 : GI2D_PG_BIG; }
 struct FastWs {
-    int32_t *cursors;      // [T * SUB]          zero between calls
-    int32_t *buckets;      // [T * C]            unsorted ids per (tile, sub)
-    int32_t *gids_sorted;  // [T * C]            ascending ids per tile (stride C)
-    int32_t *tile_bins;    // [T * 2]            [t*C, t*C + len)
+    int32_t *lists;        // [T * LROW]         persistent tile lists (see above)
+    int32_t *gids_sorted;  // == lists: tile_bins hold absolute word positions into it
+    int32_t *tile_bins;    // [T * 2]            [row base + HDR, row base + HDR + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
+    int2 *prev_box;        // [N]                tile box each gaussian was last binned with (packed, 0/0 = none)
     float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
     float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
     int32_t *tile_order;   // [T]                tile handled by workgroup b of the single-pass tile kernel: a
                            //                    permutation that balances tile populations over the CUs
+    float *meta;           // [64]               [0]: radius_clip of the last binning step (the tile pass tests with it)
     size_t bytes;
 };
 static FastWs carve_fast(void *base, int n, int num_tiles) {
@@ -47,20 +62,21 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     char *b = (char *)base;
     size_t off = 0;
     const size_t t = (size_t)(num_tiles > 0 ? num_tiles : 1), nn = (size_t)(n > 0 ? n : 1);
-    w.cursors = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_SUB * GI2D_CURSOR_STRIDE * sizeof(int32_t));
-    w.buckets = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
-    w.gids_sorted = (int32_t *)(b + off);
-    off += align_up(t * GI2D_FAST_C * sizeof(int32_t));
+    w.lists = (int32_t *)(b + off);
+    w.gids_sorted = w.lists;
+    off += align_up(t * GI2D_FAST_LROW * sizeof(int32_t));
     w.tile_bins = (int32_t *)(b + off);
     off += align_up(t * 2 * sizeof(int32_t));
     w.packed = (GaussRec *)(b + off);
     off += align_up(t * GI2D_TILE_LIST_CAP * sizeof(GaussRec));
-    // cursors and tile_order carry state from call to call: both sit in front of every region whose offset depends
-    // on the gaussian count, so a workspace initialised for a capacity can be used with any smaller population
+    // lists, tile_order and prev_box carry state from call to call: they sit in front of every region whose offset
+    // depends on the gaussian count, so a workspace initialised for a capacity can be used with any smaller population
     w.tile_order = (int32_t *)(b + off);
     off += align_up(t * sizeof(int32_t));
+    w.meta = (float *)(b + off);
+    off += align_up(64 * sizeof(float));
+    w.prev_box = (int2 *)(b + off);
+    off += align_up(nn * sizeof(int2));
     w.partial_g = (float4 *)(b + off);
     off += align_up(nn * GI2D_FAST_S * GI2D_FAST_ROW * sizeof(float4));
     w.partial_big = (float4 *)(b + off);
@@ -68,40 +84,199 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     w.bytes = off;
     return w;
 }
+__host__ __device__ __forceinline__ int list_base(int tile) { return tile * GI2D_FAST_LROW + GI2D_FAST_HDR; }
 
 // ----------------------------------------------------------------------------------------- fill
-__device__ __forceinline__ void fill_one(int g, int mnx, int mny, int mxx, int mxy, int tiles_x,
-                                         int32_t *__restrict__ cursors, int32_t *__restrict__ buckets) {
-    const int sub = g & (GI2D_FAST_SUB - 1);
+// Tile boxes are kept as (min | max << 16) per axis; 0/0 is the empty box of a gaussian that is in no list.
+__device__ __forceinline__ int2 pack_box(int mnx, int mny, int mxx, int mxy) {
+    return make_int2(mnx | (mxx << 16), mny | (mxy << 16));
+}
+// Bin gaussian g with tile box [mnx, mxx) x [mny, mxy) (`member` false: it is in no tile -- culled, clipped or off
+// screen): append it to the rows of the tiles of the new box that were not in the box it was binned with before.
+__device__ __forceinline__ void fill_diff(int g, bool member, int mnx, int mny, int mxx, int mxy, int tiles_x,
+                                          int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
+    member = member && mxx > mnx && mxy > mny;
+    const int2 nw = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
+    const int2 old = prev_box[g];
+    if (old.x == nw.x && old.y == nw.y) return;  // the usual case: same tiles as last time, nothing to do
+    prev_box[g] = nw;
+    if (!member) return;  // its old entries are dropped by the tile pass (they fail the membership test)
+    const int omnx = old.x & 0xffff, omxx = (int)((unsigned)old.x >> 16), omny = old.y & 0xffff,
+              omxy = (int)((unsigned)old.y >> 16);
     const int w = mxx - mnx, nt = w * (mxy - mny);
-    // GI2D_FILL_BATCH tiles per trip: the returning atomics of a trip are issued back to back, then the stores, so
-    // a lane pays one L2 round trip per trip instead of one per tile (dependent atomics cost ~2 us each: a gaussian
-    // on 3x3 tiles used to spend 9 of them in a row).
+    // GI2D_FILL_BATCH tiles per trip: the returning atomics of a trip are issued back to back, then the stores, so a
+    // lane pays one round trip per trip instead of one per tile
     int di = 0, dj = 0;
     for (int base = 0; base < nt; base += GI2D_FILL_BATCH) {
         int c[GI2D_FILL_BATCH], p[GI2D_FILL_BATCH];
 #pragma unroll
         for (int q = 0; q < GI2D_FILL_BATCH; ++q) {
-            c[q] = (base + q < nt) ? ((mny + di) * tiles_x + mnx + dj) * GI2D_FAST_SUB + sub : -1;
+            const int ti = mny + di, tj = mnx + dj;
+            const bool was = tj >= omnx && tj < omxx && ti >= omny && ti < omxy;  // still listed from before
+            c[q] = (base + q < nt && !was) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
             if (++dj == w) dj = 0, ++di;
         }
 #pragma unroll
-        for (int q = 0; q < GI2D_FILL_BATCH; ++q)
-            p[q] = c[q] >= 0 ? atomicAdd(&cursors[c[q] * GI2D_CURSOR_STRIDE], 1) : GI2D_FAST_CSUB;
+        for (int q = 0; q < GI2D_FILL_BATCH; ++q) p[q] = c[q] >= 0 ? atomicAdd(&lists[c[q]], 1) : GI2D_FAST_C;
 #pragma unroll
         for (int q = 0; q < GI2D_FILL_BATCH; ++q)
-            if (p[q] < GI2D_FAST_CSUB) buckets[c[q] * GI2D_FAST_CSUB + p[q]] = g;
+            if (p[q] < GI2D_FAST_C) lists[c[q] + GI2D_FAST_HDR + p[q]] = g;  // a fuller row is flagged by the tile pass
     }
 }
-
-// partial-row code of gaussian g in tile (tx, ty): >= 0 gaussian-major row, < 0: -(big row) - 1
-__device__ __forceinline__ int partial_slot(int g, const float2 xy, int rad, int tiles_x, int tiles_y, int tx,
-                                            int ty, int big_row) {
-    int mnx, mny, mxx, mxy;
+// The tile box a gaussian with centre xy and INT radius rad is binned with -- the rule of map_gaussian_to_intersects
+// (forward.cu:161-166): radius > 0, not below the clip, box of the int radius.  False: it is in no tile.
+__device__ __forceinline__ bool bin_box(const float2 xy, int rad, float radius_clip, int tiles_x, int tiles_y, int &mnx,
+                                        int &mny, int &mxx, int &mxy) {
+    mnx = mny = mxx = mxy = 0;
+    if (rad <= 0 || (float)rad < radius_clip) return false;
     tile_bbox(xy.x, xy.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
+    return mxx > mnx && mxy > mny;
+}
+// Is tile (tx, ty) in that box?  (What the tile pass asks of every entry of its row.)
+__device__ __forceinline__ bool tile_member(const float2 xy, int rad, float radius_clip, int tiles_x, int tiles_y,
+                                            int tx, int ty, int &mnx, int &mny, int &mxx, int &mxy) {
+    return bin_box(xy, rad, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && tx >= mnx && tx < mxx && ty >= mny &&
+           ty < mxy;
+}
+// First thing of every binning kernel (lane of gaussian 0): reset the per-call status words (status[2] is the sticky
+// copy of the overflow flag) and note the clip radius the membership rule uses, for the tile pass that follows.
+__device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ status, float *__restrict__ meta,
+                                              float radius_clip) {
+    if (g == 0) {
+        status[0] = 0;
+        status[1] = 0;
+        status[3] = 0;
+        meta[0] = radius_clip;
+    }
+}
+// Binning step of a gaussian straight after its projection (the rasterizer's radius_clip equals the projection's on
+// this path).
+__device__ __forceinline__ void bin_projected(int g, const ProjOut &o, int tiles_x, int tiles_y, float radius_clip,
+                                              int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
+    int mnx, mny, mxx, mxy;
+    const bool member = bin_box(o.xy, o.radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && o.tiles_hit > 0;
+    fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, prev_box, lists);
+}
+
+// partial-row code of gaussian g in tile (tx, ty) of its box: >= 0 gaussian-major row, < 0: -(big row) - 1
+__device__ __forceinline__ int partial_slot(int g, int mnx, int mny, int mxx, int mxy, int tx, int ty, int big_row) {
     const int w = mxx - mnx, ntiles = w * (mxy - mny);
     if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + (ty - mny) * w + (tx - mnx);
     return -big_row - 1;
+}
+
+// ------------------------------------------------------------------------------- head of a tile pass
+// What every tile kernel of the fast path does first (all 256 lanes of the tile's workgroup): read the tile's row,
+// test every entry against the current box of its gaussian, order the survivors by ascending id (the stable key sort
+// of the reference pipeline: bin_and_sort_gaussians with depth == 0), write the row / header / tile_bins back where
+// they changed, and hand every survivor to `emit(rank, g, record, box)` (rank = position in the ascending list; the
+// caller stages rank < 256).  Entries [0, sorted_len) are already ascending, so a survivor among them only needs the
+// number of survivors in front of it (a ballot scan) plus the number of smaller APPENDED ids; an appended entry is
+// ranked against everything.  With no append since the last pass -- the steady state of a fit -- there is no loop at
+// all, and nothing is stored.  The row header and the first 256 ids are ONE round of loads (the ids are read before
+// the count is known; slots past the count hold stale ids that are ignored).
+// `ids`: GI2D_FAST_C ints of LDS, `grp`: 32 ints of LDS; both are free again when the function returns (it ends with
+// a workgroup barrier only if `trailing_barrier`).  Returns the number of survivors.
+struct TileBox {
+    int mnx, mny, mxx, mxy;
+};
+template <class Emit>
+__device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty, int tiles_x, int tiles_y,
+                                              const float *__restrict__ meta, const float2 *__restrict__ xys,
+                                              const int32_t *__restrict__ radii, const float *__restrict__ conics,
+                                              const float *__restrict__ colors, const float *__restrict__ opacities,
+                                              int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
+                                              int32_t *__restrict__ status, Emit emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
+    const int hdr_count = row[0], hdr_sorted = row[1];
+    const float radius_clip = meta[0];
+    int my_id[GI2D_FAST_EPT];
+    my_id[0] = row[GI2D_FAST_HDR + tid];
+    const int count = min(max(hdr_count, 0), GI2D_FAST_C), sorted = min(max(hdr_sorted, 0), count);
+    if (tid == 0 && hdr_count > GI2D_FAST_C) {  // more candidates than a row holds: the caller must fall back
+        atomicOr(&status[1], 1);
+        atomicOr(&status[2], 1);
+    }
+    if (tid >= count) my_id[0] = -1;
+#pragma unroll
+    for (int u = 1; u < GI2D_FAST_EPT; ++u) {
+        const int e = tid + 256 * u;
+        my_id[u] = e < count ? row[GI2D_FAST_HDR + e] : -1;
+    }
+    // the first entry's whole record is gathered now and kept; entries past 256 (rare) gather theirs again below
+    GaussRec r0;
+    TileBox b0 = {0, 0, 0, 0};
+    bool keep[GI2D_FAST_EPT];
+    keep[0] = false;
+    if (my_id[0] >= 0) {
+        r0 = load_gaussian(my_id[0], xys, conics, colors, opacities);
+        keep[0] = tile_member(make_float2(r0.gx, r0.gy), radii[my_id[0]], radius_clip, tiles_x, tiles_y, tx, ty, b0.mnx,
+                              b0.mny, b0.mxx, b0.mxy);
+    }
+#pragma unroll
+    for (int u = 1; u < GI2D_FAST_EPT; ++u) {
+        keep[u] = false;
+        if (my_id[u] >= 0) {
+            TileBox b;
+            keep[u] = tile_member(xys[my_id[u]], radii[my_id[u]], radius_clip, tiles_x, tiles_y, tx, ty, b.mnx, b.mny,
+                                  b.mxx, b.mxy);
+        }
+    }
+    int pos[GI2D_FAST_EPT];
+#pragma unroll
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
+        const int e = tid + 256 * u;
+        if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
+        const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
+        pos[u] = __popcll(kp & lanemask_lt());
+        if (lane == 0) {
+            grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
+            grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
+        }
+    }
+    __syncthreads();
+    int before[GI2D_FAST_EPT], total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int u = 0; u < GI2D_FAST_EPT; ++u)
+            if (i == wv + 4 * u) before[u] = total;
+        total += grp[i];
+    }
+    int len = total;
+#pragma unroll
+    for (int i = 16; i < 32; ++i) len += grp[i];
+    if (tid == 0) {
+        // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
+        if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {
+            row[0] = len;
+            row[1] = len;
+        }
+        tile_bins[tile] = make_int2(list_base(tile), list_base(tile) + len);
+    }
+#pragma unroll
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
+        if (!keep[u]) continue;
+        const int e = tid + 256 * u, g = my_id[u];
+        GaussRec r = r0;
+        TileBox b = b0;
+        if (u > 0) {
+            r = load_gaussian(g, xys, conics, colors, opacities);
+            tile_member(make_float2(r.gx, r.gy), radii[g], radius_clip, tiles_x, tiles_y, tx, ty, b.mnx, b.mny, b.mxx,
+                        b.mxy);
+        }
+        // ids are unique within a row, so "smaller" needs no tie rule; dropped entries read as -1 = 0xffffffff
+        int rank, lo, hi;
+        if (e < sorted)
+            rank = before[u] + pos[u], lo = sorted, hi = count;
+        else
+            rank = 0, lo = 0, hi = count;
+        for (int q = lo; q < hi; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
+        if (!(e < sorted && rank == e)) row[GI2D_FAST_HDR + rank] = g;
+        emit(rank, g, r, b);
+    }
+    return len;
 }
 
 // ------------------------------------------------------------------------------- tile order
@@ -115,7 +290,7 @@ __device__ __forceinline__ int partial_slot(int g, const float2 xy, int rad, int
 // (dispatch order is undefined by contract).  Measured: training iteration at N=50 000 50.2 -> 44.6 us; hot-path
 // step 38.3 -> 37.0 us.  Its LDS histogram atomics (many lanes per bin) take ~5 us, so it only rides on kernels that
 // are longer than that (the training update kernel; the end-of-step kernel above 32k gaussians).
-#define GI2D_ORDER_BINS 1025 /* populations 0 .. GI2D_FAST_C */
+#define GI2D_ORDER_BINS (GI2D_FAST_C + 1) /* populations 0 .. GI2D_FAST_C */
 #define GI2D_CU_SLOTS 256
 #define GI2D_ORDER_MAX_TILES 2048 /* larger grids run in several rounds of resident workgroups and balance themselves */
 __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile_bins, int num_tiles,
@@ -214,7 +389,7 @@ __device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restric
                 const int tile = i * tiles_x + j;
                 const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, g);
                 if (pos >= 0)
-                    add_partial<GI2D_FAST_ROW>(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
+                    add_partial<GI2D_FAST_ROW>(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - list_base(tile)));
             }
     }
     unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F);
@@ -231,7 +406,7 @@ __device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restric
             const int tile = (by0 + t / bw) * tiles_x + bx0 + t % bw;
             const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, bg);
             if (pos >= 0)
-                add_partial<GI2D_FAST_ROW>(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - tile * GI2D_FAST_C));
+                add_partial<GI2D_FAST_ROW>(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - list_base(tile)));
         }
 #pragma unroll
         for (int q = 0; q < 11; ++q) {

@@ -62,6 +62,7 @@ struct FusedLds {
     int slot[GI2D_TILE_LIST_CAP];       // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big)
     float sse_w[4];
     int scan_w[4];  // per-wave totals of the backward's item scan (outside the overlay: written during the forward phase)
+    int grp[32];    // tile_list_head: survivors per 64 entries (ascending part, appended part)
     union {
         struct {
             int ids[GI2D_FAST_C];
@@ -86,25 +87,14 @@ struct FusedLds {
 // MODE 1: `vsrc` is the target image gt[H,W,3]; the pixel gradient is that of mean((clamp(out,0,1) - gt)^2):
 //         grad_scale * (clamp(out) - gt) where the clamp passes gradient (models/gaussianimage_cholesky.py:307-310
 //         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
-// ids in list order, kept until they leave as whole-line stores: entry k sits in the last 64 words of the (not yet
-// used) pair buffer of the wave that will read it -- no wave can overwrite what another one still has to read, and
-// even wave 0's slots lie beyond the id sort buffer that is still being read while they are written
-__device__ __forceinline__ int *gid_slot(FusedLds &sm, int k) {
-    return reinterpret_cast<int *>(reinterpret_cast<float *>(sm.pairbuf) + (k >> 6) * GI2D_FWD_PAIRBUF +
-                                   (GI2D_FWD_PAIRBUF - 64)) + (k & 63);
-}
-static_assert(sizeof(unsigned char) * 4 * 2 * GI2D_FWD_LISTLEN + sizeof(float) * (GI2D_FWD_PAIRBUF - 64) >=
-                  sizeof(int) * GI2D_FAST_C,
-              "gid slots of wave 0 must lie beyond the id sort buffer");
-
 template <int MODE>
 __device__ __forceinline__ void fused_tile(
     FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
     const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, int32_t *__restrict__ cursors, const int32_t *__restrict__ buckets,
-    int32_t *__restrict__ gids_sorted, int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g,
-    float4 *__restrict__ partial_big, int32_t *__restrict__ status, float *__restrict__ out_img,
-    const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
+    const float *__restrict__ opacities, const float *__restrict__ meta, int32_t *__restrict__ lists,
+    int2 *__restrict__ tile_bins,
+    float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
+    float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lx = tid & 15, ly = tid >> 4;  // == (lane & 15, wv * 4 + (lane >> 4)): wave wv owns pixel rows 4wv..4wv+3
@@ -121,72 +111,35 @@ __device__ __forceinline__ void fused_tile(
         p2 = vsrc[3 * pix + 2];
     }
 
-    // ---- bucket -> ordered, staged list (as fast_fwd_kernel, but every lane reads the four cursors itself -- one
-    // broadcast transaction each -- instead of four lanes publishing them through LDS behind a barrier)
-    int cnt4[GI2D_FAST_SUB];
-#pragma unroll
-    for (int q = 0; q < GI2D_FAST_SUB; ++q)
-        cnt4[q] = cursors[(tile * GI2D_FAST_SUB + q) * GI2D_CURSOR_STRIDE];
+    // ---- the tile's row -> validated, ordered, staged list (gi2d_fast_internal.h::tile_list_head)
     if (tid == 0) {
         sm.gA[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
         sm.gB[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
         sm.gCb[GI2D_TILE_LIST_CAP] = 0.f;
-        if (cnt4[0] > GI2D_FAST_CSUB || cnt4[1] > GI2D_FAST_CSUB || cnt4[2] > GI2D_FAST_CSUB ||
-            cnt4[3] > GI2D_FAST_CSUB) {
-            atomicOr(&status[1], 1);
-            atomicOr(&status[2], 1);
-        }
     }
     GI2D_TRACE(1);
-    const int c0 = min(cnt4[0], GI2D_FAST_CSUB), c1 = c0 + min(cnt4[1], GI2D_FAST_CSUB),
-              c2 = c1 + min(cnt4[2], GI2D_FAST_CSUB), L = c2 + min(cnt4[3], GI2D_FAST_CSUB);
-    if (tid == 0) tile_bins[tile] = make_int2(tile * GI2D_FAST_C, tile * GI2D_FAST_C + L);
-    int my_id[GI2D_FAST_EPT];
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        const int e = tid + 256 * u;
-        my_id[u] = -1;
-        if (e < L) {
-            const int sub = (e >= c0) + (e >= c1) + (e >= c2);
-            const int off = e - (sub == 0 ? 0 : (sub == 1 ? c0 : (sub == 2 ? c1 : c2)));
-            my_id[u] = buckets[(tile * GI2D_FAST_SUB + sub) * GI2D_FAST_CSUB + off];
-            sm.ids[e] = my_id[u];
-        }
-    }
-    __syncthreads();
-    GI2D_TRACE(2);
-    // every lane has read the cursors: ready them for the next call
-    if (tid < GI2D_FAST_SUB) cursors[(tile * GI2D_FAST_SUB + tid) * GI2D_CURSOR_STRIDE] = 0;
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        if (my_id[u] < 0) continue;
-        const int g = my_id[u];
-        const GaussRec r = load_gaussian(g, xys, conics, colors, opacities);  // gathers in flight under the rank loop
-        const int rad = radii[g];
-        int rank = 0;
-        for (int q = 0; q < L; ++q) rank += (sm.ids[q] < g) ? 1 : 0;
-        const int big_row = tile * GI2D_TILE_LIST_CAP + rank;
-        const int slot = partial_slot(g, make_float2(r.gx, r.gy), rad, tiles_x, tiles_y, tx, ty, big_row);
-        if (rank < GI2D_TILE_LIST_CAP) {
-            *gid_slot(sm, rank) = g;
-            sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
-            sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
-            sm.gCb[rank] = r.cb;
-            sm.cullw[rank] = cull_word(r, tx0, ty0, img_h);
-            sm.slot[rank] = slot;
-        } else if (slot >= 0) {
-            // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
-            partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
-            partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
-        }
-    }
+    const int L = tile_list_head(
+        sm.ids, sm.grp, tile, tx, ty, tiles_x, tiles_y, meta, xys, radii, conics, colors, opacities, lists,
+        tile_bins, status, [&](int rank, int g, const GaussRec &r, const TileBox &b) {
+            const int slot = partial_slot(g, b.mnx, b.mny, b.mxx, b.mxy, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
+            if (rank < GI2D_TILE_LIST_CAP) {
+                sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
+                sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
+                sm.gCb[rank] = r.cb;
+                sm.cullw[rank] = cull_word(r, tx0, ty0, img_h);
+                sm.slot[rank] = slot;
+            } else if (slot >= 0) {
+                // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
+                partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
+                partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
+            }
+        });
+    GI2D_TRACE(2);
     __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
-    // the tile's ascending id list (only its first 256 entries are ever looked up: find_in_tile), contiguous
-    if (tid < len) gids_sorted[tile * GI2D_FAST_C + tid] = *gid_slot(sm, tid);
     GI2D_TRACE(3);
 
     // ---- forward (the routine every forward kernel shares: gi2d_raster_core.h::fwd_pixel_half_lists)

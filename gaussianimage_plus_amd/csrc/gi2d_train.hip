@@ -97,14 +97,10 @@ template <int KIND>
 __global__ __launch_bounds__(256) void train_project_fill_kernel(
     int n, float clip_coe, TrainParams P, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
     float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors, int32_t *__restrict__ buckets,
-    int32_t *__restrict__ status) {
+    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+    float *__restrict__ meta, int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) {
-        status[0] = 0;
-        status[1] = 0;
-        status[3] = 0;  // status[2] is sticky (any overflow since the caller last cleared it)
-    }
+    begin_binning(g, status, meta, radius_clip);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -117,11 +113,7 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
-        int mnx, mny, mxx, mxy;
-        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
-    }
+    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
 }
 
 struct AdamStep {
@@ -215,7 +207,9 @@ __device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx,
 // begins with its tile pass -- one launch and one parameter round trip less per iteration.
 struct NextFill {
     float clip_coe;
-    int32_t *num_tiles_hit, *cursors, *buckets, *status, *tile_order;
+    int32_t *num_tiles_hit, *lists, *status, *tile_order;
+    int2 *prev_box;
+    float *meta;
 };
 
 // optimizer.py::_multi_tensor_adan / _single_tensor_adan (weight_decay 0, no gradient clipping), operation by
@@ -339,11 +333,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
-        if (g == 0) {
-            next.status[0] = 0;
-            next.status[1] = 0;
-            next.status[3] = 0;
-        }
+        begin_binning(g, next.status, next.meta, radius_clip);
         // From the rows just written, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
         // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
@@ -361,11 +351,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         conics[3 * g + 1] = o.k1;
         conics[3 * g + 2] = o.k2;
         next.num_tiles_hit[g] = o.tiles_hit;
-        if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
-            int mnx, mny, mxx, mxy;
-            tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-            fill_one(g, mnx, mny, mxx, mxy, tiles_x, next.cursors, next.buckets);
-        }
+        bin_projected(g, o, tiles_x, tiles_y, radius_clip, next.prev_box, next.lists);
     }
     if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned)
         best.xyz[2 * g] = P.xyz[2 * g];
@@ -449,14 +435,10 @@ __device__ __forceinline__ void quantise_row(const TrainParams &P, const QuantTr
 __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors, int32_t *__restrict__ buckets,
-    int32_t *__restrict__ status) {
+    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+    float *__restrict__ meta, int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) {
-        status[0] = 0;
-        status[1] = 0;
-        status[3] = 0;
-    }
+    begin_binning(g, status, meta, radius_clip);
     if (g >= n) return;
     const QuantVals v = load_quant(Q);
     QuantRow r;
@@ -473,11 +455,7 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
-        int mnx, mny, mxx, mxy;
-        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
-    }
+    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
 }
 
 // (min, count) / (max, count) combination: equal extremes add their counts
@@ -853,14 +831,10 @@ __device__ __forceinline__ void quantise_row_rs(const QuantTrain &Q, const Quant
 __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int32_t *__restrict__ cursors, int32_t *__restrict__ buckets,
-    int32_t *__restrict__ status) {
+    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+    float *__restrict__ meta, int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) {
-        status[0] = 0;
-        status[1] = 0;
-        status[3] = 0;
-    }
+    begin_binning(g, status, meta, radius_clip);
     if (g >= n) return;
     const QuantValsRS v = load_quant_rs(Q);
     QuantRowRS r;
@@ -876,11 +850,7 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    if (o.radius > 0 && !((float)o.radius < radius_clip) && o.tiles_hit > 0) {
-        int mnx, mny, mxx, mxy;
-        tile_bbox(o.xy.x, o.xy.y, (float)o.radius, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-        fill_one(g, mnx, mny, mxx, mxy, tiles_x, cursors, buckets);
-    }
+    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
 }
 
 __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
@@ -1071,15 +1041,15 @@ static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w
     if (s->kind == 2)
         hipLaunchKernelGGL(train_project_fill_kernel<kScaleRot>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
     else if (s->kind == 0)
         hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
     else
         hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
 }
 
 
@@ -1153,7 +1123,7 @@ static void train_launch_project_fill_quant(const gi2d_train_state *s, const Fas
     const int n = s->num_points, bs = per_gaussian_block(n);
     hipLaunchKernelGGL(train_project_fill_quant_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P, Q,
                        (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
 }
 
 static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
@@ -1161,7 +1131,7 @@ static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const 
     const int n = s->num_points, bs = per_gaussian_block(n);
     hipLaunchKernelGGL(train_project_fill_quant_rs_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P,
                        Q, (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.cursors, w.buckets, s->status);
+                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
 }
 
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
@@ -1295,8 +1265,9 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     NextFill next;
     next.clip_coe = s->clip_coe;
     next.num_tiles_hit = s->num_tiles_hit;
-    next.cursors = w.cursors;
-    next.buckets = w.buckets;
+    next.lists = w.lists;
+    next.prev_box = w.prev_box;
+    next.meta = w.meta;
     next.status = s->status;
     next.tile_order = w.tile_order;
     const int bs = per_gaussian_block(n);

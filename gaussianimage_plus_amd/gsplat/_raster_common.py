@@ -3,11 +3,11 @@
 Reference orchestration (rasterize_sum_plus.py:98-172): cumsum -> `.item()` (host sync in the middle of
 the forward) -> map -> torch.sort -> gather -> bin edges -> rasterize.  Here one forward is two native calls
 on a pooled workspace of the fused fast path (csrc/gi2d_fast.hip):
-    gi2d_fast_bin (bucket fill)  ->  gi2d_fast_rasterize_forward (in-tile ordering + rasterizer)
+    gi2d_fast_bin (binning step on the workspace's persistent tile lists)  ->  gi2d_fast_rasterize_forward
 and one backward is gi2d_fast_rasterize_backward_tiles + _reduce on the same workspace: no float atomics,
 bitwise reproducible.  Eight bytes of status are read back AFTER everything is enqueued (the GPU never
 waits for the host): "no intersection at all" gives the background image (rasterize_sum_plus.py:110-118),
-and a tile bucket overflow (more than 256 gaussians of one id-mod-4 class in a tile) re-runs the forward on
+and a tile row overflow (more than 1024 candidates in one tile) re-runs the forward on
 the capacity-free ops (gi2d_bin_gaussians + plain rasterizer), so results are always exact."""
 from __future__ import annotations
 
@@ -79,6 +79,7 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
     any_hit, overflow = lease.ws.status[:2].tolist()  # after everything is enqueued
     ctx.exact = None
     if overflow:
+        lease.ws.reset()  # the overflowing row lost entries: its workspace starts from empty lists next time
         out_img, final_idx, gids, bins, m = _exact_forward(plus, xys, radii, conics, colors, opacity, img_height,
                                                            img_width, tile_bounds, block, img_size, background,
                                                            radius_clip, isprint)

@@ -268,8 +268,14 @@ class FastWorkspace:
         nbytes = _lib.load().gi2d_fast_workspace_bytes(self.n, self.tx, self.ty)
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
         self.status = torch.zeros(4, dtype=torch.int32, device=like.device)
-        with torch.cuda.device(like.device):
-            _lib.call("gi2d_fast_workspace_init", self.buf.data_ptr(), nbytes, self.n, self.tx, self.ty, _stream(like))
+        self.reset(like)
+
+    def reset(self, like=None):
+        """Empty tile lists: at creation, and after an overflow (its lost entries leave lists and boxes inconsistent)."""
+        t = self.buf if like is None else like
+        with torch.cuda.device(t.device):
+            _lib.call("gi2d_fast_workspace_init", self.buf.data_ptr(), self.buf.numel(), self.n, self.tx, self.ty,
+                      _stream(t))
 
 
 def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_width, radius_clip):

@@ -16,7 +16,7 @@ nothing else: no allocation, no host read-back, nothing but kernel launches on t
   mode "exact" -- the capacity-free ops (any tile population):
       gi2d_project_*_forward -> gi2d_bin_gaussians -> gi2d_rasterize_sum_forward
       -> gi2d_rasterize_backward_tiles -> gi2d_rasterize_backward_reduce -> gi2d_project_*_backward
-`check_status()` raises if a fused step overflowed a tile bucket; `step_safe()` re-runs such a step in
+`check_status()` raises if a fused step overflowed a tile row (and empties the workspace); `step_safe()` re-runs such a step in
 "exact" mode.  Both modes produce the same numbers (tests/test_hotpath_gpu.py).
 
 The gradient image of a step is either given (`set_v_out`) or -- `set_target(gt)` -- the L2-loss gradient of the
@@ -66,7 +66,7 @@ class HotPath:
         self.grad_scale = 2.0 / (3.0 * h * w)
         self.v_xy, self.v_conic, self.v_rgb, self.v_opac = f32(n, 2), f32(n, 3), f32(n, 3), f32(n, 1)
         self.v_cov2d, self.v_mean2d, self.v_params = f32(n, 3), f32(n, 2), f32(n, 2 if kind == "scale_rot" else 3)
-        # fused-path workspace (cursors zeroed once; every forward leaves them zero)
+        # fused-path workspace (persistent tile lists, emptied once here)
         nbytes = self.lib.gi2d_fast_workspace_bytes(n, self.tx, self.ty)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._stream_ptr = torch.cuda.current_stream(dev).cuda_stream
@@ -173,13 +173,17 @@ class HotPath:
         self._drop_bins()
 
     def _drop_bins(self):
-        self._graph = None  # a captured step assumes the buckets it left behind
-        """Buckets filled ahead for inputs that have changed meanwhile: empty them (cursors back to zero)."""
-        if self._binned:
-            with torch.cuda.device(self.dev):
-                _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), self.ws.numel(), self.n, self.tx, self.ty,
-                          self._stream())
-            self._binned = False
+        """The inputs changed: what was binned ahead for the old ones is not the next step's binning.  The tile lists in
+        the workspace stay as they are -- the next project+bin call diffs every gaussian's tile box against them."""
+        self._graph = None  # a captured step assumes the binning it left behind
+        self._binned = False
+
+    def _reset_workspace(self):
+        """Empty tile lists (after an overflow, whose entries are lost, the lists no longer match the boxes)."""
+        with torch.cuda.device(self.dev):
+            _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), self.ws.numel(), self.n, self.tx, self.ty,
+                      self._stream())
+        self._binned = False
 
     def set_v_out(self, v_out: torch.Tensor):
         """Use a fixed gradient image dL/d(out_img) [H,W,3]."""
@@ -276,6 +280,7 @@ class HotPath:
         the flag of this step's tile pass is still there to read."""
         self.step(pipelined=False)
         if self.mode == "fused" and self.status[1].item():
+            self._reset_workspace()
             self.mode = "exact"
             try:
                 self.step()
@@ -300,6 +305,18 @@ class HotPath:
     def replay(self):
         self._graph.replay()
 
+    def tile_lists(self):
+        """(ids, tile_bins) of the last fused tile pass: `ids` is an int32 view of the workspace, tile_bins[t] = [start,
+        end) word positions of tile t's ascending id list in it (gi2d_fast_workspace_views; tests, debugging)."""
+        import ctypes
+        gp, bp = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call("gi2d_fast_workspace_views", self.ws.data_ptr(), self.ws.numel(), self.n, self.tx, self.ty,
+                  ctypes.byref(gp), ctypes.byref(bp))
+        base = self.ws.data_ptr()
+        ids = self.ws[gp.value - base:].view(torch.int32)
+        bins = self.ws[bp.value - base:bp.value - base + 8 * self.T].view(torch.int32).view(self.T, 2)
+        return ids, bins
+
     # ------------------------------------------------------------------ bookkeeping for bench.py
     def num_intersects(self) -> int:
         """Intersection count M = sum(num_tiles_hit) of the last projection (a setup/teardown query)."""
@@ -313,7 +330,9 @@ class HotPath:
         self.status[2] = 0
         overflow = int(bool(now or sticky))
         if overflow:
-            what = "a tile bucket" if self.mode == "fused" else f"the intersection capacity {self.capacity}"
+            if self.mode == "fused":
+                self._reset_workspace()  # the overflowed rows lost entries: start over from empty lists
+            what = "a tile row" if self.mode == "fused" else f"the intersection capacity {self.capacity}"
             raise RuntimeError(f"{what} overflowed (M={m}); results of the last step are invalid")
 
     def kernel_timers(self, steps: int):

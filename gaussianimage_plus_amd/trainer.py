@@ -228,6 +228,14 @@ class NativeFitter:
     def _set_n(self, n: int):
         self.n = int(n)
         self.state.num_points = self.n
+        self._reset_bins()
+
+    def _reset_bins(self):
+        """Rows were renumbered, appended or replaced wholesale (prune / grow / load): the workspace's persistent tile
+        lists refer to gaussian ids, so they start over from empty."""
+        with torch.cuda.device(self.dev):
+            _lib.call("gi2d_fast_workspace_init", self.ws.data_ptr(), self.ws.numel(), self.cap, self.tx, self.ty,
+                      torch.cuda.current_stream(self.dev).cuda_stream)
 
     # ------------------------------------------------------------------
     def _check(self, rc, what):
@@ -286,7 +294,8 @@ class NativeFitter:
             raise RuntimeError("more variances tie with an extreme of the log-quantiser range than the parking list "
                                "holds; results invalid")
         if now or sticky:
-            raise RuntimeError("a tile bucket overflowed (> 256 gaussians per (tile, id mod 4)); results invalid")
+            self._reset_bins()
+            raise RuntimeError("a tile row overflowed (> 1024 candidate gaussians in one tile); results invalid")
 
     # ------------------------------------------------------------------ best-model snapshot (train.py:133-139,157-160)
     def best(self):

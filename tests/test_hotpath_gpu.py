@@ -81,7 +81,7 @@ def test_covariance_kind_fused_equals_exact():
 
 
 def test_bucket_overflow_is_flagged_and_step_safe_recovers(oracle):
-    """> 256 gaussians of one (tile, id mod 4) bucket: status[1] is raised and step_safe() redoes the step
+    """> 1024 candidates in one tile row: status[1] is raised and step_safe() redoes the step
     on the capacity-free ops."""
     from gaussianimage_plus_amd.hotpath import HotPath
     n, h, w = 1400, 32, 48
@@ -100,7 +100,7 @@ def test_bucket_overflow_is_flagged_and_step_safe_recovers(oracle):
     exact.step()
     exact.check_status()
     assert torch.equal(fused.out_img, exact.out_img) and torch.equal(fused.v_params, exact.v_params)
-    # the cursors were left clean: a later, non-overflowing problem on the same object still works
+    # the workspace was emptied: a later, non-overflowing problem on the same object still works
     xyz2, L2, col2, op2 = synth_cholesky(n, h, w, 5)
     fused.set_inputs(xyz2, L2, col2, op2)
     exact.set_inputs(xyz2, L2, col2, op2)
