@@ -41,17 +41,16 @@ SIGNATURES = {
 SIGNATURES.update({
     "gi2d_fast_workspace_init": [_p, _sz, _i, _i, _i, _p],
     "gi2d_fast_workspace_views": [_p, _sz, _i, _i, _i, _p, _p],
-    "gi2d_fast_bin": [_i, _p, _p, _i, _i, _f, _p, _sz, _p, _p],
-    "gi2d_fast_project_bin": [_i, _i, _f, _p, _p, _p, _u, _u, _i, _i, _f, _p, _p, _p, _p, _p, _p, _sz, _p, _p],
-    "gi2d_fast_rasterize_forward": [_i, _i, _i, _u, _u, _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p, _p, _p, _p],
-    "gi2d_fast_rasterize_forward_backward": [_i, _i, _i, _u, _u, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _sz, _p, _p,
-                                             _p],
+    "gi2d_fast_bin": [_i, _p, _p, _p, _p, _p, _i, _i, _f, _p, _sz, _p, _p],
+    "gi2d_fast_project_bin": [_i, _i, _f, _p, _p, _p, _p, _p, _u, _u, _i, _i, _f, _p, _p, _p, _p, _p, _p, _sz, _p, _p],
+    "gi2d_fast_rasterize_forward": [_i, _i, _i, _u, _u, _p, _p, _sz, _p, _p, _p, _p, _p],
+    "gi2d_fast_rasterize_forward_backward": [_i, _i, _i, _u, _u, _p, _p, _p, _f, _p, _p, _sz, _p, _p, _p],
     "gi2d_fast_rasterize_backward_tiles": [_i, _i, _i, _u, _u, _p, _p, _i, _p, _sz, _p],
-    "gi2d_fast_rasterize_backward_reduce": [_i, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p, _p],
+    "gi2d_fast_rasterize_backward_reduce": [_i, _i, _i, _p, _sz, _p, _p, _p, _p, _p, _p],
     "gi2d_fast_reduce_project_backward": [_i, _i, _p, _p, _u, _u, _p, _p, _p, _i, _i, _f, _p, _sz, _p, _p, _p, _p, _p,
                                           _p, _p, _p, _p, _p],
-    "gi2d_fast_reduce_project_backward_project_bin": [_i, _i, _f, _p, _p, _p, _u, _u, _p, _p, _p, _p, _p, _i, _i, _f, _p,
-                                                      _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "gi2d_fast_reduce_project_backward_project_bin": [_i, _i, _f, _p, _p, _p, _p, _p, _u, _u, _p, _p, _p, _p, _p, _i, _i,
+                                                      _f, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_fast_tile_capacity": [],
     "gi2d_timer_create": [_p], "gi2d_timer_destroy": [_p], "gi2d_timer_arm": [_p], "gi2d_timer_elapsed_us": [_p, _p],
     # struct gi2d_train_state* (gaussianimage_plus_amd/trainer.py::_TrainState)

@@ -99,26 +99,47 @@ __device__ __forceinline__ float pair_vis(float sigma_l2) { return __builtin_amd
 struct CullBox {
     float x0, x1, y0, y1;  // inclusive pixel-coordinate range
 };
-__device__ __forceinline__ bool cull_box(float gx, float gy, float a, float b, float c, float opac,
-                                         CullBox &box) {
-    const float big = 3.0e38f;
+// Half extents (hx, hy) of that box around the centre: hx < 0 -- the gaussian can never contribute; hx = GI2D_CULL_FULL --
+// no finite box exists (non positive definite conic or non-finite inputs) and every pixel must be evaluated.  One
+// gaussian's extents do not depend on the tile, so the fast path computes them once per gaussian in its binning step.
+#define GI2D_CULL_FULL 3.0e38f
+__device__ __forceinline__ void cull_extent(float gx, float gy, float a, float b, float c, float opac, float &hx,
+                                            float &hy) {
+    const float big = GI2D_CULL_FULL;
+    hx = hy = big;
+    if (!(opac == opac)) return;             // NaN opacity: min(1, NaN) = 1 in the reference
+    if (!(opac * 255.f >= 1.f)) {            // alpha <= opac < 1/255 whenever sigma >= 0
+        hx = hy = -1.f;
+        return;
+    }
+    const float det = a * c - b * b;
+    if (!(a > 0.f) || !(c > 0.f) || !(det > 0.f)) return;  // not PD / NaN: no box
+    const float tau2 = 2.f * __logf(opac * 255.f) * 1.0002f + 1e-3f;
+    const float ex = sqrtf(tau2 * c / det) * 1.0002f + 0.75f;
+    const float ey = sqrtf(tau2 * a / det) * 1.0002f + 0.75f;
+    if (!(ex < big) || !(ey < big) || !(gx == gx) || !(gy == gy)) return;
+    hx = ex;
+    hy = ey;
+}
+__device__ __forceinline__ bool cull_box_of(float gx, float gy, float hx, float hy, CullBox &box) {
+    const float big = GI2D_CULL_FULL;
     box.x0 = -big;
     box.x1 = big;
     box.y0 = -big;
     box.y1 = big;
-    if (!(opac == opac)) return true;      // NaN opacity: min(1, NaN) = 1 in the reference
-    if (!(opac * 255.f >= 1.f)) return false;  // alpha <= opac < 1/255 whenever sigma >= 0
-    const float det = a * c - b * b;
-    if (!(a > 0.f) || !(c > 0.f) || !(det > 0.f)) return true;  // not PD / NaN: no box
-    const float tau2 = 2.f * __logf(opac * 255.f) * 1.0002f + 1e-3f;
-    const float hx = sqrtf(tau2 * c / det) * 1.0002f + 0.75f;
-    const float hy = sqrtf(tau2 * a / det) * 1.0002f + 0.75f;
-    if (!(hx < big) || !(hy < big) || !(gx == gx) || !(gy == gy)) return true;
+    if (hx < 0.f) return false;
+    if (hx >= big) return true;
     box.x0 = gx - hx;
     box.x1 = gx + hx;
     box.y0 = gy - hy;
     box.y1 = gy + hy;
     return true;
+}
+__device__ __forceinline__ bool cull_box(float gx, float gy, float a, float b, float c, float opac,
+                                         CullBox &box) {
+    float hx, hy;
+    cull_extent(gx, gy, a, b, c, opac, hx, hy);
+    return cull_box_of(gx, gy, hx, hy, box);
 }
 
 }  // namespace gi2d

@@ -31,17 +31,21 @@
 namespace gi2d {
 
 // ----------------------------------------------------------------------------------------- fill
+// Binning step on given projection outputs (what the autograd wrappers have: the projection is a separate operator).
 __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__restrict__ xys,
-                                                        const int32_t *__restrict__ radii, int tiles_x,
-                                                        int tiles_y, float radius_clip, int2 *__restrict__ prev_box,
-                                                        int32_t *__restrict__ lists, float *__restrict__ meta,
+                                                        const int32_t *__restrict__ radii,
+                                                        const float *__restrict__ conics,
+                                                        const float *__restrict__ colors,
+                                                        const float *__restrict__ opacities, int tiles_x, int tiles_y,
+                                                        float radius_clip, int2 *__restrict__ prev_box,
+                                                        int32_t *__restrict__ lists, float4 *__restrict__ recs,
                                                         int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    begin_binning(g, status, meta, radius_clip);
+    begin_binning(g, status);
     if (g >= n) return;
-    int mnx, mny, mxx, mxy;  // forward.cu:161: culled gaussians are in no tile
-    const bool member = bin_box(xys[g], radii[g], radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-    fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, prev_box, lists);
+    // forward.cu:161: culled gaussians are in no tile
+    bin_one(g, xys[g], radii[g], true, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g], colors[3 * g],
+            colors[3 * g + 1], colors[3 * g + 2], tiles_x, tiles_y, radius_clip, prev_box, lists, recs);
 }
 
 // projection of gaussian g + its binning step (g == 0 also resets the per-call status words)
@@ -50,9 +54,8 @@ __device__ __forceinline__ void project_fill_one(
     int g, int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip, float2 *xys,
     float *__restrict__ depths, int32_t *radii, float *conics, int32_t *__restrict__ num_tiles_hit,
-    int2 *__restrict__ prev_box, int32_t *__restrict__ lists, float *__restrict__ meta,
-    int32_t *__restrict__ status) {
-    begin_binning(g, status, meta, radius_clip);
+    const BinTarget &bt) {
+    begin_binning(g, bt.status);
     if (g >= n) return;
     const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
     xys[g] = o.xy;
@@ -62,7 +65,8 @@ __device__ __forceinline__ void project_fill_one(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
+    bin_projected(g, o, bt.opacities[g], bt.colors[3 * g], bt.colors[3 * g + 1], bt.colors[3 * g + 2], tiles_x, tiles_y,
+                  radius_clip, bt.prev_box, bt.lists, bt.recs);
 }
 
 template <int KIND>
@@ -70,10 +74,9 @@ __global__ __launch_bounds__(256) void fast_project_fill_kernel(
     int n, float clip_coe, const float2 *__restrict__ means2d, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
     float2 *__restrict__ xys, float *__restrict__ depths, int32_t *__restrict__ radii,
-    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box,
-    int32_t *__restrict__ lists, float *__restrict__ meta, int32_t *__restrict__ status) {
+    float *__restrict__ conics, int32_t *__restrict__ num_tiles_hit, BinTarget bt) {
     project_fill_one<KIND>(blockIdx.x * blockDim.x + threadIdx.x, n, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x,
-                           tiles_y, radius_clip, xys, depths, radii, conics, num_tiles_hit, prev_box, lists, meta, status);
+                           tiles_y, radius_clip, xys, depths, radii, conics, num_tiles_hit, bt);
 }
 
 // -------------------------------------------------------------------------------------- forward
@@ -83,12 +86,11 @@ struct FastFwdLds {
 static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id buffer of the list head overlays the pair buffers");
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
-    int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
-    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, const float *__restrict__ background, const float *__restrict__ meta,
-    int32_t *__restrict__ lists, int2 *__restrict__ tile_bins, GaussRec *__restrict__ packed,
-    float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
-    float *__restrict__ final_Ts, int32_t *__restrict__ final_idx, float *__restrict__ out_img) {
+    int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
+    const float *__restrict__ background, int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
+    GaussRec *__restrict__ packed, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
+    int32_t *__restrict__ status, float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
+    float *__restrict__ out_img) {
     __shared__ FastFwdLds sm;
     __shared__ int grp[32];
     int *ids = reinterpret_cast<int *>(sm.f.pairbuf);  // id buffer of the head: dead before the pair buffers are first written
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     if (tid == 0) fwd_stage_dummy(sm.f);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
     const int L = tile_list_head(
-        ids, grp, tile, tx, ty, tiles_x, tiles_y, meta, xys, radii, conics, colors, opacities, lists, tile_bins,
-        status, [&](int rank, int g, const GaussRec &r, const TileBox &b) {
-            const int slot = partial_slot(g, b.mnx, b.mny, b.mxx, b.mxy, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
+        ids, grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
+            const GaussRec &r = br.r;
+            const int slot = partial_slot(g, br.box, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
             if (rank < GI2D_TILE_LIST_CAP) {
-                const unsigned mask = cull_word(r, tx0, ty0, img_h);
+                const unsigned mask = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
                 fwd_stage_entry(sm.f, rank, r, mask);
                 float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
                 dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
@@ -193,28 +195,24 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 // ----------------------------------------------------------------- forward + backward in one pass
 template <int MODE>
 __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
-    int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
-    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, const float *__restrict__ meta, int32_t *__restrict__ lists,
+    int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs, int32_t *__restrict__ lists,
     int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
     int32_t *__restrict__ status, float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale,
     float *__restrict__ tile_sse, const int32_t *__restrict__ tile_order) {
     __shared__ FusedLds sm;
-    fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, xys, radii, conics, colors, opacities,
-                     meta, lists, tile_bins, partial_g, partial_big, status, out_img, vsrc, grad_scale, tile_sse);
+    fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, recs, lists, tile_bins, partial_g,
+                     partial_big, status, out_img, vsrc, grad_scale, tile_sse);
 }
 
 // --------------------------------------------------------------------------------------- reduce
 __global__ __launch_bounds__(256) void fast_reduce_kernel(
-    int n, const float2 *__restrict__ xys, const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
-    float radius_clip, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
-    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float2 *__restrict__ v_xy,
-    float *__restrict__ v_conic, float *__restrict__ v_rgb, float *__restrict__ v_opacity,
+    int n, const int2 *__restrict__ prev_box, int tiles_x, int tiles_y, const int32_t *__restrict__ gids_sorted,
+    const int2 *__restrict__ tile_bins, const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big,
+    float2 *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_rgb, float *__restrict__ v_opacity,
     float4 *__restrict__ v_abs_xy) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float acc[11];
-    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
-               partial_g, partial_big, acc);
+    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     if (g < n) store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
 }
 
@@ -224,9 +222,8 @@ struct NextProject {
     float clip_coe;
     const float2 *means2d;
     float *depths;
-    int32_t *num_tiles_hit, *lists, *status;
-    int2 *prev_box;
-    float *meta;
+    int32_t *num_tiles_hit;
+    BinTarget bt;
     int32_t *tile_order;  // non-null: one extra workgroup re-balances the next tile pass (large populations only,
                           // where this kernel is long enough to hide it)
 };
@@ -234,7 +231,7 @@ struct NextProject {
 template <int KIND, bool FILL_NEXT>
 __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     int n, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
-    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    int2 *prev_box, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, float2 *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_rgb, float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy,
@@ -246,8 +243,7 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float acc[11];
-    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
-               partial_g, partial_big, acc);
+    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     if (g >= n) return;
     store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
     ProjGrad r;
@@ -261,8 +257,7 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     store_proj_grad(g, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
     if (FILL_NEXT)
         project_fill_one<KIND>(g, n, next.clip_coe, next.means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip,
-                               xys, next.depths, radii, conics, next.num_tiles_hit, next.prev_box, next.lists, next.meta,
-                               next.status);
+                               xys, next.depths, radii, conics, next.num_tiles_hit, next.bt);
 }
 
 static int check_ws(const char *what, void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y) {
@@ -363,40 +358,55 @@ int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int 
     return check_launch("fast workspace init");
 }
 
-int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, int tiles_x, int tiles_y, float radius_clip,
-                  void *ws, size_t ws_bytes, int32_t *status, gi2d_stream_t st) {
+static BinTarget bin_target(const FastWs &w, const float *colors, const float *opac, int32_t *status) {
+    BinTarget bt;
+    bt.colors = colors;
+    bt.opacities = opac;
+    bt.prev_box = w.prev_box;
+    bt.lists = w.lists;
+    bt.recs = w.recs;
+    bt.status = status;
+    return bt;
+}
+
+int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, const float *conics, const float *colors,
+                  const float *opac, int tiles_x, int tiles_y, float radius_clip, void *ws, size_t ws_bytes,
+                  int32_t *status, gi2d_stream_t st) {
     int rc = check_ws("fast bin: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
-    if (!status || (n > 0 && (!xys || !radii))) {
+    if (!status || (n > 0 && (!xys || !radii || !conics || !colors || !opac))) {
         set_error("fast bin: null pointer");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int fbs = per_gaussian_block(n);
     hipLaunchKernelGGL(fast_fill_kernel, dim3((n + fbs - 1) / fbs > 0 ? (n + fbs - 1) / fbs : 1), dim3(fbs), 0,
-                       (hipStream_t)st, n, (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.prev_box,
-                       w.lists, w.meta, status);
+                       (hipStream_t)st, n, (const float2 *)xys, radii, conics, colors, opac, tiles_x, tiles_y,
+                       radius_clip, w.prev_box, w.lists, w.recs, status);
     return check_launch("fast bin");
 }
 
 int gi2d_fast_project_bin(int kind, int n, float clip_coe, const float *means2d, const float *p0,
-                          const float *p1, unsigned h, unsigned w_, int tiles_x, int tiles_y, float radius_clip,
-                          float *xys, float *depths, int32_t *radii, float *conics, int32_t *nth, void *ws,
-                          size_t ws_bytes, int32_t *status, gi2d_stream_t st) {
+                          const float *p1, const float *colors, const float *opac, unsigned h, unsigned w_,
+                          int tiles_x, int tiles_y, float radius_clip, float *xys, float *depths, int32_t *radii,
+                          float *conics, int32_t *nth, void *ws, size_t ws_bytes, int32_t *status,
+                          gi2d_stream_t st) {
     int rc = check_ws("fast project+bin: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     if (kind < 0 || kind > 2 || !status ||
-        (n > 0 && (!means2d || !p0 || !xys || !depths || !radii || !conics || !nth || (kind == 2 && !p1)))) {
+        (n > 0 && (!means2d || !p0 || !colors || !opac || !xys || !depths || !radii || !conics || !nth ||
+                   (kind == 2 && !p1)))) {
         set_error("fast project+bin: bad argument");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int bs = per_gaussian_block(n);
     const dim3 grid((n + bs - 1) / bs > 0 ? (n + bs - 1) / bs : 1), block(bs);
+    const BinTarget bt = bin_target(w, colors, opac, status);
 #define GI2D_LAUNCH_PF(K)                                                                                       \
     hipLaunchKernelGGL(fast_project_fill_kernel<K>, grid, block, 0, (hipStream_t)st, n, clip_coe,              \
                        (const float2 *)means2d, p0, p1, (float)w_, (float)h, tiles_x, tiles_y, radius_clip,    \
-                       (float2 *)xys, depths, radii, conics, nth, w.prev_box, w.lists, w.meta, status)
+                       (float2 *)xys, depths, radii, conics, nth, bt)
     if (kind == 0)
         GI2D_LAUNCH_PF(kCholesky);
     else if (kind == 1)
@@ -407,11 +417,9 @@ int gi2d_fast_project_bin(int kind, int n, float clip_coe, const float *means2d,
     return check_launch("fast project+bin");
 }
 
-int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *xys,
-                                const int32_t *radii, const float *conics, const float *colors,
-                                const float *opac, const float *background, void *ws, size_t ws_bytes,
-                                int32_t *status, float *final_Ts, int32_t *final_idx, float *out_img,
-                                gi2d_stream_t st) {
+int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *background,
+                                void *ws, size_t ws_bytes, int32_t *status, float *final_Ts, int32_t *final_idx,
+                                float *out_img, gi2d_stream_t st) {
     int rc = check_ws("fast rasterize forward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     const long long t = (long long)tiles_x * tiles_y;
@@ -420,26 +428,24 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
         set_error("fast rasterize forward: tile grid does not cover the image");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
-    if (!status || !out_img || (n > 0 && (!xys || !radii || !conics || !colors || !opac))) {
+    if (!status || !out_img) {
         set_error("fast rasterize forward: null pointer");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
     hipLaunchKernelGGL(fast_fwd_kernel, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
-                       (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, background,
-                       (const float *)w.meta, w.lists, (int2 *)w.tile_bins, w.packed, w.partial_g, w.partial_big, status,
-                       final_Ts, final_idx, out_img);
+                       (int)w_, (int)h, (const float4 *)w.recs, background, w.lists, (int2 *)w.tile_bins, w.packed,
+                       w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);
     return check_launch("fast rasterize forward");
 }
 
-int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *xys,
-                                         const int32_t *radii, const float *conics, const float *colors,
-                                         const float *opac, const float *background, const float *v_output,
-                                         const float *target, float grad_scale, float *tile_sse, void *ws,
-                                         size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st) {
+int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h,
+                                         const float *background, const float *v_output, const float *target,
+                                         float grad_scale, float *tile_sse, void *ws, size_t ws_bytes,
+                                         int32_t *status, float *out_img, gi2d_stream_t st) {
     int rc = check_ws("fast rasterize forward+backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     const long long t = (long long)tiles_x * tiles_y;
@@ -448,8 +454,7 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
         set_error("fast rasterize forward+backward: tile grid does not cover the image");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
-    if (!status || !out_img || (n > 0 && (!xys || !radii || !conics || !colors || !opac)) ||
-        ((v_output != nullptr) == (target != nullptr)) || (target && !tile_sse)) {
+    if (!status || !out_img || ((v_output != nullptr) == (target != nullptr)) || (target && !tile_sse)) {
         set_error("fast rasterize forward+backward: bad argument (exactly one of v_output / target; tile_sse with target)");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
@@ -457,14 +462,12 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
     float *no_sse = nullptr;
     if (v_output)
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, (const float *)w.meta, w.lists,
-                          (int2 *)w.tile_bins, w.partial_g, w.partial_big,
-                          status, out_img, v_output, 0.f, no_sse, (const int32_t *)w.tile_order);
+                          (int)w_, (int)h, (const float4 *)w.recs, w.lists, (int2 *)w.tile_bins, w.partial_g,
+                          w.partial_big, status, out_img, v_output, 0.f, no_sse, (const int32_t *)w.tile_order);
     else
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, (const float2 *)xys, radii, conics, colors, opac, (const float *)w.meta, w.lists,
-                          (int2 *)w.tile_bins, w.partial_g, w.partial_big,
-                          status, out_img, target, grad_scale, tile_sse, (const int32_t *)w.tile_order);
+                          (int)w_, (int)h, (const float4 *)w.recs, w.lists, (int2 *)w.tile_bins, w.partial_g,
+                          w.partial_big, status, out_img, target, grad_scale, tile_sse, (const int32_t *)w.tile_order);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);
@@ -494,22 +497,21 @@ int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned
     return check_launch("fast rasterize backward tiles");
 }
 
-int gi2d_fast_rasterize_backward_reduce(int n, const float *xys, const int32_t *radii, int tiles_x, int tiles_y,
-                                        float radius_clip, void *ws, size_t ws_bytes, float *v_xy, float *v_conic,
-                                        float *v_rgb, float *v_opacity, float *v_abs_xy, gi2d_stream_t st) {
+int gi2d_fast_rasterize_backward_reduce(int n, int tiles_x, int tiles_y, void *ws, size_t ws_bytes, float *v_xy,
+                                        float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
+                                        gi2d_stream_t st) {
     int rc = check_ws("fast rasterize backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     if (n == 0) return GI2D_OK;
-    if (!xys || !radii || !v_xy || !v_conic || !v_rgb || !v_opacity) {
+    if (!v_xy || !v_conic || !v_rgb || !v_opacity) {
         set_error("fast rasterize backward reduce: null pointer");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int rbs = per_gaussian_block(n);
     hipLaunchKernelGGL(fast_reduce_kernel, dim3((n + rbs - 1) / rbs), dim3(rbs), 0, (hipStream_t)st, n,
-                       (const float2 *)xys, radii, tiles_x, tiles_y, radius_clip, w.gids_sorted,
-                       (const int2 *)w.tile_bins, w.partial_g, w.partial_big, (float2 *)v_xy, v_conic, v_rgb,
-                       v_opacity, (float4 *)v_abs_xy);
+                       (const int2 *)w.prev_box, tiles_x, tiles_y, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g,
+                       w.partial_big, (float2 *)v_xy, v_conic, v_rgb, v_opacity, (float4 *)v_abs_xy);
     return check_launch("fast rasterize backward reduce");
 }
 
@@ -531,19 +533,20 @@ static int reduce_project_impl(int kind, int n, const float *p0, const float *p1
     np.clip_coe = 0.f;
     np.means2d = nullptr;
     np.depths = nullptr;
-    np.num_tiles_hit = np.status = np.tile_order = nullptr;
-    if (next) np = *next;
-    np.lists = w.lists;
-    np.prev_box = w.prev_box;
-    np.meta = w.meta;
+    np.num_tiles_hit = np.tile_order = nullptr;
+    np.bt = bin_target(w, nullptr, nullptr, nullptr);
+    if (next) {
+        np = *next;
+        np.bt = bin_target(w, next->bt.colors, next->bt.opacities, next->bt.status);
+    }
     const int bs = per_gaussian_block(n);
     np.tile_order = (next && n > 32768) ? w.tile_order : nullptr;
     const dim3 grid((n + bs - 1) / bs + (np.tile_order ? 1 : 0)), block(bs);
 #define GI2D_LAUNCH_RP(K, F)                                                                                        \
     hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, (float2 *)xys, radii, \
-                       conics, tiles_x, tiles_y, radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g, \
-                       w.partial_big, p0, p1, (float)w_, (float)h, (float2 *)v_xy, v_conic, v_rgb, v_opacity,        \
-                       (float4 *)v_abs_xy, v_cov2d, (float2 *)v_mean2d, v_p0, v_p1, np)
+                       conics, tiles_x, tiles_y, radius_clip, w.prev_box, w.gids_sorted, (const int2 *)w.tile_bins,  \
+                       w.partial_g, w.partial_big, p0, p1, (float)w_, (float)h, (float2 *)v_xy, v_conic, v_rgb,      \
+                       v_opacity, (float4 *)v_abs_xy, v_cov2d, (float2 *)v_mean2d, v_p0, v_p1, np)
 #define GI2D_LAUNCH_RP2(K)           \
     do {                             \
         if (next)                    \
@@ -574,14 +577,14 @@ int gi2d_fast_reduce_project_backward(int kind, int n, const float *p0, const fl
 }
 
 int gi2d_fast_reduce_project_backward_project_bin(int kind, int n, float clip_coe, const float *means2d,
-                                                  const float *p0, const float *p1, unsigned h, unsigned w_,
-                                                  float *xys, float *depths, int32_t *radii, float *conics,
-                                                  int32_t *nth, int tiles_x, int tiles_y, float radius_clip,
-                                                  void *ws, size_t ws_bytes, int32_t *status, float *v_xy,
-                                                  float *v_conic, float *v_rgb, float *v_opacity, float *v_abs_xy,
-                                                  float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
-                                                  gi2d_stream_t st) {
-    if (n > 0 && (!means2d || !depths || !nth || !status)) {
+                                                  const float *p0, const float *p1, const float *colors,
+                                                  const float *opac, unsigned h, unsigned w_, float *xys,
+                                                  float *depths, int32_t *radii, float *conics, int32_t *nth,
+                                                  int tiles_x, int tiles_y, float radius_clip, void *ws,
+                                                  size_t ws_bytes, int32_t *status, float *v_xy, float *v_conic,
+                                                  float *v_rgb, float *v_opacity, float *v_abs_xy, float *v_cov2d,
+                                                  float *v_mean2d, float *v_p0, float *v_p1, gi2d_stream_t st) {
+    if (n > 0 && (!means2d || !depths || !nth || !status || !colors || !opac)) {
         set_error("fast reduce+project backward + project+bin: null pointer");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
@@ -590,10 +593,13 @@ int gi2d_fast_reduce_project_backward_project_bin(int kind, int n, float clip_co
     np.means2d = (const float2 *)means2d;
     np.depths = depths;
     np.num_tiles_hit = nth;
-    np.status = status;
-    np.lists = nullptr;
-    np.prev_box = nullptr;
-    np.meta = nullptr;
+    np.tile_order = nullptr;
+    np.bt.colors = colors;
+    np.bt.opacities = opac;
+    np.bt.status = status;
+    np.bt.prev_box = nullptr;
+    np.bt.lists = nullptr;
+    np.bt.recs = nullptr;
     return reduce_project_impl(kind, n, p0, p1, h, w_, xys, radii, conics, tiles_x, tiles_y, radius_clip, ws, ws_bytes,
                                v_xy, v_conic, v_rgb, v_opacity, v_abs_xy, v_cov2d, v_mean2d, v_p0, v_p1, &np, st);
 }

@@ -50,11 +50,12 @@ struct FastWs {
     int32_t *tile_bins;    // [T * 2]            [row base + HDR, row base + HDR + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
     int2 *prev_box;        // [N]                tile box each gaussian was last binned with (packed, 0/0 = none)
+    float4 *recs;          // [N * 4]            one 64-byte record per gaussian as of the last binning step: what a tile
+                           //                    pass needs of it, in ONE cache line (see write_record)
     float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
     float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
     int32_t *tile_order;   // [T]                tile handled by workgroup b of the single-pass tile kernel: a
                            //                    permutation that balances tile populations over the CUs
-    float *meta;           // [64]               [0]: radius_clip of the last binning step (the tile pass tests with it)
     size_t bytes;
 };
 static FastWs carve_fast(void *base, int n, int num_tiles) {
@@ -73,10 +74,10 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     // depends on the gaussian count, so a workspace initialised for a capacity can be used with any smaller population
     w.tile_order = (int32_t *)(b + off);
     off += align_up(t * sizeof(int32_t));
-    w.meta = (float *)(b + off);
-    off += align_up(64 * sizeof(float));
     w.prev_box = (int2 *)(b + off);
     off += align_up(nn * sizeof(int2));
+    w.recs = (float4 *)(b + off);
+    off += align_up(nn * 4 * sizeof(float4));
     w.partial_g = (float4 *)(b + off);
     off += align_up(nn * GI2D_FAST_S * GI2D_FAST_ROW * sizeof(float4));
     w.partial_big = (float4 *)(b + off);
@@ -138,59 +139,112 @@ __device__ __forceinline__ bool tile_member(const float2 xy, int rad, float radi
     return bin_box(xy, rad, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && tx >= mnx && tx < mxx && ty >= mny &&
            ty < mxy;
 }
+// What a binning step needs besides the projection: colour / opacity for the records, the workspace's state.
+struct BinTarget {
+    const float *colors, *opacities;
+    int2 *prev_box;
+    int32_t *lists;
+    float4 *recs;
+    int32_t *status;
+};
+
 // First thing of every binning kernel (lane of gaussian 0): reset the per-call status words (status[2] is the sticky
-// copy of the overflow flag) and note the clip radius the membership rule uses, for the tile pass that follows.
-__device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ status, float *__restrict__ meta,
-                                              float radius_clip) {
+// copy of the overflow flag).
+__device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ status) {
     if (g == 0) {
         status[0] = 0;
         status[1] = 0;
         status[3] = 0;
-        meta[0] = radius_clip;
     }
 }
-// Binning step of a gaussian straight after its projection (the rasterizer's radius_clip equals the projection's on
-// this path).
-__device__ __forceinline__ void bin_projected(int g, const ProjOut &o, int tiles_x, int tiles_y, float radius_clip,
-                                              int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
+// The record a binning step leaves per gaussian -- everything a tile pass needs of it, gathered with four 16-byte loads
+// of ONE line instead of nine dwords from five arrays (each of the ~72 entries of a tile used to cost 5-6 line requests,
+// all 1536 tiles asking at once):
+//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, -, -, -)
+// a, b, c: conic; (hx, hy): half extents of the alpha >= 1/255 box (gi2d_common.h::cull_extent), computed here once per
+// gaussian instead of once per (tile, gaussian); box: the tile box it is binned with (0/0: in no tile), which is what
+// the tile pass tests membership against and derives the partial-row slot from.
+__device__ __forceinline__ void write_record(float4 *__restrict__ recs, int g, float2 xy, float a, float b, float c,
+                                             float opac, float cr, float cg, float cb, int2 box) {
+    float hx, hy;
+    cull_extent(xy.x, xy.y, a, b, c, opac, hx, hy);
+    float4 *r = recs + 4 * (size_t)g;
+    r[0] = make_float4(xy.x, xy.y, a, b);
+    r[1] = make_float4(c, opac, cr, cg);
+    r[2] = make_float4(cb, hx, hy, __int_as_float(box.x));
+    r[3] = make_float4(__int_as_float(box.y), 0.f, 0.f, 0.f);
+}
+struct BinRec {
+    GaussRec r;
+    float hx, hy;
+    int2 box;
+};
+__device__ __forceinline__ BinRec load_record(const float4 *__restrict__ recs, int g) {
+    const float4 *p = recs + 4 * (size_t)g;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const float by = p[3].x;
+    BinRec o;
+    o.r.gx = q0.x, o.r.gy = q0.y, o.r.a = q0.z, o.r.b = q0.w;
+    o.r.c = q1.x, o.r.opac = q1.y, o.r.cr = q1.z, o.r.cg = q1.w;
+    o.r.cb = q2.x, o.r.slot = -1, o.r.gid = g, o.r.pad = 0;
+    o.hx = q2.y, o.hy = q2.z;
+    o.box = make_int2(__float_as_int(q2.w), __float_as_int(by));
+    return o;
+}
+__device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mxx, int &mxy) {
+    mnx = box.x & 0xffff, mxx = (int)((unsigned)box.x >> 16), mny = box.y & 0xffff, mxy = (int)((unsigned)box.y >> 16);
+}
+// Binning step of one gaussian: its tile box (the rasterizer's radius_clip equals the projection's on this path), the
+// appends to the rows of tiles it has entered, and its record.
+__device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
+                                        float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
+                                        float radius_clip, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+                                        float4 *__restrict__ recs) {
     int mnx, mny, mxx, mxy;
-    const bool member = bin_box(o.xy, o.radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && o.tiles_hit > 0;
+    const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
     fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, prev_box, lists);
+    write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0));
+}
+__device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
+                                              int tiles_x, int tiles_y, float radius_clip, int2 *__restrict__ prev_box,
+                                              int32_t *__restrict__ lists, float4 *__restrict__ recs) {
+    bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
+            prev_box, lists, recs);
 }
 
 // partial-row code of gaussian g in tile (tx, ty) of its box: >= 0 gaussian-major row, < 0: -(big row) - 1
-__device__ __forceinline__ int partial_slot(int g, int mnx, int mny, int mxx, int mxy, int tx, int ty, int big_row) {
+__device__ __forceinline__ int partial_slot(int g, int2 box, int tx, int ty, int big_row) {
+    int mnx, mny, mxx, mxy;
+    unpack_box(box, mnx, mny, mxx, mxy);
     const int w = mxx - mnx, ntiles = w * (mxy - mny);
     if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + (ty - mny) * w + (tx - mnx);
     return -big_row - 1;
 }
 
+#ifndef GI2D_HEAD_TRACE /* gi2d_fused_core.h defines it for its phase trace (development aid) */
+#define GI2D_HEAD_TRACE(i) \
+    do {                   \
+    } while (0)
+#endif
 // ------------------------------------------------------------------------------- head of a tile pass
 // What every tile kernel of the fast path does first (all 256 lanes of the tile's workgroup): read the tile's row,
-// test every entry against the current box of its gaussian, order the survivors by ascending id (the stable key sort
-// of the reference pipeline: bin_and_sort_gaussians with depth == 0), write the row / header / tile_bins back where
-// they changed, and hand every survivor to `emit(rank, g, record, box)` (rank = position in the ascending list; the
-// caller stages rank < 256).  Entries [0, sorted_len) are already ascending, so a survivor among them only needs the
-// number of survivors in front of it (a ballot scan) plus the number of smaller APPENDED ids; an appended entry is
-// ranked against everything.  With no append since the last pass -- the steady state of a fit -- there is no loop at
-// all, and nothing is stored.  The row header and the first 256 ids are ONE round of loads (the ids are read before
-// the count is known; slots past the count hold stale ids that are ignored).
-// `ids`: GI2D_FAST_C ints of LDS, `grp`: 32 ints of LDS; both are free again when the function returns (it ends with
-// a workgroup barrier only if `trailing_barrier`).  Returns the number of survivors.
-struct TileBox {
-    int mnx, mny, mxx, mxy;
-};
+// test every entry against the box its gaussian is binned with NOW (its record), order the survivors by ascending id
+// (the stable key sort of the reference pipeline: bin_and_sort_gaussians with depth == 0), write the row / header /
+// tile_bins back where they changed, and hand every survivor to `emit(rank, g, record)` (rank = position in the
+// ascending list; the caller stages rank < 256).  Entries [0, sorted_len) are already ascending, so a survivor among
+// them only needs the number of survivors in front of it (a ballot scan) plus the number of smaller APPENDED ids; an
+// appended entry is ranked against everything.  With no append since the last pass -- the steady state of a fit --
+// there is no loop at all, and nothing is stored.  The row header and the first 256 ids are ONE round of loads (the ids
+// are read before the count is known; slots past the count hold stale ids that are ignored), the records the second.
+// `ids`: GI2D_FAST_C ints of LDS, `grp`: 32 ints of LDS; both are free again after the caller's next workgroup
+// barrier.  Returns the number of survivors.
 template <class Emit>
-__device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty, int tiles_x, int tiles_y,
-                                              const float *__restrict__ meta, const float2 *__restrict__ xys,
-                                              const int32_t *__restrict__ radii, const float *__restrict__ conics,
-                                              const float *__restrict__ colors, const float *__restrict__ opacities,
-                                              int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
-                                              int32_t *__restrict__ status, Emit emit) {
+__device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty,
+                                              const float4 *__restrict__ recs, int32_t *__restrict__ lists,
+                                              int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Emit emit) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
     const int hdr_count = row[0], hdr_sorted = row[1];
-    const float radius_clip = meta[0];
     int my_id[GI2D_FAST_EPT];
     my_id[0] = row[GI2D_FAST_HDR + tid];
     const int count = min(max(hdr_count, 0), GI2D_FAST_C), sorted = min(max(hdr_sorted, 0), count);
@@ -199,54 +253,64 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         atomicOr(&status[2], 1);
     }
     if (tid >= count) my_id[0] = -1;
-#pragma unroll
-    for (int u = 1; u < GI2D_FAST_EPT; ++u) {
-        const int e = tid + 256 * u;
-        my_id[u] = e < count ? row[GI2D_FAST_HDR + e] : -1;
-    }
-    // the first entry's whole record is gathered now and kept; entries past 256 (rare) gather theirs again below
-    GaussRec r0;
-    TileBox b0 = {0, 0, 0, 0};
+    GI2D_HEAD_TRACE(11);
+    // the first entry's record is kept in registers; entries past 256 (rare) fetch theirs again when they are staged
+    BinRec r0;
     bool keep[GI2D_FAST_EPT];
     keep[0] = false;
+    const auto member = [&](int2 box) {
+        int mnx, mny, mxx, mxy;
+        unpack_box(box, mnx, mny, mxx, mxy);
+        return tx >= mnx && tx < mxx && ty >= mny && ty < mxy;  // the empty box 0/0 contains no tile
+    };
     if (my_id[0] >= 0) {
-        r0 = load_gaussian(my_id[0], xys, conics, colors, opacities);
-        keep[0] = tile_member(make_float2(r0.gx, r0.gy), radii[my_id[0]], radius_clip, tiles_x, tiles_y, tx, ty, b0.mnx,
-                              b0.mny, b0.mxx, b0.mxy);
+        r0 = load_record(recs, my_id[0]);
+        keep[0] = member(r0.box);
     }
+    const int rounds = (count + 255) >> 8;  // tile-uniform
 #pragma unroll
     for (int u = 1; u < GI2D_FAST_EPT; ++u) {
         keep[u] = false;
-        if (my_id[u] >= 0) {
-            TileBox b;
-            keep[u] = tile_member(xys[my_id[u]], radii[my_id[u]], radius_clip, tiles_x, tiles_y, tx, ty, b.mnx, b.mny,
-                                  b.mxx, b.mxy);
+        my_id[u] = -1;
+        if (u < rounds) {
+            const int e = tid + 256 * u;
+            if (e < count) {
+                my_id[u] = row[GI2D_FAST_HDR + e];
+                const float4 *p = recs + 4 * (size_t)my_id[u];
+                keep[u] = member(make_int2(__float_as_int(p[2].w), __float_as_int(p[3].x)));
+            }
         }
     }
+    GI2D_HEAD_TRACE(12);
     int pos[GI2D_FAST_EPT];
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        const int e = tid + 256 * u;
-        if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
-        const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
-        pos[u] = __popcll(kp & lanemask_lt());
-        if (lane == 0) {
-            grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
-            grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
+        pos[u] = 0;
+        if (u < rounds) {
+            const int e = tid + 256 * u;
+            if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
+            const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
+            pos[u] = __popcll(kp & lanemask_lt());
+            if (lane == 0) {
+                grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
+                grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
+            }
+        } else if (lane == 0) {
+            grp[wv + 4 * u] = 0;
+            grp[16 + wv + 4 * u] = 0;
         }
     }
     __syncthreads();
-    int before[GI2D_FAST_EPT], total = 0;
+    GI2D_HEAD_TRACE(13);
+    // one wave-level scan gives every lane what it needs: lane i < 16 holds group i's ascending survivors, lanes
+    // 16..31 the appended ones
+    const int cnt = lane < 32 ? grp[lane] : 0;
+    const int incl = wave_inclusive_scan(cnt);
+    const int asc_total = __shfl(incl, 15, 64), len = __shfl(incl, 31, 64);
+    int before[GI2D_FAST_EPT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-#pragma unroll
-        for (int u = 0; u < GI2D_FAST_EPT; ++u)
-            if (i == wv + 4 * u) before[u] = total;
-        total += grp[i];
-    }
-    int len = total;
-#pragma unroll
-    for (int i = 16; i < 32; ++i) len += grp[i];
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) before[u] = __shfl(incl - cnt, wv + 4 * u, 64);
+    (void)asc_total;
     if (tid == 0) {
         // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
         if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {
@@ -257,15 +321,8 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
     }
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        if (!keep[u]) continue;
+        if (u >= rounds || !keep[u]) continue;
         const int e = tid + 256 * u, g = my_id[u];
-        GaussRec r = r0;
-        TileBox b = b0;
-        if (u > 0) {
-            r = load_gaussian(g, xys, conics, colors, opacities);
-            tile_member(make_float2(r.gx, r.gy), radii[g], radius_clip, tiles_x, tiles_y, tx, ty, b.mnx, b.mny, b.mxx,
-                        b.mxy);
-        }
         // ids are unique within a row, so "smaller" needs no tie rule; dropped entries read as -1 = 0xffffffff
         int rank, lo, hi;
         if (e < sorted)
@@ -274,7 +331,7 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
             rank = 0, lo = 0, hi = count;
         for (int q = lo; q < hi; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
         if (!(e < sorted && rank == e)) row[GI2D_FAST_HDR + rank] = g;
-        emit(rank, g, r, b);
+        emit(rank, g, u == 0 ? r0 : load_record(recs, g));
     }
     return len;
 }
@@ -345,10 +402,10 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
     }
 }
 
-// acc[11] <- ordered sum of gaussian g's partial rows.  Must be called by whole waves.
-__device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restrict__ xys,
-                                           const int32_t *__restrict__ radii, int tiles_x, int tiles_y,
-                                           float radius_clip, const int32_t *__restrict__ gids_sorted,
+// acc[11] <- ordered sum of gaussian g's partial rows; `box_of` = prev_box: the tile box g was binned with for the
+// tile pass that wrote them.  Must be called by whole waves.
+__device__ __forceinline__ void reduce_one(int g, int n, const int2 *__restrict__ box_of, int tiles_x,
+                                           const int32_t *__restrict__ gids_sorted,
                                            const int2 *__restrict__ tile_bins, int num_tiles,
                                            const float4 *__restrict__ partial_g,
                                            const float4 *__restrict__ partial_big, float (&acc)[11]) {
@@ -358,12 +415,8 @@ __device__ __forceinline__ void reduce_one(int g, int n, const float2 *__restric
     int mnx = 0, mny = 0, mxx = 0, mxy = 0;
     bool mapped = false;
     if (g < n) {
-        const int rad = radii[g];
-        if (rad > 0 && !((float)rad < radius_clip)) {
-            const float2 c = xys[g];
-            tile_bbox(c.x, c.y, (float)rad, tiles_x, tiles_y, mnx, mny, mxx, mxy);
-            mapped = mxx > mnx && mxy > mny;
-        }
+        unpack_box(box_of[g], mnx, mny, mxx, mxy);
+        mapped = mxx > mnx && mxy > mny;
     }
     const int ntiles = mapped ? (mxx - mnx) * (mxy - mny) : 0;
     if (mapped && ntiles <= GI2D_FAST_S) {

@@ -31,6 +31,7 @@ __device__ unsigned long long *g_fused_trace = nullptr;  // [tiles][16]
         if (threadIdx.x == 0 && g_fused_trace) g_fused_trace[tile * 16 + (i)] = (v);  \
     } while (0)
 #define GI2D_BWD_TRACE(i) GI2D_TRACE_AT(blockIdx.x, i)
+#define GI2D_HEAD_TRACE(i) GI2D_TRACE_AT(tile, i)
 #else
 #define GI2D_TRACE(i) \
     do {              \
@@ -89,10 +90,8 @@ struct FusedLds {
 //         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
 template <int MODE>
 __device__ __forceinline__ void fused_tile(
-    FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float2 *__restrict__ xys,
-    const int32_t *__restrict__ radii, const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, const float *__restrict__ meta, int32_t *__restrict__ lists,
-    int2 *__restrict__ tile_bins,
+    FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
+    int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
     float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
     float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -120,14 +119,14 @@ __device__ __forceinline__ void fused_tile(
     GI2D_TRACE(1);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
     const int L = tile_list_head(
-        sm.ids, sm.grp, tile, tx, ty, tiles_x, tiles_y, meta, xys, radii, conics, colors, opacities, lists,
-        tile_bins, status, [&](int rank, int g, const GaussRec &r, const TileBox &b) {
-            const int slot = partial_slot(g, b.mnx, b.mny, b.mxx, b.mxy, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
+        sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
+            const GaussRec &r = br.r;
+            const int slot = partial_slot(g, br.box, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
             if (rank < GI2D_TILE_LIST_CAP) {
                 sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
                 sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
                 sm.gCb[rank] = r.cb;
-                sm.cullw[rank] = cull_word(r, tx0, ty0, img_h);
+                sm.cullw[rank] = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
                 sm.slot[rank] = slot;
             } else if (slot >= 0) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
@@ -138,6 +137,9 @@ __device__ __forceinline__ void fused_tile(
             }
         });
     GI2D_TRACE(2);
+#if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 1 /* development aid: instruction / time budget of the phases */
+    if (L >= 0) return;
+#endif
     __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     GI2D_TRACE(3);
@@ -159,6 +161,12 @@ __device__ __forceinline__ void fused_tile(
         },
         (float)j, (float)i, o0, o1, o2, last_unused);
     GI2D_TRACE(5);
+#if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 2
+    if (L >= 0) {
+        if (o0 + o1 + o2 == 12345.f) out_img[0] = o0;
+        return;
+    }
+#endif
     fwd_store_pixels(mybuf, o0, o1, o2, tx, ty, img_w, img_h, out_img);
 
     // ---- this pixel's gradient
@@ -187,6 +195,12 @@ __device__ __forceinline__ void fused_tile(
     __syncthreads();  // every wave is done with its list / pair buffer: the overlay becomes the backward's buffers
 
     GI2D_TRACE(6);
+#if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 3
+    if (L >= 0) {
+        if (v0 + v1 + v2 + (float)scan_incl == 12345.f) out_img[0] = v0;
+        return;
+    }
+#endif
     // ---- backward on the same staged records
     bwd_publish_pixel(sm, lx, ly, v0, v1, v2, 0.f);
     float4 *dst = nullptr;

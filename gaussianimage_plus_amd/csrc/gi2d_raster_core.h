@@ -46,17 +46,27 @@ __device__ __forceinline__ GaussRec load_gaussian(int g, const float2 *__restric
 //   (rows / pairs of the 16x16 tile, from the conservative box of gi2d_common.h::cull_box, clipped to the
 //   image height); 0 when it reaches nothing.  Evaluating more pixels than necessary never changes a
 //   result (they fail the alpha test); the box guarantees none that passes is left out.
-__device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, float ty0, int img_h) {
-    CullBox box;
-    if (!cull_box(r.gx, r.gy, r.a, r.b, r.c, r.opac, box)) return 0u;
+__device__ __forceinline__ unsigned cull_word_of(const CullBox &box, float tx0, float ty0, int img_h) {
     const float last_row = fminf(15.f, (float)(img_h - 1) - ty0);
     const float r0f = fmaxf(ceilf(box.y0 - ty0), 0.f), r1f = fminf(floorf(box.y1 - ty0), last_row);
     const float c0f = fmaxf(ceilf(box.x0 - tx0), 0.f), c1f = fminf(floorf(box.x1 - tx0), 15.f);
     if (!(r1f >= r0f) || !(c1f >= c0f)) return 0u;
     const unsigned r0 = (unsigned)r0f, r1 = (unsigned)r1f, q0 = (unsigned)c0f >> 1, q1 = (unsigned)c1f >> 1;
-    unsigned strips = 0;
-    for (unsigned s4 = r0 >> 2; s4 <= (r1 >> 2); ++s4) strips |= 1u << s4;
+    const unsigned s0 = r0 >> 2, s1 = r1 >> 2;
+    const unsigned strips = ((2u << s1) - 1u) & ~((1u << s0) - 1u);  // bits s0 .. s1
     return strips | (r0 << 8) | (r1 << 12) | (q0 << 16) | (q1 << 20);
+}
+__device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, float ty0, int img_h) {
+    CullBox box;
+    if (!cull_box(r.gx, r.gy, r.a, r.b, r.c, r.opac, box)) return 0u;
+    return cull_word_of(box, tx0, ty0, img_h);
+}
+// the same from extents computed once per gaussian (fast path records)
+__device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, float hy, float tx0, float ty0,
+                                                  int img_h) {
+    CullBox box;
+    if (!cull_box_of(gx, gy, hx, hy, box)) return 0u;
+    return cull_word_of(box, tx0, ty0, img_h);
 }
 
 // =========================================================================================== forward

@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     int n, float clip_coe, TrainParams P, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
     float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
     int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-    float *__restrict__ meta, int32_t *__restrict__ status) {
+    float4 *__restrict__ recs, int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    begin_binning(g, status, meta, radius_clip);
+    begin_binning(g, status);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
+    const Row3 col = load_row3(P.feat, g);
+    bin_projected(g, o, P.opacity[g], col.a, col.b, col.c, tiles_x, tiles_y, radius_clip, prev_box, lists, recs);
 }
 
 struct AdamStep {
@@ -149,7 +150,7 @@ __device__ __forceinline__ AdamRows adam_load_rows(const TrainParams &P, int g) 
 __device__ __forceinline__ void adam_rows(const TrainParams &P, int g, AdamRows r, float gx, float gy,
                                           const float (&gp)[3], const float (&gf)[3], const AdamStep &a_xyz,
                                           const AdamStep &a_chol, const AdamStep &a_feat, float2 &new_xy,
-                                          Row3 &new_chol) {
+                                          Row3 &new_chol, Row3 &new_feat) {
     const float nx = adam(r.x.x, gx, r.mx.x, r.vx.x, a_xyz), ny = adam(r.x.y, gy, r.mx.y, r.vx.y, a_xyz);
     const float c0 = adam(r.c.a, gp[0], r.mc.a, r.vc.a, a_chol), c1 = adam(r.c.b, gp[1], r.mc.b, r.vc.b, a_chol),
                 c2 = adam(r.c.c, gp[2], r.mc.c, r.vc.c, a_chol);
@@ -157,6 +158,7 @@ __device__ __forceinline__ void adam_rows(const TrainParams &P, int g, AdamRows 
                 f2 = adam(r.f.c, gf[2], r.mf.c, r.vf.c, a_feat);
     new_xy = make_float2(nx, ny);
     new_chol.a = c0, new_chol.b = c1, new_chol.c = c2;
+    new_feat.a = f0, new_feat.b = f1, new_feat.c = f2;
     store_row2(P.xyz, g, nx, ny);
     store_row2(P.m_xyz, g, r.mx.x, r.mx.y);
     store_row2(P.v_xyz, g, r.vx.x, r.vx.y);
@@ -172,7 +174,7 @@ __device__ __forceinline__ float adan(float p, float g, float &m, float &n, floa
 // Adan on one gaussian's rows, every row read and written whole (five state arrays per parameter group).
 __device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx, float gy, const float (&gp)[3],
                                           const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
-                                          const AdamStep &a_feat, float2 &new_xy, Row3 &new_chol) {
+                                          const AdamStep &a_feat, float2 &new_xy, Row3 &new_chol, Row3 &new_feat) {
     const float2 x = load_row2(P.xyz, g);
     float2 m = load_row2(P.m_xyz, g), v = load_row2(P.v_xyz, g), d = load_row2(P.d_xyz, g), pg = load_row2(P.pg_xyz, g);
     const Row3 c = load_row3(P.chol, g), f = load_row3(P.feat, g);
@@ -185,6 +187,7 @@ __device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx,
                 f2 = adan(f.c, gf[2], mf.c, vf.c, df.c, pf.c, a_feat);
     new_xy = make_float2(nx, ny);
     new_chol.a = c0, new_chol.b = c1, new_chol.c = c2;
+    new_feat.a = f0, new_feat.b = f1, new_feat.c = f2;
     store_row2(P.xyz, g, nx, ny);
     store_row2(P.m_xyz, g, m.x, m.y);
     store_row2(P.v_xyz, g, v.x, v.y);
@@ -209,7 +212,7 @@ struct NextFill {
     float clip_coe;
     int32_t *num_tiles_hit, *lists, *status, *tile_order;
     int2 *prev_box;
-    float *meta;
+    float4 *recs;
 };
 
 // optimizer.py::_multi_tensor_adan / _single_tensor_adan (weight_decay 0, no gradient clipping), operation by
@@ -265,7 +268,7 @@ __device__ __forceinline__ bool best_decision(const BestSnap &best, int n, int g
 template <int KIND, bool FILL_NEXT, bool ADAN>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     int n, TrainParams P, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
-    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    const int2 *prev_box, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
 #pragma clang fp contract(off)
@@ -278,8 +281,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (!ADAN && g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y,
-               partial_g, partial_big, acc);
+    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -325,15 +327,15 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         d[7] = gf[2];
     }
     float2 new_xy;
-    Row3 new_chol;
+    Row3 new_chol, new_feat;
     if (ADAN) {
-        adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
+        adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
     } else {
-        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
+        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
-        begin_binning(g, next.status, next.meta, radius_clip);
+        begin_binning(g, next.status);
         // From the rows just written, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
         // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         conics[3 * g + 1] = o.k1;
         conics[3 * g + 2] = o.k2;
         next.num_tiles_hit[g] = o.tiles_hit;
-        bin_projected(g, o, tiles_x, tiles_y, radius_clip, next.prev_box, next.lists);
+        bin_projected(g, o, P.opacity[g], new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip,
+                      next.prev_box, next.lists, next.recs);
     }
     if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned)
         best.xyz[2 * g] = P.xyz[2 * g];
@@ -436,9 +439,9 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
     int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-    float *__restrict__ meta, int32_t *__restrict__ status) {
+    float4 *__restrict__ recs, int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    begin_binning(g, status, meta, radius_clip);
+    begin_binning(g, status);
     if (g >= n) return;
     const QuantVals v = load_quant(Q);
     QuantRow r;
@@ -455,7 +458,8 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
+    bin_projected(g, o, P.opacity[g], r.col[0].dequant, r.col[1].dequant, r.col[2].dequant, tiles_x, tiles_y,
+                  radius_clip, prev_box, lists, recs);
 }
 
 // (min, count) / (max, count) combination: equal extremes add their counts
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainPara
 
 __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const int2 *__restrict__ prev_box,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best,
@@ -687,8 +691,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
-               partial_big, acc);
+    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     float sums[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) sums[k] = 0.f;
@@ -832,9 +835,9 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
     int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-    float *__restrict__ meta, int32_t *__restrict__ status) {
+    float4 *__restrict__ recs, int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    begin_binning(g, status, meta, radius_clip);
+    begin_binning(g, status);
     if (g >= n) return;
     const QuantValsRS v = load_quant_rs(Q);
     QuantRowRS r;
@@ -850,12 +853,13 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, tiles_x, tiles_y, radius_clip, prev_box, lists);
+    bin_projected(g, o, P.opacity[g], r.col[0].dequant, r.col[1].dequant, r.col[2].dequant, tiles_x, tiles_y,
+                  radius_clip, prev_box, lists, recs);
 }
 
 __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const int2 *__restrict__ prev_box,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
@@ -865,8 +869,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     if (g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, n, xys, radii, tiles_x, tiles_y, radius_clip, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
-               partial_big, acc);
+    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     float sums[GI2D_QT_RS_SUMS];
 #pragma unroll
     for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = 0.f;
@@ -900,8 +903,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
             d[0] = gx, d[1] = gy, d[2] = gp[0], d[3] = gp[1], d[4] = gp[2], d[5] = gf[0], d[6] = gf[1], d[7] = gf[2];
         }
         float2 new_xy;
-        Row3 new_chol;
-        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol);
+        Row3 new_chol, new_feat;
+        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
         if (snapshot) {
             best.xyz[2 * g] = P.xyz[2 * g];
             best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
@@ -1041,15 +1044,15 @@ static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w
     if (s->kind == 2)
         hipLaunchKernelGGL(train_project_fill_kernel<kScaleRot>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
     else if (s->kind == 0)
         hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
     else
         hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
 }
 
 
@@ -1123,7 +1126,7 @@ static void train_launch_project_fill_quant(const gi2d_train_state *s, const Fas
     const int n = s->num_points, bs = per_gaussian_block(n);
     hipLaunchKernelGGL(train_project_fill_quant_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P, Q,
                        (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
+                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
 }
 
 static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
@@ -1131,7 +1134,7 @@ static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const 
     const int n = s->num_points, bs = per_gaussian_block(n);
     hipLaunchKernelGGL(train_project_fill_quant_rs_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P,
                        Q, (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.meta, s->status);
+                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
 }
 
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
@@ -1154,14 +1157,13 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
             train_launch_quant_range(s, P, Q, st);
             train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
         }
-        return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
-                                           s->radii, s->conics, Q.qfeat, s->opacity, nullptr, s->workspace,
-                                           s->workspace_bytes, s->status, nullptr, nullptr, s->out_img, st_);
+        return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr,
+                                           s->workspace, s->workspace_bytes, s->status, nullptr, nullptr, s->out_img,
+                                           st_);
     }
     train_launch_project_fill(s, w, P, tx, ty, st);
-    return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys, s->radii,
-                                       s->conics, s->feat, s->opacity, nullptr, s->workspace, s->workspace_bytes,
-                                       s->status, nullptr, nullptr, s->out_img, st_);
+    return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr, s->workspace,
+                                       s->workspace_bytes, s->status, nullptr, nullptr, s->out_img, st_);
 }
 
 // `count` full iterations: render, L2 loss gradient + backward, Adam update.  lr[3] / first_step are host values:
@@ -1217,9 +1219,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
                 const int step = first_step + it, qstep = q->first_step + it;
                 train_launch_project_fill_quant_rs(s, w, P, Q, tx, ty, st);
                 rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
-                                                          s->xys, s->radii, s->conics, Q.qfeat, s->opacity, nullptr,
-                                                          nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
-                                                          s->workspace_bytes, s->status, s->out_img, st_);
+                                                          nullptr, nullptr, s->gt, grad_scale, s->tile_sse,
+                                                          s->workspace, s->workspace_bytes, s->status, s->out_img, st_);
                 if (rc != GI2D_OK) return rc;
                 AdamStep a[3], aq[3];
                 for (int k = 0; k < 3; ++k) {
@@ -1229,7 +1230,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
                 best.step = step;
                 hipLaunchKernelGGL(train_reduce_update_quant_rs_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
                                    (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
-                                   s->radius_clip, (const int32_t *)w.gids_sorted, (const int2 *)w.tile_bins,
+                                   s->radius_clip, (const int2 *)w.prev_box, (const int32_t *)w.gids_sorted,
+                                   (const int2 *)w.tile_bins,
                                    (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
                                    (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best);
                 hipLaunchKernelGGL(train_quant_finish_rs_kernel, dim3(1), dim3(256), 0, st, blocks, Q, aq[0], aq[1],
@@ -1242,8 +1244,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
             const int step = first_step + it, qstep = q->first_step + it;
             train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
             rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
-                                                      s->xys, s->radii, s->conics, Q.qfeat, s->opacity, nullptr,
-                                                      nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
+                                                      nullptr, nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
                                                       s->workspace_bytes, s->status, s->out_img, st_);
             if (rc != GI2D_OK) return rc;
             AdamStep a[3], aq[3];
@@ -1254,7 +1255,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
             best.step = step;
             hipLaunchKernelGGL(train_reduce_update_quant_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
                                (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
-                               s->radius_clip, (const int32_t *)w.gids_sorted, (const int2 *)w.tile_bins,
+                               s->radius_clip, (const int2 *)w.prev_box, (const int32_t *)w.gids_sorted,
+                               (const int2 *)w.tile_bins,
                                (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
                                (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, s->status);
             hipLaunchKernelGGL(train_quant_finish_kernel<false>, dim3(1), dim3(256), 0, st, blocks, P, Q, a[1], aq[0],
@@ -1267,7 +1269,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     next.num_tiles_hit = s->num_tiles_hit;
     next.lists = w.lists;
     next.prev_box = w.prev_box;
-    next.meta = w.meta;
+    next.recs = w.recs;
     next.status = s->status;
     next.tile_order = w.tile_order;
     const int bs = per_gaussian_block(n);
@@ -1275,10 +1277,9 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     train_launch_project_fill(s, w, P, tx, ty, st);
     for (int it = 0; it < count; ++it) {
         const int step = first_step + it;
-        rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, s->xys,
-                                                  s->radii, s->conics, s->feat, s->opacity, nullptr, nullptr, s->gt,
-                                                  grad_scale, s->tile_sse, s->workspace, s->workspace_bytes,
-                                                  s->status, s->out_img, st_);
+        rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr,
+                                                  nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
+                                                  s->workspace_bytes, s->status, s->out_img, st_);
         if (rc != GI2D_OK) return rc;
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s->beta3, eps, step, adan_opt);
@@ -1286,7 +1287,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
         const bool more = it + 1 < count;
 #define GI2D_LAUNCH_RU(K, F, A)                                                                                      \
     hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A>), gg, bb, 0, st, n, P, (float2 *)s->xys, s->radii,        \
-                       s->conics, tx, ty, s->radius_clip, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g,      \
+                       s->conics, tx, ty, s->radius_clip, (const int2 *)w.prev_box, w.gids_sorted,                    \
+                       (const int2 *)w.tile_bins, w.partial_g,                                                        \
                        w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, \
                        next)
 #define GI2D_LAUNCH_RU2(K, F) \

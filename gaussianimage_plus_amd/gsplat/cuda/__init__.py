@@ -279,7 +279,8 @@ class FastWorkspace:
 
 
 def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_width, radius_clip):
-    """gi2d_fast_bin + gi2d_fast_rasterize_forward -> out_img[H,W,3]; ws.status = {any intersection, overflow}."""
+    """gi2d_fast_bin (binning step + records on the workspace's persistent lists) + gi2d_fast_rasterize_forward
+    -> out_img[H,W,3]; ws.status = {any intersection, overflow}."""
     for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (opacities, "opacities")):
         _chk(t, nm, torch.float32)
     _chk(radii, "radii", torch.int32)
@@ -287,10 +288,10 @@ def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_widt
     out_img = _f32(h, w, 3, like=xys)
     with torch.cuda.device(xys.device):
         st = _stream(xys)
-        _lib.call("gi2d_fast_bin", ws.n, xys.data_ptr(), radii.data_ptr(), ws.tx, ws.ty, float(radius_clip),
-                  ws.buf.data_ptr(), ws.buf.numel(), ws.status.data_ptr(), st)
-        _lib.call("gi2d_fast_rasterize_forward", ws.n, ws.tx, ws.ty, w, h, xys.data_ptr(), radii.data_ptr(),
-                  conics.data_ptr(), colors.data_ptr(), opacities.data_ptr(), None, ws.buf.data_ptr(), ws.buf.numel(),
+        _lib.call("gi2d_fast_bin", ws.n, xys.data_ptr(), radii.data_ptr(), conics.data_ptr(), colors.data_ptr(),
+                  opacities.data_ptr(), ws.tx, ws.ty, float(radius_clip), ws.buf.data_ptr(), ws.buf.numel(),
+                  ws.status.data_ptr(), st)
+        _lib.call("gi2d_fast_rasterize_forward", ws.n, ws.tx, ws.ty, w, h, None, ws.buf.data_ptr(), ws.buf.numel(),
                   ws.status.data_ptr(), None, None, out_img.data_ptr(), st)
     return out_img
 
@@ -309,9 +310,8 @@ def fast_backward(ws, xys, radii, v_output, img_height, img_width, radius_clip, 
         st = _stream(xys)
         _lib.call("gi2d_fast_rasterize_backward_tiles", n, ws.tx, ws.ty, int(img_width), int(img_height), None,
                   v_output.data_ptr(), 1 if with_abs else 0, ws.buf.data_ptr(), ws.buf.numel(), st)
-        _lib.call("gi2d_fast_rasterize_backward_reduce", n, xys.data_ptr(), radii.data_ptr(), ws.tx, ws.ty,
-                  float(radius_clip), ws.buf.data_ptr(), ws.buf.numel(), v_xy.data_ptr(), v_conic.data_ptr(),
-                  v_colors.data_ptr(), v_opacity.data_ptr(), _ptr(v_abs), st)
+        _lib.call("gi2d_fast_rasterize_backward_reduce", n, ws.tx, ws.ty, ws.buf.data_ptr(), ws.buf.numel(),
+                  v_xy.data_ptr(), v_conic.data_ptr(), v_colors.data_ptr(), v_opacity.data_ptr(), _ptr(v_abs), st)
     return v_xy, v_conic, v_colors, v_opacity, v_abs
 
 

@@ -76,7 +76,7 @@ class HotPath:
         self.capacity = 0
         self._exact_ready = False
         self._graph = None
-        self._binned = False  # the workspace's buckets already hold the projection of the current inputs
+        self._binned = False  # lists / records of the workspace are those of the current inputs' projection
         self._build_fused_calls()
 
     # ------------------------------------------------------------------ call lists
@@ -88,24 +88,22 @@ class HotPath:
         rot = p(self.rot) if self.kind == "scale_rot" else None
         v_rot = p(self.v_rot) if self.kind == "scale_rot" else None
         self._f_bin = (L.gi2d_fast_project_bin, "fast project+bin",
-                       [k, n, self.clip_coe, p(self.means), p(self.params), rot, h, w, tx, ty, self.radius_clip,
-                        p(self.xys), p(self.depths), p(self.radii), p(self.conics), p(self.nth), ws, wsb,
+                       [k, n, self.clip_coe, p(self.means), p(self.params), rot, p(self.colors), p(self.opac), h, w, tx, ty,
+                        self.radius_clip, p(self.xys), p(self.depths), p(self.radii), p(self.conics), p(self.nth), ws, wsb,
                         p(self.status)])
         self._f_fwd = (L.gi2d_fast_rasterize_forward, "fast rasterize forward",
-                       [n, tx, ty, w, h, p(self.xys), p(self.radii), p(self.conics), p(self.colors), p(self.opac),
-                        None, ws, wsb, p(self.status), None, None, p(self.out_img)])
+                       [n, tx, ty, w, h, None, ws, wsb, p(self.status), None, None, p(self.out_img)])
         tgt = p(self.target) if self.target is not None else None
         self._f_both = (L.gi2d_fast_rasterize_forward_backward, "fast rasterize forward+backward",
-                        [n, tx, ty, w, h, p(self.xys), p(self.radii), p(self.conics), p(self.colors), p(self.opac),
-                         None, None if tgt else p(self.v_out), tgt, self.grad_scale, p(self.tile_sse), ws, wsb,
-                         p(self.status), p(self.out_img)])
+                        [n, tx, ty, w, h, None, None if tgt else p(self.v_out), tgt, self.grad_scale, p(self.tile_sse), ws,
+                         wsb, p(self.status), p(self.out_img)])
         self._f_tiles = (L.gi2d_fast_rasterize_backward_tiles, "fast rasterize backward tiles",
                          [n, tx, ty, w, h, None, p(self.v_out), 0, ws, wsb])
         self._f_red_next = (L.gi2d_fast_reduce_project_backward_project_bin, "fast reduce+project backward + project+bin",
-                            [k, n, self.clip_coe, p(self.means), p(self.params), rot, h, w, p(self.xys), p(self.depths),
-                             p(self.radii), p(self.conics), p(self.nth), tx, ty, self.radius_clip, ws, wsb,
-                             p(self.status), p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,
-                             p(self.v_cov2d), p(self.v_mean2d), p(self.v_params), v_rot])
+                            [k, n, self.clip_coe, p(self.means), p(self.params), rot, p(self.colors), p(self.opac), h, w,
+                             p(self.xys), p(self.depths), p(self.radii), p(self.conics), p(self.nth), tx, ty,
+                             self.radius_clip, ws, wsb, p(self.status), p(self.v_xy), p(self.v_conic), p(self.v_rgb),
+                             p(self.v_opac), None, p(self.v_cov2d), p(self.v_mean2d), p(self.v_params), v_rot])
         self._f_red = (L.gi2d_fast_reduce_project_backward, "fast reduce+project backward",
                        [k, n, p(self.params), rot, h, w, p(self.xys), p(self.radii), p(self.conics), tx, ty,
                         self.radius_clip, ws, wsb, p(self.v_xy), p(self.v_conic), p(self.v_rgb), p(self.v_opac), None,
@@ -215,7 +213,7 @@ class HotPath:
                 if not self._binned:
                     self._run(self._f_bin, st)
                 self._run(self._f_fwd, st)
-                self._binned = False  # the tile kernel consumed the buckets
+                self._binned = True  # lists and records stay valid for these inputs (another pass may follow)
             else:
                 self._exact_forward(st)
         return self.out_img

@@ -231,48 +231,60 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
                                    gi2d_stream_t stream);
 
 /* ------------------------------------------------------------------ fused fast path
- * The whole per-iteration path in 3 launches (project+fill, forward+backward tile pass,
- * reduce+project backward; 4 when forward and backward tiles are issued separately) on one
- * caller-owned workspace.  Results equal the ops above
- * (bit-identical index work; the same per-pair arithmetic).  Contract:
- *   - workspace: gi2d_fast_workspace_bytes(N, tiles_x, tiles_y) bytes, initialised ONCE with
- *     gi2d_fast_workspace_init (zeroes the bucket cursors; every forward leaves them zero again).
- *     The forward fills it (tile-sorted ids, tile_bins, packed 48-byte gaussian records), the
- *     backward reads it: one workspace per in-flight forward/backward pair.
- *   - capacity: at most gi2d_fast_tile_capacity() (=256) gaussians per (tile, id mod 4) bucket.
- *     status i32[4] = {1 if any tile is non-empty else 0, 1 if a bucket overflowed (results
- *     invalid: use gi2d_bin_gaussians + the plain ops instead), sticky copy of the overflow flag
- *     (never reset by the library: for loops that check once per many steps), 0}; [0], [1] are
- *     reset by the bin call and raised by the forward.  The intersection count itself is sum(num_tiles_hit).
+ * The whole per-iteration path in 3 launches (project+bin, forward+backward tile pass, reduce+project backward;
+ * 4 when forward and backward tiles are issued separately; 2 per step in a loop, where the call that ends a step
+ * also projects and bins for the next) on one caller-owned workspace.  Results equal the ops above (bit-identical
+ * index work; the same per-pair arithmetic).  Contract:
+ *   - workspace: gi2d_fast_workspace_bytes(N, tiles_x, tiles_y) bytes, emptied ONCE with gi2d_fast_workspace_init.
+ *     It holds STATE between calls: persistent per-tile id lists, the tile box every gaussian was last binned with,
+ *     and one 64-byte record per gaussian (centre, conic, colour, opacity, cull extents, tile box).  A binning call
+ *     (gi2d_fast_bin, gi2d_fast_project_bin, the ..._project_bin form of the reduce call) appends a gaussian only to
+ *     the tiles it has ENTERED since the previous binning call and refreshes its record; the tile pass drops the
+ *     entries that left and keeps every list in ascending id order.  Results are those of a from-scratch binning
+ *     for ANY change of the inputs between two calls; what must hold is
+ *       * one binning call before every tile pass (the tile pass takes geometry, colour and opacity from the
+ *         records of that call, not from the caller's arrays);
+ *       * the same num_points in every call between two gi2d_fast_workspace_init (call it again when gaussians are
+ *         renumbered, appended or dropped, and after an overflow);
+ *       * one workspace per in-flight forward/backward pair (the backward reads what the forward left).
+ *   - capacity: at most gi2d_fast_tile_capacity() (= 1024) candidate gaussians per tile, of which the 256 lowest ids
+ *     are rasterized (forward.cu:553).  status i32[4] = {1 if any tile is non-empty else 0, 1 if a tile row
+ *     overflowed (results invalid: use gi2d_bin_gaussians + the plain ops instead and re-initialise the workspace;
+ *     the flag is raised by every tile pass until then), sticky copy of the overflow flag (never reset by the
+ *     library: for loops that check once per many steps), 0}; [0], [1] are reset by the binning call and raised by
+ *     the tile pass.  The intersection count itself is sum(num_tiles_hit).
  *   - kind: 0 Cholesky (project_gaussians_2d), 1 covariance, 2 scale-rot (p0 = scales, p1 = rot).
  *   - gi2d_fast_rasterize_forward: final_Ts may be NULL (it is the constant 1); `background`
  *     non-NULL adds the "no intersection at all -> image = background" rule of
  *     rasterize_sum_plus.py:110-118 (one extra tiny launch); NULL leaves such an image at 0.
- *   - final_idx (positions in the workspace's strided list, tile*1024 + rank) is optional in both
- *     directions: the fused backward does not need it (its forward evaluated every pair with the
+ *   - final_idx (word positions in the workspace's list array, as gi2d_fast_workspace_views reports them) is
+ *     optional in both directions: the fused backward does not need it (its forward evaluated every pair with the
  *     same instructions, so "idx <= final_idx" is implied by the alpha test); pass NULL to skip it.
  */
 size_t gi2d_fast_workspace_bytes(int num_points, int tiles_x, int tiles_y);
 int gi2d_fast_tile_capacity(void);
 int gi2d_fast_workspace_init(void *workspace, size_t workspace_bytes, int num_points, int tiles_x,
                              int tiles_y, gi2d_stream_t stream);
+/* tile_bins[t] = [start, end) word positions of tile t's ascending id list in gaussian_ids_sorted (valid after a
+ * tile pass). */
 int gi2d_fast_workspace_views(void *workspace, size_t workspace_bytes, int num_points, int tiles_x,
                               int tiles_y, int32_t **gaussian_ids_sorted, int32_t **tile_bins);
-int gi2d_fast_bin(int num_points, const float *xys, const int32_t *radii, int tiles_x, int tiles_y,
-                  float radius_clip, void *workspace, size_t workspace_bytes, int32_t *status,
-                  gi2d_stream_t stream);
+/* Binning step on given projection outputs (replaces compute_cumulative_intersects + bin_and_sort_gaussians,
+ * gsplat/gsplat/utils.py:231-311, for depth == 0); conics / colors / opacities go into the records. */
+int gi2d_fast_bin(int num_points, const float *xys, const int32_t *radii, const float *conics,
+                  const float *colors, const float *opacities, int tiles_x, int tiles_y, float radius_clip,
+                  void *workspace, size_t workspace_bytes, int32_t *status, gi2d_stream_t stream);
+/* Projection (as gi2d_project_gaussians_2d*_forward) + binning step in one launch. */
 int gi2d_fast_project_bin(int kind, int num_points, float clip_coe, const float *means2d,
-                          const float *p0, const float *p1, unsigned img_height, unsigned img_width,
-                          int tiles_x, int tiles_y, float radius_clip, float *xys, float *depths,
-                          int32_t *radii, float *conics, int32_t *num_tiles_hit, void *workspace,
-                          size_t workspace_bytes, int32_t *status, gi2d_stream_t stream);
+                          const float *p0, const float *p1, const float *colors, const float *opacities,
+                          unsigned img_height, unsigned img_width, int tiles_x, int tiles_y, float radius_clip,
+                          float *xys, float *depths, int32_t *radii, float *conics, int32_t *num_tiles_hit,
+                          void *workspace, size_t workspace_bytes, int32_t *status, gi2d_stream_t stream);
 int gi2d_fast_rasterize_forward(int num_points, int tiles_x, int tiles_y, unsigned img_width,
-                                unsigned img_height, const float *xys, const int32_t *radii,
-                                const float *conics, const float *colors, const float *opacities,
-                                const float *background, void *workspace, size_t workspace_bytes,
-                                int32_t *status, float *final_Ts, int32_t *final_idx,
+                                unsigned img_height, const float *background, void *workspace,
+                                size_t workspace_bytes, int32_t *status, float *final_Ts, int32_t *final_idx,
                                 float *out_img, gi2d_stream_t stream);
-/* Forward AND backward tiles in ONE launch (one workgroup per tile ranks / gathers / stages its
+/* Forward AND backward tiles in ONE launch (one workgroup per tile validates / gathers / stages its
  * gaussians once and runs both passes on them).  Exactly one of:
  *   v_output f32[H,W,3]  the gradient image is given (it cannot depend on this call's out_img);
  *   target   f32[H,W,3]  the gradient is the L2-loss gradient formed per pixel from the pixel the
@@ -283,9 +295,7 @@ int gi2d_fast_rasterize_forward(int num_points, int tiles_x, int tiles_y, unsign
  * Leaves the workspace exactly as gi2d_fast_rasterize_forward + _backward_tiles(with_abs=0) would
  * for the reduce calls below, except that the packed record list is not written. */
 int gi2d_fast_rasterize_forward_backward(int num_points, int tiles_x, int tiles_y, unsigned img_width,
-                                         unsigned img_height, const float *xys, const int32_t *radii,
-                                         const float *conics, const float *colors,
-                                         const float *opacities, const float *background,
+                                         unsigned img_height, const float *background,
                                          const float *v_output, const float *target, float grad_scale,
                                          float *tile_sse, void *workspace, size_t workspace_bytes,
                                          int32_t *status, float *out_img, gi2d_stream_t stream);
@@ -293,8 +303,7 @@ int gi2d_fast_rasterize_backward_tiles(int num_points, int tiles_x, int tiles_y,
                                        unsigned img_height, const int32_t *final_idx,
                                        const float *v_output, int with_abs, void *workspace,
                                        size_t workspace_bytes, gi2d_stream_t stream);
-int gi2d_fast_rasterize_backward_reduce(int num_points, const float *xys, const int32_t *radii,
-                                        int tiles_x, int tiles_y, float radius_clip, void *workspace,
+int gi2d_fast_rasterize_backward_reduce(int num_points, int tiles_x, int tiles_y, void *workspace,
                                         size_t workspace_bytes, float *v_xy, float *v_conic,
                                         float *v_rgb, float *v_opacity, float *v_abs_xy,
                                         gi2d_stream_t stream);
@@ -308,17 +317,18 @@ int gi2d_fast_reduce_project_backward(int kind, int num_points, const float *p0,
                                       gi2d_stream_t stream);
 
 /* The call that ends step i of a loop can also start step i+1: reduce + projection backward of the
- * gradients just produced, then projection + bucket fill (gi2d_fast_project_bin) of the same gaussians
- * from means2d / p0 / p1 as they are NOW, in one launch -- xys / radii / conics / num_tiles_hit are
- * overwritten with the new projection after the backward has consumed the old one, and the next
- * gi2d_fast_rasterize_forward[_backward] finds its buckets filled.  A caller that then changes the
- * inputs or wants to bin again must first restore the cursors with gi2d_fast_workspace_init. */
+ * gradients just produced, then projection + binning step (gi2d_fast_project_bin) of the same gaussians
+ * from means2d / p0 / p1 / colors / opacities as they are NOW, in one launch -- xys / radii / conics /
+ * num_tiles_hit are overwritten with the new projection after the backward has consumed the old one, and the
+ * next gi2d_fast_rasterize_forward[_backward] finds its lists and records ready.  If the inputs change after this
+ * call, simply bin again (gi2d_fast_project_bin) before the next tile pass. */
 int gi2d_fast_reduce_project_backward_project_bin(
     int kind, int num_points, float clip_coe, const float *means2d, const float *p0, const float *p1,
-    unsigned img_height, unsigned img_width, float *xys, float *depths, int32_t *radii, float *conics,
-    int32_t *num_tiles_hit, int tiles_x, int tiles_y, float radius_clip, void *workspace,
-    size_t workspace_bytes, int32_t *status, float *v_xy, float *v_conic, float *v_rgb, float *v_opacity,
-    float *v_abs_xy, float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1, gi2d_stream_t stream);
+    const float *colors, const float *opacities, unsigned img_height, unsigned img_width, float *xys,
+    float *depths, int32_t *radii, float *conics, int32_t *num_tiles_hit, int tiles_x, int tiles_y,
+    float radius_clip, void *workspace, size_t workspace_bytes, int32_t *status, float *v_xy, float *v_conic,
+    float *v_rgb, float *v_opacity, float *v_abs_xy, float *v_cov2d, float *v_mean2d, float *v_p0, float *v_p1,
+    gi2d_stream_t stream);
 
 /* Kernel timer for measurement code: an armed timer attaches start/stop events to the NEXT
  * gi2d_fast_rasterize_forward_backward launch issued by the calling thread (hipExtLaunchKernelGGL), so

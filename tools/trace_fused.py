@@ -29,41 +29,18 @@ for _ in range(20):
     hp.step()
 torch.cuda.synchronize()
 raw = trace.cpu().numpy()
-t = raw.astype(np.float64)[:, :11] * 0.01  # 100 MHz ticks -> us
+order_cols = [0, 11, 12, 13, 2, 3, 5, 6, 7, 8, 9, 10]
+names = ["start", "hdr+ids", "gathered", "barrier 1", "ranked+staged", "barrier 2", "fwd loop", "pixel out", "bwd items",
+         "bwd lane0", "bwd handoff", "bwd done"]
+t = raw.astype(np.float64)[:, order_cols] * 0.01  # 100 MHz ticks -> us
 t -= t[:, 0].min()
-names = ["start", "cursors", "ids", "staged", "lists", "fwd loop", "pixel out", "bwd items", "bwd lane0", "bwd handoff", "bwd done"]
 print(f"N={n} M={hp.num_intersects()} tiles={hp.T}   (us since the first workgroup started)")
-print(f"{'phase':10s} {'min':>7s} {'p50':>7s} {'p90':>7s} {'max':>7s}   {'dur p50':>8s} {'dur p90':>8s} {'dur max':>8s}")
+print(f"{'phase':14s} {'min':>7s} {'p50':>7s} {'p90':>7s} {'max':>7s}   {'dur p50':>8s} {'dur p90':>8s} {'dur max':>8s}")
 for i, nm in enumerate(names):
     c = t[:, i]
     d = t[:, i] - t[:, i - 1] if i else np.zeros_like(c)
-    print(f"{nm:10s} {c.min():7.2f} {np.percentile(c, 50):7.2f} {np.percentile(c, 90):7.2f} {c.max():7.2f}   "
+    print(f"{nm:14s} {c.min():7.2f} {np.percentile(c, 50):7.2f} {np.percentile(c, 90):7.2f} {c.max():7.2f}   "
           f"{np.percentile(d, 50):8.2f} {np.percentile(d, 90):8.2f} {d.max():8.2f}")
 late = t[:, 0] > 3.0
 print(f"workgroups starting later than 3 us: {int(late.sum())}")
 
-# placement: which workgroups shared a CU, and does the CU's total tile population explain who finishes last?
-hw, xcc, pop = raw[:, 11], raw[:, 12] & 0xf, raw[:, 13]
-cu_key = (xcc << 16) | (hw & 0xff00)  # XCC, SE/SH/CU fields of HW_ID
-end = t[:, 10]
-keys, inv = np.unique(cu_key, return_inverse=True)
-per_cu_n = np.bincount(inv)
-per_cu_pop = np.bincount(inv, weights=pop)
-per_cu_end = np.array([end[inv == i].max() for i in range(len(keys))])
-print(f"distinct CU keys: {len(keys)}, workgroups per CU min/max {per_cu_n.min()}/{per_cu_n.max()}")
-print(f"tile population: mean {pop.mean():.1f} max {pop.max()}; per-CU sum mean {per_cu_pop.mean():.0f} max {per_cu_pop.max():.0f}")
-print(f"corr(CU population sum, CU finish time) = {np.corrcoef(per_cu_pop, per_cu_end)[0, 1]:.2f};  "
-      f"corr(tile population, workgroup finish) = {np.corrcoef(pop, end)[0, 1]:.2f}")
-order = np.argsort(per_cu_end)
-print("slowest CUs: finish", np.round(per_cu_end[order[-5:]], 1), "population", per_cu_pop[order[-5:]], "n", per_cu_n[order[-5:]])
-print("fastest CUs: finish", np.round(per_cu_end[order[:5]], 1), "population", per_cu_pop[order[:5]], "n", per_cu_n[order[:5]])
-blk = np.arange(hp.T)
-same = [len(np.unique(blk[inv == i] % 8)) for i in range(len(keys))]
-print("blockIdx % 8 values per CU (1 = all workgroups of a CU share the residue):", np.bincount(same))
-for i in order[:3]:
-    print("blocks on one CU:", sorted(blk[inv == i].tolist()))
-d = np.diff(np.sort(blk[inv == order[0]]))
-print("block-index strides on that CU:", d.tolist())
-stride_sets = [tuple(np.diff(np.sort(blk[inv == i])).tolist()) for i in range(len(keys))]
-import collections
-print("most common stride patterns:", collections.Counter(stride_sets).most_common(4))
