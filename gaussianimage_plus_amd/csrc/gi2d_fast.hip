@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__r
                                                         const float *__restrict__ colors,
                                                         const float *__restrict__ opacities, int tiles_x, int tiles_y,
                                                         float radius_clip, int2 *__restrict__ prev_box,
-                                                        int32_t *__restrict__ lists, float4 *__restrict__ recs,
+                                                        int32_t *__restrict__ lists, RecSets rs,
                                                         int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
+    float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     // forward.cu:161: culled gaussians are in no tile
     bin_one(g, xys[g], radii[g], true, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g], colors[3 * g],
@@ -56,6 +57,7 @@ __device__ __forceinline__ void project_fill_one(
     float *__restrict__ depths, int32_t *radii, float *conics, int32_t *__restrict__ num_tiles_hit,
     const BinTarget &bt) {
     begin_binning(g, bt.status);
+    float4 *recs = recs_for_binning(bt.recs, g == 0);
     if (g >= n) return;
     const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
     xys[g] = o.xy;
@@ -66,7 +68,7 @@ __device__ __forceinline__ void project_fill_one(
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
     bin_projected(g, o, bt.opacities[g], bt.colors[3 * g], bt.colors[3 * g + 1], bt.colors[3 * g + 2], tiles_x, tiles_y,
-                  radius_clip, bt.prev_box, bt.lists, bt.recs);
+                  radius_clip, bt.prev_box, bt.lists, recs);
 }
 
 template <int KIND>
@@ -86,8 +88,8 @@ struct FastFwdLds {
 static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id buffer of the list head overlays the pair buffers");
 
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
-    int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
-    const float *__restrict__ background, int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
+    int tiles_x, int tiles_y, int img_w, int img_h, RecSets rs, const float *__restrict__ background,
+    int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
     GaussRec *__restrict__ packed, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
     int32_t *__restrict__ status, float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
     float *__restrict__ out_img) {
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x;
+    const float4 *recs = recs_for_tile_pass(rs, blockIdx.x == 0 && tid == 0);
     if (tid == 0) fwd_stage_dummy(sm.f);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
     const int L = tile_list_head(
@@ -182,8 +185,9 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
 // Empty state of a workspace: every tile row empty, no gaussian binned, identity tile order.
 __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n, int32_t *__restrict__ lists,
                                                            int32_t *__restrict__ tile_order,
-                                                           int2 *__restrict__ prev_box) {
+                                                           int2 *__restrict__ prev_box, int32_t *__restrict__ ver) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2) ver[i] = 0;
     if (i < num_tiles) {
         lists[(size_t)i * GI2D_FAST_LROW] = 0;
         lists[(size_t)i * GI2D_FAST_LROW + 1] = 0;
@@ -195,11 +199,12 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 // ----------------------------------------------------------------- forward + backward in one pass
 template <int MODE>
 __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
-    int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs, int32_t *__restrict__ lists,
+    int tiles_x, int tiles_y, int img_w, int img_h, RecSets rs, int32_t *__restrict__ lists,
     int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
     int32_t *__restrict__ status, float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale,
     float *__restrict__ tile_sse, const int32_t *__restrict__ tile_order) {
     __shared__ FusedLds sm;
+    const float4 *recs = recs_for_tile_pass(rs, blockIdx.x == 0 && threadIdx.x == 0);
     fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, recs, lists, tile_bins, partial_g,
                      partial_big, status, out_img, vsrc, grad_scale, tile_sse);
 }
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256) void fast_reduce_kernel(
     float4 *__restrict__ v_abs_xy) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float acc[11];
-    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
+               partial_big, acc);
     if (g < n) store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
 }
 
@@ -228,36 +234,63 @@ struct NextProject {
                           // where this kernel is long enough to hide it)
 };
 
+// FILL_NEXT: the launch holds two kinds of workgroups (plus the tile-ordering one) -- the first `role_blocks` finish
+// step i (gradient reduce + projection backward, from the records the tile pass used), the next `role_blocks` start
+// step i + 1 (projection + binning step + records into the other set): the two do not depend on each other, and a
+// one-lane-per-gaussian kernel this short is all dependent latency, so side by side they take the time of the longer one
+// instead of the sum.  The backward lanes therefore take conic / radius / tile box from the RECORD, never from the
+// xys / radii / conics arrays the projection lanes overwrite in the same launch.
 template <int KIND, bool FILL_NEXT>
 __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
-    int n, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
+    int n, int role_blocks, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
     int2 *prev_box, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, float2 *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_rgb, float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy,
     float *__restrict__ v_cov2d, float2 *__restrict__ v_mean2d, float *__restrict__ v_p0, float *__restrict__ v_p1,
     NextProject next) {
-    if (FILL_NEXT && next.tile_order != nullptr && blockIdx.x == gridDim.x - 1) {
-        compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);  // the extra workgroup (see there)
-        return;
+    int block = blockIdx.x;
+    if (FILL_NEXT) {
+        if (block >= 2 * role_blocks) {
+            compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);  // the extra workgroup (see there)
+            return;
+        }
+        if (block >= role_blocks) {
+            project_fill_one<KIND>((block - role_blocks) * blockDim.x + threadIdx.x, n, next.clip_coe, next.means2d, p0,
+                                   p1, img_w, img_h, tiles_x, tiles_y, radius_clip, xys, next.depths, radii, conics,
+                                   next.num_tiles_hit, next.bt);
+            return;
+        }
     }
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = block * blockDim.x + threadIdx.x;
+    int2 box = make_int2(0, 0);
+    float conic[3] = {0.f, 0.f, 0.f};
+    int radius = 0;
+    if (g < n) {
+        if (FILL_NEXT) {
+            const float4 *rec = recs_of_last_pass(next.bt.recs) + 4 * (size_t)g;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            conic[0] = q0.z, conic[1] = q0.w, conic[2] = q1.x;
+            box = make_int2(__float_as_int(q2.w), __float_as_int(q3.x));
+            radius = __float_as_int(q3.y);
+        } else {
+            box = prev_box[g];
+            conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
+            radius = radii[g];
+        }
+    }
     float acc[11];
-    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     if (g >= n) return;
     store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
     ProjGrad r;
     r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
     r.v_mean = make_float2(0.f, 0.f);
-    if (radii[g] > 0) {
-        const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
+    if (radius > 0) {
         const float vc[3] = {acc[2], acc[3], acc[4]};
         r = project_bwd_one<KIND>(g, p0, p1, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
     }
     store_proj_grad(g, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
-    if (FILL_NEXT)
-        project_fill_one<KIND>(g, n, next.clip_coe, next.means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip,
-                               xys, next.depths, radii, conics, next.num_tiles_hit, next.bt);
 }
 
 static int check_ws(const char *what, void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y) {
@@ -354,17 +387,17 @@ int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int 
     const int work = t > n ? t : n;
     if (work == 0) return GI2D_OK;
     hipLaunchKernelGGL(fast_ws_init_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)st, t, n,
-                       w.lists, w.tile_order, w.prev_box);
+                       w.lists, w.tile_order, w.prev_box, w.ver);
     return check_launch("fast workspace init");
 }
 
-static BinTarget bin_target(const FastWs &w, const float *colors, const float *opac, int32_t *status) {
+static BinTarget bin_target(const FastWs &w, int n, const float *colors, const float *opac, int32_t *status) {
     BinTarget bt;
     bt.colors = colors;
     bt.opacities = opac;
     bt.prev_box = w.prev_box;
     bt.lists = w.lists;
-    bt.recs = w.recs;
+    bt.recs = rec_sets(w, n);
     bt.status = status;
     return bt;
 }
@@ -382,7 +415,7 @@ int gi2d_fast_bin(int n, const float *xys, const int32_t *radii, const float *co
     const int fbs = per_gaussian_block(n);
     hipLaunchKernelGGL(fast_fill_kernel, dim3((n + fbs - 1) / fbs > 0 ? (n + fbs - 1) / fbs : 1), dim3(fbs), 0,
                        (hipStream_t)st, n, (const float2 *)xys, radii, conics, colors, opac, tiles_x, tiles_y,
-                       radius_clip, w.prev_box, w.lists, w.recs, status);
+                       radius_clip, w.prev_box, w.lists, rec_sets(w, n), status);
     return check_launch("fast bin");
 }
 
@@ -402,7 +435,7 @@ int gi2d_fast_project_bin(int kind, int n, float clip_coe, const float *means2d,
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int bs = per_gaussian_block(n);
     const dim3 grid((n + bs - 1) / bs > 0 ? (n + bs - 1) / bs : 1), block(bs);
-    const BinTarget bt = bin_target(w, colors, opac, status);
+    const BinTarget bt = bin_target(w, n, colors, opac, status);
 #define GI2D_LAUNCH_PF(K)                                                                                       \
     hipLaunchKernelGGL(fast_project_fill_kernel<K>, grid, block, 0, (hipStream_t)st, n, clip_coe,              \
                        (const float2 *)means2d, p0, p1, (float)w_, (float)h, tiles_x, tiles_y, radius_clip,    \
@@ -434,7 +467,7 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
     }
     FastWs w = carve_fast(ws, n, (int)t);
     hipLaunchKernelGGL(fast_fwd_kernel, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
-                       (int)w_, (int)h, (const float4 *)w.recs, background, w.lists, (int2 *)w.tile_bins, w.packed,
+                       (int)w_, (int)h, rec_sets(w, n), background, w.lists, (int2 *)w.tile_bins, w.packed,
                        w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
@@ -462,11 +495,11 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
     float *no_sse = nullptr;
     if (v_output)
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, (const float4 *)w.recs, w.lists, (int2 *)w.tile_bins, w.partial_g,
+                          (int)w_, (int)h, rec_sets(w, n), w.lists, (int2 *)w.tile_bins, w.partial_g,
                           w.partial_big, status, out_img, v_output, 0.f, no_sse, (const int32_t *)w.tile_order);
     else
         GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, (const float4 *)w.recs, w.lists, (int2 *)w.tile_bins, w.partial_g,
+                          (int)w_, (int)h, rec_sets(w, n), w.lists, (int2 *)w.tile_bins, w.partial_g,
                           w.partial_big, status, out_img, target, grad_scale, tile_sse, (const int32_t *)w.tile_order);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
@@ -534,17 +567,21 @@ static int reduce_project_impl(int kind, int n, const float *p0, const float *p1
     np.means2d = nullptr;
     np.depths = nullptr;
     np.num_tiles_hit = np.tile_order = nullptr;
-    np.bt = bin_target(w, nullptr, nullptr, nullptr);
+    np.bt = bin_target(w, n, nullptr, nullptr, nullptr);
     if (next) {
         np = *next;
-        np.bt = bin_target(w, next->bt.colors, next->bt.opacities, next->bt.status);
+        np.bt = bin_target(w, n, next->bt.colors, next->bt.opacities, next->bt.status);
     }
-    const int bs = per_gaussian_block(n);
+    const int bs = per_gaussian_block(n), role_blocks = (n + bs - 1) / bs;
     np.tile_order = (next && n > 32768) ? w.tile_order : nullptr;
-    const dim3 grid((n + bs - 1) / bs + (np.tile_order ? 1 : 0)), block(bs);
+#ifdef GI2D_NO_TILE_ORDER /* development aid: tools/order_cost.sh */
+    np.tile_order = nullptr;
+#endif
+    const dim3 grid((next ? 2 : 1) * role_blocks + (np.tile_order ? 1 : 0)), block(bs);
 #define GI2D_LAUNCH_RP(K, F)                                                                                        \
-    hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, (float2 *)xys, radii, \
-                       conics, tiles_x, tiles_y, radius_clip, w.prev_box, w.gids_sorted, (const int2 *)w.tile_bins,  \
+    hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, role_blocks,          \
+                       (float2 *)xys, radii, conics, tiles_x, tiles_y, radius_clip, w.prev_box, w.gids_sorted,       \
+                       (const int2 *)w.tile_bins,                                                                    \
                        w.partial_g, w.partial_big, p0, p1, (float)w_, (float)h, (float2 *)v_xy, v_conic, v_rgb,      \
                        v_opacity, (float4 *)v_abs_xy, v_cov2d, (float2 *)v_mean2d, v_p0, v_p1, np)
 #define GI2D_LAUNCH_RP2(K)           \
@@ -599,7 +636,6 @@ int gi2d_fast_reduce_project_backward_project_bin(int kind, int n, float clip_co
     np.bt.status = status;
     np.bt.prev_box = nullptr;
     np.bt.lists = nullptr;
-    np.bt.recs = nullptr;
     return reduce_project_impl(kind, n, p0, p1, h, w_, xys, radii, conics, tiles_x, tiles_y, radius_clip, ws, ws_bytes,
                                v_xy, v_conic, v_rgb, v_opacity, v_abs_xy, v_cov2d, v_mean2d, v_p0, v_p1, &np, st);
 }

@@ -50,8 +50,9 @@ struct FastWs {
     int32_t *tile_bins;    // [T * 2]            [row base + HDR, row base + HDR + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
     int2 *prev_box;        // [N]                tile box each gaussian was last binned with (packed, 0/0 = none)
-    float4 *recs;          // [N * 4]            one 64-byte record per gaussian as of the last binning step: what a tile
-                           //                    pass needs of it, in ONE cache line (see write_record)
+    float4 *recs;          // [2][N * 4]         one 64-byte record per gaussian as of the last binning step: what a tile
+                           //                    pass needs of it, in ONE cache line (see write_record); two sets, see RecSets
+    int32_t *ver;          // [2]                which record set is current (RecSets)
     float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
     float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
     int32_t *tile_order;   // [T]                tile handled by workgroup b of the single-pass tile kernel: a
@@ -76,8 +77,10 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     off += align_up(t * sizeof(int32_t));
     w.prev_box = (int2 *)(b + off);
     off += align_up(nn * sizeof(int2));
+    w.ver = (int32_t *)(b + off);
+    off += align_up(64 * sizeof(int32_t));
     w.recs = (float4 *)(b + off);
-    off += align_up(nn * 4 * sizeof(float4));
+    off += 2 * align_up(nn * 4 * sizeof(float4));
     w.partial_g = (float4 *)(b + off);
     off += align_up(nn * GI2D_FAST_S * GI2D_FAST_ROW * sizeof(float4));
     w.partial_big = (float4 *)(b + off);
@@ -139,12 +142,45 @@ __device__ __forceinline__ bool tile_member(const float2 xy, int rad, float radi
     return bin_box(xy, rad, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && tx >= mnx && tx < mxx && ty >= mny &&
            ty < mxy;
 }
+// The records exist in two sets so that ONE launch can hold lanes that still read the records the last tile pass used
+// (gradient reduce + projection backward of step i) next to lanes that already write those of step i + 1 (projection +
+// binning): the end-of-step kernel of a loop over given inputs runs the two as separate workgroups.  Which set is
+// which follows from two counters that are only ever written with values derived from the OTHER one, so every lane of a
+// launch computes the same answer whenever it looks (kernels of one stream do not overlap):
+//   a binning kernel   reads ver[0] = c, writes set (c + 1) & 1, leaves ver[1] = c + 1;
+//   a tile pass        reads ver[1] = b, reads set b & 1, leaves ver[0] = b;
+//   "the records the last tile pass used" are set ver[0] & 1.
+struct RecSets {
+    float4 *base;
+    size_t stride;  // float4 per set
+    int32_t *ver;
+};
+__device__ __forceinline__ float4 *recs_for_binning(const RecSets &rs, bool writer) {
+    const int c = rs.ver[0];
+    if (writer) rs.ver[1] = c + 1;
+    return rs.base + ((c + 1) & 1) * rs.stride;
+}
+__device__ __forceinline__ const float4 *recs_for_tile_pass(const RecSets &rs, bool writer) {
+    const int b = rs.ver[1];
+    if (writer) rs.ver[0] = b;
+    return rs.base + (b & 1) * rs.stride;
+}
+__device__ __forceinline__ const float4 *recs_of_last_pass(const RecSets &rs) {
+    return rs.base + (rs.ver[0] & 1) * rs.stride;
+}
+static inline RecSets rec_sets(const FastWs &w, int n) {
+    RecSets rs;
+    rs.base = w.recs;
+    rs.stride = align_up((size_t)(n > 0 ? n : 1) * 4 * sizeof(float4)) / sizeof(float4);
+    rs.ver = w.ver;
+    return rs;
+}
 // What a binning step needs besides the projection: colour / opacity for the records, the workspace's state.
 struct BinTarget {
     const float *colors, *opacities;
     int2 *prev_box;
     int32_t *lists;
-    float4 *recs;
+    RecSets recs;
     int32_t *status;
 };
 
@@ -160,19 +196,19 @@ __device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ statu
 // The record a binning step leaves per gaussian -- everything a tile pass needs of it, gathered with four 16-byte loads
 // of ONE line instead of nine dwords from five arrays (each of the ~72 entries of a tile used to cost 5-6 line requests,
 // all 1536 tiles asking at once):
-//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, -, -, -)
+//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, radius, -, -)
 // a, b, c: conic; (hx, hy): half extents of the alpha >= 1/255 box (gi2d_common.h::cull_extent), computed here once per
 // gaussian instead of once per (tile, gaussian); box: the tile box it is binned with (0/0: in no tile), which is what
 // the tile pass tests membership against and derives the partial-row slot from.
 __device__ __forceinline__ void write_record(float4 *__restrict__ recs, int g, float2 xy, float a, float b, float c,
-                                             float opac, float cr, float cg, float cb, int2 box) {
+                                             float opac, float cr, float cg, float cb, int2 box, int radius) {
     float hx, hy;
     cull_extent(xy.x, xy.y, a, b, c, opac, hx, hy);
     float4 *r = recs + 4 * (size_t)g;
     r[0] = make_float4(xy.x, xy.y, a, b);
     r[1] = make_float4(c, opac, cr, cg);
     r[2] = make_float4(cb, hx, hy, __int_as_float(box.x));
-    r[3] = make_float4(__int_as_float(box.y), 0.f, 0.f, 0.f);
+    r[3] = make_float4(__int_as_float(box.y), __int_as_float(radius), 0.f, 0.f);
 }
 struct BinRec {
     GaussRec r;
@@ -203,7 +239,8 @@ __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_t
     int mnx, mny, mxx, mxy;
     const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
     fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, prev_box, lists);
-    write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0));
+    write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
+                 radius);
 }
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
                                               int tiles_x, int tiles_y, float radius_clip, int2 *__restrict__ prev_box,
@@ -402,22 +439,19 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
     }
 }
 
-// acc[11] <- ordered sum of gaussian g's partial rows; `box_of` = prev_box: the tile box g was binned with for the
-// tile pass that wrote them.  Must be called by whole waves.
-__device__ __forceinline__ void reduce_one(int g, int n, const int2 *__restrict__ box_of, int tiles_x,
-                                           const int32_t *__restrict__ gids_sorted,
+// acc[11] <- ordered sum of gaussian g's partial rows; `box`: the tile box g was binned with for the tile pass that
+// wrote them (prev_box[g] or the box field of its record; 0/0 for lanes without a gaussian).  Must be called by whole
+// waves.
+__device__ __forceinline__ void reduce_one(int g, int2 box, int tiles_x, const int32_t *__restrict__ gids_sorted,
                                            const int2 *__restrict__ tile_bins, int num_tiles,
                                            const float4 *__restrict__ partial_g,
                                            const float4 *__restrict__ partial_big, float (&acc)[11]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int q = 0; q < 11; ++q) acc[q] = 0.f;
-    int mnx = 0, mny = 0, mxx = 0, mxy = 0;
-    bool mapped = false;
-    if (g < n) {
-        unpack_box(box_of[g], mnx, mny, mxx, mxy);
-        mapped = mxx > mnx && mxy > mny;
-    }
+    int mnx, mny, mxx, mxy;
+    unpack_box(box, mnx, mny, mxx, mxy);
+    const bool mapped = mxx > mnx && mxy > mny;
     const int ntiles = mapped ? (mxx - mnx) * (mxy - mny) : 0;
     if (mapped && ntiles <= GI2D_FAST_S) {
         // GI2D_REDUCE_BATCH rows per trip: their loads are in flight together, the additions stay in ascending

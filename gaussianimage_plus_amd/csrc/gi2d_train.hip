@@ -97,10 +97,11 @@ template <int KIND>
 __global__ __launch_bounds__(256) void train_project_fill_kernel(
     int n, float clip_coe, TrainParams P, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
     float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-    float4 *__restrict__ recs, int32_t *__restrict__ status) {
+    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
+    int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
+    float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -212,7 +213,7 @@ struct NextFill {
     float clip_coe;
     int32_t *num_tiles_hit, *lists, *status, *tile_order;
     int2 *prev_box;
-    float4 *recs;
+    RecSets recs;
 };
 
 // optimizer.py::_multi_tensor_adan / _single_tensor_adan (weight_decay 0, no gradient clipping), operation by
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (!ADAN && g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
+               partial_big, acc);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
         begin_binning(g, next.status);
+        float4 *recs = recs_for_binning(next.recs, g == 0);
         // From the rows just written, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
         // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         conics[3 * g + 2] = o.k2;
         next.num_tiles_hit[g] = o.tiles_hit;
         bin_projected(g, o, P.opacity[g], new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip,
-                      next.prev_box, next.lists, next.recs);
+                      next.prev_box, next.lists, recs);
     }
     if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned)
         best.xyz[2 * g] = P.xyz[2 * g];
@@ -438,10 +441,11 @@ __device__ __forceinline__ void quantise_row(const TrainParams &P, const QuantTr
 __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-    float4 *__restrict__ recs, int32_t *__restrict__ status) {
+    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
+    int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
+    float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     const QuantVals v = load_quant(Q);
     QuantRow r;
@@ -691,7 +695,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
+               partial_big, acc);
     float sums[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) sums[k] = 0.f;
@@ -834,10 +839,11 @@ __device__ __forceinline__ void quantise_row_rs(const QuantTrain &Q, const Quant
 __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-    float4 *__restrict__ recs, int32_t *__restrict__ status) {
+    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
+    int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
+    float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     const QuantValsRS v = load_quant_rs(Q);
     QuantRowRS r;
@@ -869,7 +875,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     if (g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, n, prev_box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
+               partial_big, acc);
     float sums[GI2D_QT_RS_SUMS];
 #pragma unroll
     for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = 0.f;
@@ -1044,15 +1051,15 @@ static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w
     if (s->kind == 2)
         hipLaunchKernelGGL(train_project_fill_kernel<kScaleRot>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
     else if (s->kind == 0)
         hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
     else
         hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
                            (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
+                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
 }
 
 
@@ -1126,7 +1133,7 @@ static void train_launch_project_fill_quant(const gi2d_train_state *s, const Fas
     const int n = s->num_points, bs = per_gaussian_block(n);
     hipLaunchKernelGGL(train_project_fill_quant_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P, Q,
                        (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
+                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
 }
 
 static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
@@ -1134,7 +1141,7 @@ static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const 
     const int n = s->num_points, bs = per_gaussian_block(n);
     hipLaunchKernelGGL(train_project_fill_quant_rs_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P,
                        Q, (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, w.recs, s->status);
+                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
 }
 
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
@@ -1269,7 +1276,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     next.num_tiles_hit = s->num_tiles_hit;
     next.lists = w.lists;
     next.prev_box = w.prev_box;
-    next.recs = w.recs;
+    next.recs = rec_sets(w, n);
     next.status = s->status;
     next.tile_order = w.tile_order;
     const int bs = per_gaussian_block(n);
