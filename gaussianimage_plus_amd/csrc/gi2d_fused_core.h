@@ -210,6 +210,9 @@ __device__ __forceinline__ void fused_tile(
     }
     bwd_run_tile<false, false, true>(sm, len, cull, 0, tx0, ty0, dst, scan_incl, sm.scan_w);
     GI2D_TRACE(10);
+    GI2D_TRACE_VALUE(14, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID
+    GI2D_TRACE_VALUE(15, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));  // HW_REG_XCC_ID
+    GI2D_TRACE_VALUE(4, (unsigned long long)L);
     if (MODE == 1 && tid == 0) tile_sse[tile] = (sm.sse_w[0] + sm.sse_w[1]) + (sm.sse_w[2] + sm.sse_w[3]);
     // "No intersection at all" is a global property: see fast_fwd_kernel
     if (tid == 0 && L > 0) status[0] = 1;

@@ -26,10 +26,14 @@ struct TrainParams {
     const float *opacity;  // [N]   (a buffer of ones in the reference models; not optimised)
     const float *bound;    // [3] or [N,3]: additive bound (cholesky_bound / cov bound)
     int bound_stride;      // 0 or 3
+    const int32_t *n_dev;  // live population on the device, or null (gi2d_train_state::num_points_dev)
     // Adam / Adan state: first moment, second moment; Adan only: moment of the gradient difference, previous gradient
     float *m_xyz, *v_xyz, *m_chol, *v_chol, *m_feat, *v_feat;
     float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
 };
+
+// The live population: the host's `n` is an upper bound when the count lives on the device.
+__device__ __forceinline__ int live_n(const TrainParams &P, int n) { return P.n_dev ? min(n, *P.n_dev) : n; }
 
 // Best-model snapshot kept on the device (train.py:133-139 deep-copies the state dict on the host whenever the
 // PSNR improves): best_sse[2] ping-pongs between steps so every workgroup of a launch reads the same value.
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
     int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
     int32_t *__restrict__ status) {
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);
         return;
     }
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     AdamRows rows;
     if (!ADAN && g < n) rows = adam_load_rows(P, g);
@@ -443,6 +449,7 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
     int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
     int32_t *__restrict__ status) {
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
@@ -667,6 +674,7 @@ __global__ __launch_bounds__(256) void train_quant_finish_kernel(int blocks, Tra
 
 // Range of the variance channels of the current parameters (start of a call, after the host touched them)
 __global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainParams P, QuantTrain Q) {
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float sums[14];
 #pragma unroll
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best,
     int32_t *__restrict__ status) {
 #pragma clang fp contract(off)
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
@@ -841,6 +850,7 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
     int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
     int32_t *__restrict__ status) {
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
@@ -870,6 +880,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
 #pragma clang fp contract(off)
+    n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     AdamRows rows;
     if (g < n) rows = adam_load_rows(P, g);
@@ -1008,6 +1019,7 @@ static TrainParams params_of(const gi2d_train_state *s) {
     P.opacity = s->opacity;
     P.bound = s->bound;
     P.bound_stride = s->bound_stride;
+    P.n_dev = s->num_points_dev;
     P.m_xyz = s->m_xyz;
     P.v_xyz = s->v_xyz;
     P.m_chol = s->m_chol;

@@ -99,7 +99,8 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
         raise ValueError("quantisation-aware fitting is wired for the covariance model (train_quantize.py) and the "
                          "rotation-scale model (models/gaussianimage_rs.py:131-163)")
     fitters = [NativeFitter(gt, num_points, kind=kind, lr=lr, seed=seed, eps=eps, optimizer=optimizer,
-                            max_points=max_points if adaptive else None, track_best=adaptive or quantize)
+                            max_points=max_points if adaptive else None, track_best=adaptive or quantize,
+                            device_resident=adaptive)
                for gt in gts]
     streams = [torch.cuda.Stream(device=dev) for _ in fitters] if len(fitters) > 1 else [torch.cuda.current_stream(dev)]
     torch.cuda.synchronize(dev)

@@ -53,7 +53,7 @@ class _TrainState(C.Structure):
         ("optimizer", C.c_int), ("beta3", C.c_float),
         ("d_xyz", C.c_void_p), ("d_chol", C.c_void_p), ("d_feat", C.c_void_p),
         ("pg_xyz", C.c_void_p), ("pg_chol", C.c_void_p), ("pg_feat", C.c_void_p),
-        ("quant", C.c_void_p),
+        ("quant", C.c_void_p), ("num_points_dev", C.c_void_p),
     ]
 
 
@@ -123,12 +123,17 @@ class NativeFitter:
                  betas=None, eps: float = 1e-8, lr_step: int = 20000, lr_gamma: float = 0.5,
                  seed: int = 3047, clip_coe: float = 3.0, radius_clip: float = 1.0,
                  init: Optional[dict] = None, debug_grads: bool = False, max_points: Optional[int] = None,
-                 track_best: bool = False, optimizer: str = "adam"):
+                 track_best: bool = False, optimizer: str = "adam", device_resident: bool = False):
         """optimizer: "adam" (torch.optim.Adam, betas (0.9, 0.999)) or "adan" (the reference's optimizer.py::Adan,
         betas (0.98, 0.92, 0.99) -- what train.py picks for the Cholesky and RS models, with lr 1e-3, eps 1e-15)."""
         assert kind in _KINDS and gt_hwc.is_cuda and gt_hwc.dim() == 3 and gt_hwc.size(2) == 3
         assert optimizer in ("adam", "adan")
+        assert not device_resident or kind == "covariance", "prune / grow are the covariance model's"
         self.optimizer = optimizer
+        # device_resident: the number of live gaussians is a word in HBM that the prune / grow kernels update
+        # (csrc/gi2d_densify.hip); `self.n` is then an UPPER BOUND until sync_population() reads the word back, and
+        # nothing in fit_schedule waits for the device
+        self.device_resident = bool(device_resident)
         if betas is None:
             betas = (0.9, 0.999) if optimizer == "adam" else (0.98, 0.92, 0.99)
         self.lib = _lib.load()
@@ -200,7 +205,13 @@ class NativeFitter:
             bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)),
             1 if optimizer == "adan" else 0, self.betas[2] if optimizer == "adan" else 0.0,
             *[(p(getattr(self, nm)) if optimizer == "adan" else None)
-              for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")], None)
+              for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")], None, None)
+        if self.device_resident:
+            self.n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+            self.dens_counts = i32(2)  # gaussians pruned / added so far (device-side tallies)
+            self.state.num_points_dev = p(self.n_dev)
+            sz = self.lib.gi2d_densify_scratch_bytes(C.byref(self.state), cap)
+            self.dens_scratch = torch.empty(sz, dtype=torch.uint8, device=dev)
         self.quant = None        # _TrainQuant once enable_quantize() ran
         self.opt_start = 0       # iteration at which the optimizer / StepLR of the gaussians was (re)created
         self._state_ref = C.byref(self.state)
@@ -225,10 +236,21 @@ class NativeFitter:
     m_feat = property(lambda self: self._m_feat[:self.n])
     v_feat = property(lambda self: self._v_feat[:self.n])
 
-    def _set_n(self, n: int):
+    def _set_n(self, n: int, exact: bool = True):
+        """New population (`exact`) or, with the count on the device, a new upper bound of it."""
         self.n = int(n)
         self.state.num_points = self.n
+        if self.device_resident and exact:
+            self.n_dev.fill_(self.n)
         self._reset_bins()
+
+    def sync_population(self) -> int:
+        """Read the live count back from the device (the one host wait of the adaptive loop, at its end)."""
+        if self.device_resident:
+            self.n = int(self.n_dev.item())
+            self.state.num_points = self.n
+            self._reset_bins()
+        return self.n
 
     def _reset_bins(self):
         """Rows were renumbered, appended or replaced wholesale (prune / grow / load): the workspace's persistent tile
@@ -410,11 +432,18 @@ class NativeFitter:
             rows.append(self._bound)
         return rows
 
-    def prune_non_definite(self) -> int:
+    def prune_non_definite(self) -> Optional[int]:
         """non_semi_definite_prune (models/gaussianimage_covariance.py:352-370): drop gaussians whose covariance
-        (+ bound) is not positive definite, keeping the order of the others.  Returns the number pruned."""
+        (+ bound) is not positive definite, keeping the order of the others.  Returns the number pruned, or None with
+        the population on the device (gi2d_train_prune: nobody waits to find out)."""
         if self.kind != "covariance":
             return 0  # L L^T is positive semi-definite by construction; the reference never prunes that model
+        if self.device_resident:
+            with torch.cuda.device(self.dev):
+                _lib.call("gi2d_train_prune", self._state_ref, self.dens_scratch.data_ptr(), self.dens_scratch.numel(),
+                          self.dens_counts.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
+            self._reset_bins()  # ids may have been renumbered
+            return None
         n = self.n
         cov = self._chol[:n] + (self._bound[:n] if self.per_point_bound else self._bound)
         valid = positive_definite_mask(cov)
@@ -426,11 +455,25 @@ class NativeFitter:
             self._set_n(keep)
         return to_prune
 
-    def add_sample_positions(self, iteration: int, iterations: int, grow_iter: int, max_points: Optional[int] = None) -> int:
+    def add_sample_positions(self, iteration: int, iterations: int, grow_iter: int,
+                             max_points: Optional[int] = None) -> Optional[int]:
         """train.py:85-118 with densification_postfix: append gaussians where the last render is worst.  Returns the
         number of gaussians added."""
         assert self.kind == "covariance", "growth places gaussians in pixel coordinates (covariance model)"
         max_points = self.cap if max_points is None else min(int(max_points), self.cap)
+        if self.device_resident:
+            # the budget itself (train.py:91-97) is formed on the device from the live count; the host only says whether
+            # this is the step that releases everything, supplies that many uniform numbers and raises its upper bound
+            budget_cap = max_points if iteration == iterations - grow_iter else 1000
+            rows = min(budget_cap, max_points)
+            rand3 = torch.rand(rows, 3, generator=self.rng).pin_memory().to(self.dev, non_blocking=True)
+            with torch.cuda.device(self.dev):
+                _lib.call("gi2d_train_grow", self._state_ref, max_points, budget_cap, rand3.data_ptr(), rows,
+                          self.dens_scratch.data_ptr(), self.dens_scratch.numel(), self.dens_counts[1:].data_ptr(),
+                          torch.cuda.current_stream(self.dev).cuda_stream)
+            self._grow_rand = rand3  # keeps the buffer alive until the kernels have read it
+            self._set_n(min(max_points, self.n + budget_cap), exact=False)
+            return None
         count = growth_budget(iteration, iterations, grow_iter, self.n, max_points)
         if not count:
             return 0
@@ -549,6 +592,7 @@ class NativeFitter:
         """models/gaussianimage_covariance.py:412-443: integer codes of every attribute; gaussians whose covariance
         is not positive definite AFTER quantisation are dropped from the encoding (and from the model)."""
         assert self.quant is not None
+        self.sync_population()
         if self.kind == "scale_rot":
             return self._compress_wo_ec_rs()
         xyq, cq, fq = self.quantizers()
@@ -683,8 +727,14 @@ class NativeFitter:
             if adaptive and adaptive_add and local % grow_iter == 0 and local < total:
                 added = self.add_sample_positions(local, total, grow_iter, max_points)
                 if log:
-                    log(f"iter {local}: added {added} gaussians, now {self.n}")
+                    log(f"iter {local}: growth step, at most {self.n} gaussians now" if added is None else
+                        f"iter {local}: added {added} gaussians, now {self.n}")
             yield local
+        if self.device_resident:
+            self.sync_population()
+            if log:
+                pruned, added = self.dens_counts.tolist()
+                log(f"population on the device: {self.n} gaussians live ({added} added, {pruned} pruned in all)")
 
     def fit_quantize_schedule(self, iterations: int, warmup_iter: int, bits=(12, 10, 6), chunk: Optional[int] = None,
                               log=None, **kw):
@@ -705,6 +755,7 @@ class NativeFitter:
             yield local
         self.load_best()
         self.prune_non_definite()
+        self.sync_population()  # the quantisers are initialised from the live rows
         self.enable_quantize(*bits)
         if log:
             log(f"iter {self.iteration - start + 1}: warm-up finished, quantisation-aware from here ({self.n} gaussians)")
@@ -715,6 +766,7 @@ class NativeFitter:
             left -= step
             yield self.iteration - start
         self.prune_non_definite()
+        self.sync_population()
 
     def fit(self, iterations: int, **kw) -> None:
         """Run fit_schedule to the end (same keyword arguments)."""

@@ -390,6 +390,11 @@ typedef struct gi2d_train_state {
     float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
     /* quantisation-aware iterations (NULL = off): see gi2d_train_quant below */
     const struct gi2d_train_quant *quant;
+    /* device-resident population (NULL = off: num_points is exact): the number of live gaussians as a word in HBM.
+     * When set, num_points is only an UPPER BOUND (launch sizes, workspace layout); every kernel works on the first
+     * min(*num_points_dev, num_points) rows, and gi2d_train_prune / gi2d_train_grow change the count without the host
+     * having to know it. */
+    int32_t *num_points_dev;
 } gi2d_train_state;
 
 /* Quantisation-aware fitting.  Covariance model (kind 1, Adam): GaussianImage_Covariance.
@@ -438,6 +443,28 @@ int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float b
  * gaussians for the next one, so the call issues 2*count + 1 launches instead of 3*count. */
 int gi2d_train_steps(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
                      float eps, int first_step, int count, gi2d_stream_t stream);
+
+/* Population changes of a fit on the device (covariance model; state->num_points_dev required):
+ *   gi2d_train_prune  non_semi_definite_prune (models/gaussianimage_covariance.py:352-382): rows whose covariance +
+ *                     bound is not positive definite are dropped, all per-gaussian arrays of the state (parameters,
+ *                     optimizer moments, opacity, per-gaussian bound) compacted in order; *pruned_total (device,
+ *                     optional) accumulates the number dropped.  Nothing moves when nothing is pruned.
+ *   gi2d_train_grow   add_sample_positions + densification_postfix (train.py:85-118, :307-350 of the model): the
+ *                     k = max(0, min(budget_cap, max_points - live count)) pixels of the last render (out_img) with the
+ *                     largest summed absolute error, in (error descending, pixel index ascending) order, become
+ *                     centres of new gaussians with covariance rand3[r] + (0.5, 0, 0.5), colour 0, opacity 1, zero
+ *                     optimizer moments and the low-pass bound of the new population; non-definite draws are skipped.
+ *                     rand3 f32[rand_rows,3]: uniform numbers (row r belongs to the r-th selected pixel); budget_cap =
+ *                     1000, or max_points at the last growth step of a run (train.py:91-97); *added (device, optional)
+ *                     accumulates the number appended.
+ * Both need gi2d_densify_scratch_bytes(state, max_points) bytes of scratch and only enqueue kernels; afterwards the
+ * caller re-initialises the fast workspace (gi2d_fast_workspace_init: gaussian ids changed) and raises its own upper
+ * bound num_points by budget_cap (clamped to max_points) after a growth. */
+size_t gi2d_densify_scratch_bytes(const gi2d_train_state *state, int max_points);
+int gi2d_train_prune(const gi2d_train_state *state, void *scratch, size_t scratch_bytes, int32_t *pruned_total,
+                     gi2d_stream_t stream);
+int gi2d_train_grow(const gi2d_train_state *state, int max_points, int budget_cap, const float *rand3, int rand_rows,
+                    void *scratch, size_t scratch_bytes, int32_t *added, gi2d_stream_t stream);
 
 /* ------------------------------------------------------------------ quantisation-aware front end
  * the quantisers train_quantize.py puts in front of the projection after its warm-up

@@ -75,7 +75,7 @@ def _reference_quantize_events(iterations, warmup_iter, prune_iter, grow_iter, n
 
 class _ScheduleProbe:
     """The host logic of NativeFitter.fit_schedule / fit_quantize_schedule with the device calls replaced by a log."""
-    kind, track_best, cap = "covariance", True, 10 ** 9
+    kind, track_best, cap, device_resident = "covariance", True, 10 ** 9, False
 
     def __init__(self, n0):
         from gaussianimage_plus_amd.trainer import NativeFitter
@@ -99,6 +99,9 @@ class _ScheduleProbe:
 
     def load_best(self):
         pass
+
+    def sync_population(self):
+        return self.n
 
     def enable_quantize(self, *bits):
         self.events.append((self.iteration + 1, "switch", self.n))

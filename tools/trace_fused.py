@@ -44,3 +44,25 @@ for i, nm in enumerate(names):
 late = t[:, 0] > 3.0
 print(f"workgroups starting later than 3 us: {int(late.sum())}")
 
+
+# placement: which workgroups shared a CU, and does the CU's total tile population explain who finishes last?
+hw, xcc, pop = raw[:, 14], raw[:, 15] & 0xf, raw[:, 4].astype(np.float64)
+cu_key = (xcc << 16) | (hw & 0xff00)  # XCC, SE/SH/CU fields of HW_ID
+end = t[:, -1]
+keys, inv = np.unique(cu_key, return_inverse=True)
+per_cu_n = np.bincount(inv)
+per_cu_pop = np.bincount(inv, weights=pop)
+per_cu_end = np.array([end[inv == i].max() for i in range(len(keys))])
+per_cu_mean_end = np.array([end[inv == i].mean() for i in range(len(keys))])
+print(f"distinct CU keys: {len(keys)}, workgroups per CU min/max {per_cu_n.min()}/{per_cu_n.max()}")
+print(f"tile population: mean {pop.mean():.1f} max {pop.max()}; per-CU sum mean {per_cu_pop.mean():.0f} min {per_cu_pop.min():.0f} max {per_cu_pop.max():.0f}")
+print(f"CU finish time: min {per_cu_end.min():.1f} p50 {np.median(per_cu_end):.1f} max {per_cu_end.max():.1f}")
+print(f"corr(CU population sum, CU finish time) = {np.corrcoef(per_cu_pop, per_cu_end)[0, 1]:.2f};  "
+      f"corr(tile population, workgroup finish) = {np.corrcoef(pop, end)[0, 1]:.2f}")
+order = np.argsort(per_cu_end)
+print("slowest CUs: finish", np.round(per_cu_end[order[-6:]], 1), "population", per_cu_pop[order[-6:]], "n", per_cu_n[order[-6:]], "xcc", (keys[order[-6:]] >> 16))
+print("fastest CUs: finish", np.round(per_cu_end[order[:6]], 1), "population", per_cu_pop[order[:6]], "n", per_cu_n[order[:6]], "xcc", (keys[order[:6]] >> 16))
+for x in range(8):
+    m = (keys >> 16) == x
+    if m.any():
+        print(f"  xcc {x}: CUs {int(m.sum())}, finish mean {per_cu_end[m].mean():.1f} max {per_cu_end[m].max():.1f}, start mean {t[:, 0][np.isin(inv, np.nonzero(m)[0])].mean():.2f}")
