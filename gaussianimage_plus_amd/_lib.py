@@ -55,8 +55,8 @@ SIGNATURES.update({
     "gi2d_timer_create": [_p], "gi2d_timer_destroy": [_p], "gi2d_timer_arm": [_p], "gi2d_timer_elapsed_us": [_p, _p],
     # struct gi2d_train_state* (gaussianimage_plus_amd/trainer.py::_TrainState)
     "gi2d_train_render": [_p, _p],
-    "gi2d_train_step": [_p, _p, _f, _f, _f, _i, _p],
-    "gi2d_train_steps": [_p, _p, _f, _f, _f, _i, _i, _p],
+    "gi2d_train_step": [_p, _p, C.c_double, C.c_double, _f, _i, _p],
+    "gi2d_train_steps": [_p, _p, C.c_double, C.c_double, _f, _i, _i, _p],
     "gi2d_train_prune": [_p, _p, _sz, _p, _p],
     "gi2d_train_grow": [_p, _i, _i, _p, _i, _p, _sz, _p, _p],
     # quantisers: struct gi2d_quant_spec* (gaussianimage_plus_amd/quantize.py::_QuantSpec)

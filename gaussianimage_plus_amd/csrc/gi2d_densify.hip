@@ -187,21 +187,27 @@ __global__ __launch_bounds__(1024) void grow_select_kernel(int npix, const uint3
         __syncthreads();
     }
     const unsigned thr = prefix;  // the k-th largest key; `want` of the keys equal to it are taken, lowest index first
-    int above_before = 0, equal_before = 0;  // totals of the blocks already swept
-    for (int base = 0; base < npix; base += 1024) {
-        const int p = base + tid;
-        const unsigned v = p < npix ? key[p] : 0u;
-        const int above = (p < npix && v > thr) ? 1 : 0, equal = (p < npix && v == thr) ? 1 : 0;
-        int t_above, t_equal;
-        const int a_before = above_before + block_exclusive_scan(above, wsum, t_above);
-        const int e_before = equal_before + block_exclusive_scan(equal, wsum, t_equal);
+    // every lane owns a contiguous run of pixels: count, one block scan of the counts, then write in index order
+    const int chunk = (npix + 1023) / 1024, p0 = tid * chunk, p1 = min(npix, p0 + chunk);
+    int above = 0, equal = 0;
+    for (int p = p0; p < p1; ++p) {
+        const unsigned v = key[p];
+        above += v > thr ? 1 : 0;
+        equal += v == thr ? 1 : 0;
+    }
+    int t_above, t_equal;
+    int a_before = block_exclusive_scan(above, wsum, t_above);
+    int e_before = block_exclusive_scan(equal, wsum, t_equal);
+    for (int p = p0; p < p1; ++p) {
+        const unsigned v = key[p];
         // position = everything selected in front of this pixel, in index order
-        if (above)
+        if (v > thr) {
             sel[a_before + min(e_before, want)] = p;
-        else if (equal && e_before < want)
-            sel[a_before + e_before] = p;
-        above_before += t_above;
-        equal_before += t_equal;
+            ++a_before;
+        } else if (v == thr) {
+            if (e_before < want) sel[a_before + e_before] = p;
+            ++e_before;
+        }
     }
 }
 

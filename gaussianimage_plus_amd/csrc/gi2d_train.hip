@@ -1189,7 +1189,7 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
 // learning rates of the xyz / cholesky / colour groups (constant over the call) and the 1-based Adam step count of
 // the first iteration.  Launches: project+fill once, then per iteration the tile pass and the update kernel, which
 // also projects and bins the updated gaussians for the following iteration (all but the last) -- 2*count + 1.
-int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps,
+int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, double beta2, float eps,
                      int first_step, int count, gi2d_stream_t st_) {
     int tx, ty;
     int rc = train_check(s, tx, ty);
@@ -1339,7 +1339,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const float *lr, float beta1, fl
     return check_launch("train steps");
 }
 
-int gi2d_train_step(const gi2d_train_state *s, const float *lr, float beta1, float beta2, float eps, int step,
+int gi2d_train_step(const gi2d_train_state *s, const double *lr, double beta1, double beta2, float eps, int step,
                     gi2d_stream_t st) {
     return gi2d_train_steps(s, lr, beta1, beta2, eps, step, 1, st);
 }

@@ -50,7 +50,7 @@ class _TrainState(C.Structure):
         ("dbg_grads", C.c_void_p),
         ("best_xyz", C.c_void_p), ("best_chol", C.c_void_p), ("best_feat", C.c_void_p), ("best_bound", C.c_void_p),
         ("best_sse", C.c_void_p), ("best_info", C.c_void_p),
-        ("optimizer", C.c_int), ("beta3", C.c_float),
+        ("optimizer", C.c_int), ("pad1", C.c_int), ("beta3", C.c_double),
         ("d_xyz", C.c_void_p), ("d_chol", C.c_void_p), ("d_feat", C.c_void_p),
         ("pg_xyz", C.c_void_p), ("pg_chol", C.c_void_p), ("pg_feat", C.c_void_p),
         ("quant", C.c_void_p), ("num_points_dev", C.c_void_p),
@@ -64,7 +64,7 @@ class _TrainQuant(C.Structure):
         ("qparams", C.c_void_p), ("qm", C.c_void_p), ("qv", C.c_void_p), ("range", C.c_void_p),
         ("qfeat", C.c_void_p), ("partial", C.c_void_p), ("defer", C.c_void_p),
         ("best_qparams", C.c_void_p), ("dbg_qgrads", C.c_void_p),
-        ("lr", C.c_float * 3), ("eps", C.c_float * 3), ("beta1", C.c_float), ("beta2", C.c_float),
+        ("lr", C.c_double * 3), ("eps", C.c_float * 3), ("pad1", C.c_int), ("beta1", C.c_double), ("beta2", C.c_double),
         ("first_step", C.c_int), ("rot_bits", C.c_int),
     ]
 
@@ -203,7 +203,7 @@ class NativeFitter:
             bp(getattr(self, "best_xyz", None)), bp(getattr(self, "best_chol", None)),
             bp(getattr(self, "best_feat", None)), bp(getattr(self, "best_bound", None)),
             bp(getattr(self, "best_sse", None)), bp(getattr(self, "best_info", None)),
-            1 if optimizer == "adan" else 0, self.betas[2] if optimizer == "adan" else 0.0,
+            1 if optimizer == "adan" else 0, 0, self.betas[2] if optimizer == "adan" else 0.0,
             *[(p(getattr(self, nm)) if optimizer == "adan" else None)
               for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")], None, None)
         if self.device_resident:
@@ -215,9 +215,9 @@ class NativeFitter:
         self.quant = None        # _TrainQuant once enable_quantize() ran
         self.opt_start = 0       # iteration at which the optimizer / StepLR of the gaussians was (re)created
         self._state_ref = C.byref(self.state)
-        self._lr3 = (C.c_float * 3)()
+        self._lr3 = (C.c_double * 3)()
         self._steps_fn = self.lib.gi2d_train_steps
-        self._steps_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+        self._steps_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_float, C.c_int, C.c_int, C.c_void_p]
         self._steps_fn.restype = C.c_int
         self._render_fn = self.lib.gi2d_train_render
         self._render_fn.argtypes = [C.c_void_p, C.c_void_p]

@@ -386,7 +386,9 @@ typedef struct gi2d_train_state {
      * with beta3, d_* = exp_avg_diff, pg_* = previous gradient (the reference stores its negative), same shapes
      * as the parameters; weight decay 0, no gradient-norm clipping. */
     int optimizer;
-    float beta3;
+    int pad1;
+    double beta3; /* betas and learning rates are doubles, like the Python floats torch's optimizers take: 1 - beta and
+                     lr / (1 - beta^t) are formed in double and only then rounded to the fp32 the kernels use */
     float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
     /* quantisation-aware iterations (NULL = off): see gi2d_train_quant below */
     const struct gi2d_train_quant *quant;
@@ -430,18 +432,20 @@ typedef struct gi2d_train_quant {
     float *qparams, *qm, *qv, *range, *qfeat, *partial;
     int32_t *defer;
     float *best_qparams, *dbg_qgrads;
-    float lr[3], eps[3];
-    float beta1, beta2;
+    double lr[3];
+    float eps[3];
+    int pad1;
+    double beta1, beta2;
     int first_step;
     int rot_bits; /* kind 2 only: bit depth of the SIGNED rotation quantiser (models/gaussianimage_rs.py:143) */
 } gi2d_train_quant;
 int gi2d_train_render(const gi2d_train_state *state, gi2d_stream_t stream);
-int gi2d_train_step(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
+int gi2d_train_step(const gi2d_train_state *state, const double *lr_host, double beta1, double beta2,
                     float eps, int step, gi2d_stream_t stream);
 /* `count` iterations with constant learning rates in one call (Adam steps first_step ...): the
  * update kernel of every iteration but the last also activates, projects and bins the updated
  * gaussians for the next one, so the call issues 2*count + 1 launches instead of 3*count. */
-int gi2d_train_steps(const gi2d_train_state *state, const float *lr_host, float beta1, float beta2,
+int gi2d_train_steps(const gi2d_train_state *state, const double *lr_host, double beta1, double beta2,
                      float eps, int first_step, int count, gi2d_stream_t stream);
 
 /* Population changes of a fit on the device (covariance model; state->num_points_dev required):

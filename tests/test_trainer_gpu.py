@@ -299,3 +299,64 @@ def test_concurrent_images_threaded_equals_round_robin():
     for ra, rb in zip(a, b):
         assert ra["mse"] == rb["mse"] and ra["num_gaussians"] == rb["num_gaussians"]  # bitwise: same kernels, same order per image
         assert ra["psnr"] > 20
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "adan"])
+def test_one_fused_update_step_equals_the_torch_optimizer_on_the_same_gradient(optimizer):
+    """The optimizer arithmetic of the update kernel in isolation: take the gradient the kernel itself reports
+    (dbg_grads) and the state it started from, apply torch.optim.Adam / the Adan statement pinned to the reference
+    (tests/helpers_adan.py) to exactly those numbers, and compare the updated parameters and moments -- at step 1 and
+    at a later step with non-zero moments.  Same operations in fp32 on both sides: 1e-6 relative."""
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    from helpers_adan import AdanRef
+    n, h, w, lr = 4000, 96, 144, 1e-2
+    gt = synthetic_image(h, w, 5).to(DEV)
+    eps = 1e-15 if optimizer == "adan" else 1e-8
+    g = torch.Generator().manual_seed(13)
+    init = {"xyz": torch.rand(n, 2, generator=g) * torch.tensor([float(w), float(h)]),
+            "chol": torch.rand(n, 3, generator=g) * torch.tensor([1.0, 0.3, 1.0]),
+            "feat": torch.rand(n, 3, generator=g) * 0.3}  # non-zero colours: every parameter group has a gradient
+    fit = NativeFitter(gt, n, kind="covariance", lr=lr, eps=eps, seed=13, debug_grads=True, optimizer=optimizer,
+                       init=init)
+    names = (("xyz", 0, 2), ("chol", 2, 5), ("feat", 5, 8))
+    prev_grad = None
+    for step in (1, 2, 3, 7):
+        fit.train(step - fit.iteration - 1)                      # up to the step under test
+        if step > 1:
+            prev_grad = fit.dbg_grads[:n].clone()                # Adan's previous gradient = the last step's
+        before = {nm: getattr(fit, nm).clone() for nm, _, _ in names}
+        m0 = {nm: getattr(fit, "m_" + nm).clone() for nm, _, _ in names}
+        v0 = {nm: getattr(fit, "v_" + nm).clone() for nm, _, _ in names}
+        d0 = {nm: getattr(fit, "_d_" + nm)[:n].clone() for nm, _, _ in names} if optimizer == "adan" else None
+        fit.train(1)
+        torch.cuda.synchronize()
+        grads = fit.dbg_grads[:n].clone()
+        params = [before[nm].clone().requires_grad_(True) for nm, _, _ in names]
+        for p, (nm, a, b) in zip(params, names):
+            p.grad = grads[:, a:b].contiguous()
+        if optimizer == "adam":
+            opt = torch.optim.Adam(params, lr=lr, eps=eps)
+            for p, (nm, _, _) in zip(params, names):
+                opt.state[p] = {"step": torch.tensor(float(step - 1)), "exp_avg": m0[nm].clone(),
+                                "exp_avg_sq": v0[nm].clone()}
+            opt.step()
+            got_m = {nm: opt.state[p]["exp_avg"] for p, (nm, _, _) in zip(params, names)}
+            got_v = {nm: opt.state[p]["exp_avg_sq"] for p, (nm, _, _) in zip(params, names)}
+        else:
+            opt = AdanRef(params, lr, eps=eps)
+            opt.step_count = step - 1
+            for s, (nm, a, b) in zip(opt.state, names):
+                s["m"], s["n"], s["d"] = m0[nm].clone(), v0[nm].clone(), d0[nm].clone()
+                s["prev"] = None if prev_grad is None else prev_grad[:, a:b].contiguous()
+            opt.step()
+            got_m = {nm: s["m"] for s, (nm, _, _) in zip(opt.state, names)}
+            got_v = {nm: s["n"] for s, (nm, _, _) in zip(opt.state, names)}
+        for p, (nm, _, _) in zip(params, names):
+            moved = (p.detach() - before[nm]).abs()
+            assert moved.max().item() > 0.1 * lr, (step, nm)      # the step did something
+            err = (getattr(fit, nm) - p.detach()).abs()
+            # the update itself (a few lr at most) is reproduced to 1e-6 of its size, the parameter to its last three ulps
+            assert (err <= 1e-6 * moved + 4e-7 * p.detach().abs() + 1e-12).all(), (step, nm, err.max().item())
+            for got, ref, what in ((getattr(fit, "m_" + nm), got_m[nm], "m"), (getattr(fit, "v_" + nm), got_v[nm], "v")):
+                assert torch.allclose(got, ref, rtol=1e-6, atol=1e-30), (step, nm, what)
