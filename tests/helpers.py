@@ -53,3 +53,25 @@ def check_close(name, got, want, scale, mask=None, rtol=RTOL, atol=1e-9, max_bad
     assert nbad <= max_bad_frac * total, (
         f"{name}: {nbad}/{total} elements beyond rtol={rtol} (worst err/tol = {worst:.3g})")
     return worst
+
+
+def rs_term_magnitudes(conics, v_conic, v_xy, scales, rot, nm):
+    """Sum of the absolute terms each scale-rot gradient entry is made of (float64)."""
+    conic, vc = np.asarray(conics, np.float64), np.asarray(v_conic, np.float64)
+    X = np.abs(np.stack([np.stack([conic[:, 0], conic[:, 1]], 1), np.stack([conic[:, 1], conic[:, 2]], 1)], 1))
+    G = np.abs(np.stack([np.stack([vc[:, 0], vc[:, 1]], 1), np.stack([vc[:, 1], vc[:, 2]], 1)], 1))
+    S = X @ G @ X
+    gm = np.stack([S[:, 0, 0], S[:, 0, 1] + S[:, 1, 0], S[:, 1, 1]], 1)
+    if nm == "v_cov2d":
+        return gm + 1e-30
+    if nm == "v_mean2d":
+        return np.abs(np.asarray(v_xy, np.float64)) + 1e-30
+    s, r = np.asarray(scales, np.float64), np.asarray(rot, np.float64).reshape(-1)
+    c, si = np.abs(np.cos(r)), np.abs(np.sin(r))
+    sx, sy = np.abs(s[:, 0]), np.abs(s[:, 1])
+    # |d Sigma / d sx| <= 2 sx (c^2, c s, s^2); |d Sigma / d sy| <= 2 sy (s^2, c s, c^2); |d Sigma / d theta| <= (sx^2 + sy^2) (2 c s, 1, 2 c s)
+    if nm == "v_scale":
+        return np.stack([2 * sx * (gm[:, 0] * c * c + 2 * gm[:, 1] * c * si + gm[:, 2] * si * si),
+                         2 * sy * (gm[:, 0] * si * si + 2 * gm[:, 1] * c * si + gm[:, 2] * c * c)], 1) + 1e-30
+    q = sx * sx + sy * sy
+    return (q * (gm[:, 0] * 2 * c * si + 2 * gm[:, 1] + gm[:, 2] * 2 * c * si))[:, None] + 1e-30

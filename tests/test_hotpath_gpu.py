@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_close, synth_cholesky, synth_gt
+from helpers import check_close, rs_term_magnitudes, synth_cholesky, synth_gt
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -185,7 +185,7 @@ def test_scale_rot_kind_at_config5_size(oracle):
     print(f"scale-rot N={n}: radii / num_tiles_hit differ on {int((~same).sum())} gaussians (device sin/cos vs libm)")
     assert int((~same).sum()) <= n // 1000
     cs = np.abs(po[3][same]).max(axis=-1, keepdims=True)
-    check_close("rs conics", d_conics[same], po[3][same], cs, rtol=4e-5)
+    check_close("rs conics", d_conics[same], po[3][same], cs, rtol=1e-5)
     m, cum = oracle.compute_cumulative_intersects(d_nth)
     _, _, so, go, bins = oracle.bin_and_sort_gaussians(n, m, d_xys, np.zeros(n, np.float32), d_radii, cum, tb, 1.0)
     out_o, fT, fidx, amb, absimg = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, d_xys, d_conics,
@@ -193,9 +193,11 @@ def test_scale_rot_kind_at_config5_size(oracle):
     check_close("rs out_img", res[0][0].cpu().numpy(), out_o, absimg, mask=np.repeat((amb == 0)[..., None], 3, -1))
     pb = oracle.project_gaussians_2d_scale_rot_backward(n, mean_px, scales, rot, h, w, d_radii, d_conics,
                                                         res[0][9].cpu().numpy(), None, res[0][10].cpu().numpy())
-    for got, want, nm in ((res[0][2], pb[2], "v_scale"), (res[0][3], pb[3], "v_rot"), (res[0][1], pb[1], "v_mean")):
-        sc = np.abs(want).max(axis=-1, keepdims=True) + 1e-30
-        check_close("rs " + nm, got.cpu().numpy().reshape(want.shape), want, sc, rtol=1e-4, max_bad_frac=1e-4)
+    v_xy_d, v_conic_d = res[0][9].cpu().numpy(), res[0][10].cpu().numpy()
+    for got, want, nm in ((res[0][2], pb[2], "v_scale"), (res[0][3], pb[3], "v_rot"), (res[0][1], pb[1], "v_mean2d")):
+        # 1e-5 of the size of the terms each entry sums (they cancel, v_rot most of all; device sin / cos vs libm's)
+        sc = rs_term_magnitudes(d_conics, v_conic_d, v_xy_d, scales, rot, nm)
+        check_close("rs " + nm, got.cpu().numpy().reshape(want.shape), want, sc, rtol=1e-5)
 
 
 def test_2k_image_config4_against_the_oracle(oracle):

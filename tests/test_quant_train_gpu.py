@@ -93,7 +93,8 @@ def test_quantised_iteration_matches_torch_loop():
     ext_t = torch.from_numpy(ext).to(DEV)
     scale = g_ref.abs().max(dim=0, keepdim=True).values + 1e-20
     err = (((g_native - g_ref).abs() / scale)[~ext_t]).max().item()
-    assert err < 3e-4, f"first-step gradient mismatch {err}"
+    print(f"first-step gradient error, relative to the column maximum: {err:.3e}")
+    assert err < 1e-5, f"first-step gradient mismatch {err}"  # measured: 0 .. 4e-6 (sin / cos of the RS model)
     assert ext.sum() >= 2
     # the variances at the extremes of the log range carry whole-array sums
     for (r, c) in np.argwhere(ext):
@@ -231,7 +232,8 @@ def test_quantised_iteration_small_and_large_populations(n, h, w):
     ext[:, 2:5:2] = (L == L.min()) | (L == L.max())
     scale = g_ref.abs().max(dim=0, keepdim=True).values + 1e-20
     err = (((g_native - g_ref).abs() / scale)[~torch.from_numpy(ext).to(DEV)]).max().item()
-    assert err < 3e-4, err
+    print(f"first-step gradient error, relative to the column maximum: {err:.3e}")
+    assert err < 1e-5, err
     q_native, q_ref = fit.dbg_qgrads[:12], want[4]["q"]
     assert ((q_native - q_ref).abs() / (q_ref.abs() + 1e-3 * q_ref.abs().max())).max().item() < 2e-2
     fit.train(1)

@@ -78,7 +78,7 @@ def _native_params(fit):
     return torch.cat([fit.xyz, fit.chol, fit.feat], 1)
 
 
-def _compare(fit, gt, n, iters=2, grad_tol=3e-4):
+def _compare(fit, gt, n, iters=2, grad_tol=1e-5):
     lr = fit.current_lr()
     qp0 = fit.qparams.clone()
     want_p, want_q, first, losses = _torch_rs_quant_loop(fit, gt, iters, lr)

@@ -72,7 +72,8 @@ def test_native_iteration_matches_torch_adam_loop(kind):
     # first-iteration gradients w.r.t. the raw parameters (through tanh / +bound / projection / rasterizer / L2)
     scale = want[3].abs().max(dim=0, keepdim=True).values + 1e-20
     err = ((g_native - want[3]).abs() / scale).max().item()
-    assert err < 2e-4, f"first-step gradient mismatch {err}"
+    print(f"first-step gradient error, relative to the column maximum: {err:.3e}")
+    assert err < 1e-5, f"first-step gradient mismatch {err}"  # measured: 0 .. 4e-6 (sin / cos of the RS model)
     fit.train(iters - 1)
     torch.cuda.synchronize()
     for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "chol"), (fit.feat, want[2], "feat")):
@@ -248,7 +249,8 @@ def test_native_scale_rot_model_matches_autograd_loop():
     want = _torch_loop("scale_rot", gt, init, bound, iters, lr)
     scale = want[3].abs().max(dim=0, keepdim=True).values + 1e-20
     err = ((g_native - want[3]).abs() / scale).max().item()
-    assert err < 3e-4, f"first-step gradient mismatch {err}"
+    print(f"first-step gradient error, relative to the column maximum: {err:.3e}")
+    assert err < 1e-5, f"first-step gradient mismatch {err}"  # measured: 0 .. 4e-6 (sin / cos of the RS model)
     fit.train(iters - 1)
     for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "chol"), (fit.feat, want[2], "feat")):
         d = (got - ref).abs()
