@@ -58,16 +58,36 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64u - lane));
 }
 
-// Inclusive scan of one int per lane across the 64-lane wave.
+// Inclusive scan of one int per lane across the 64-lane wave: six DPP adds (row shifts 1, 2, 4, 8 inside the rows of
+// 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into the upper half) -- register to register,
+// where the shuffle form (ds_bpermute) pays six dependent LDS round trips.
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+#define GI2D_DPP_ADD(ctrl, row_mask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, row_mask, 0xf, false)
+    GI2D_DPP_ADD(0x111, 0xf);  // row_shr:1
+    GI2D_DPP_ADD(0x112, 0xf);  // row_shr:2
+    GI2D_DPP_ADD(0x114, 0xf);  // row_shr:4
+    GI2D_DPP_ADD(0x118, 0xf);  // row_shr:8
+    GI2D_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+    GI2D_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+#undef GI2D_DPP_ADD
     return v;
 }
+// Sum of one float per lane over the wave, the same value in every lane (fixed order: the scan's).
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    int v = __float_as_int(x);
+#define GI2D_DPP_FADD(ctrl, row_mask) \
+    v = __float_as_int(__int_as_float(v) + __int_as_float(__builtin_amdgcn_update_dpp(0, v, ctrl, row_mask, 0xf, false)))
+    GI2D_DPP_FADD(0x111, 0xf);
+    GI2D_DPP_FADD(0x112, 0xf);
+    GI2D_DPP_FADD(0x114, 0xf);
+    GI2D_DPP_FADD(0x118, 0xf);
+    GI2D_DPP_FADD(0x142, 0xa);
+    GI2D_DPP_FADD(0x143, 0xc);
+#undef GI2D_DPP_FADD
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+// value of `v` in lane `lane` (wave-uniform index): a scalar read, no LDS
+__device__ __forceinline__ int wave_read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 // ---- pair evaluation shared (bitwise) by the forward and backward rasterizers -------------
 // The conic is pre-scaled by log2(e) so the exponential is a bare v_exp_f32:

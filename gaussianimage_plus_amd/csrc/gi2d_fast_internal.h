@@ -343,11 +343,11 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
     // 16..31 the appended ones
     const int cnt = lane < 32 ? grp[lane] : 0;
     const int incl = wave_inclusive_scan(cnt);
-    const int asc_total = __shfl(incl, 15, 64), len = __shfl(incl, 31, 64);
+    const int len = wave_read_lane(incl, 31);
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     int before[GI2D_FAST_EPT];
 #pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) before[u] = __shfl(incl - cnt, wv + 4 * u, 64);
-    (void)asc_total;
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) before[u] = wave_read_lane(incl - cnt, wv_u + 4 * u);
     if (tid == 0) {
         // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
         if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {

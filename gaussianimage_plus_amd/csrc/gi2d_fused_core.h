@@ -185,8 +185,7 @@ __device__ __forceinline__ void fused_tile(
             }
             v0 = v[0], v1 = v[1], v2 = v[2];
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) sse += __shfl_xor(sse, d, 64);
+        sse = wave_sum_dpp(sse);
         if (lane == 0) sm.sse_w[wv] = sse;
     }
     // the backward's item scan starts here, ahead of the barrier that is needed anyway
