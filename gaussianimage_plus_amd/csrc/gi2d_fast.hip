@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const float4 *recs = recs_for_tile_pass(rs, blockIdx.x == 0 && tid == 0);
     if (tid == 0) fwd_stage_dummy(sm.f);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
-    const int L = tile_list_head(
+    const int L = tile_list_head<false>(
         ids, grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
             const GaussRec &r = br.r;
             const int slot = partial_slot(g, br.box, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);

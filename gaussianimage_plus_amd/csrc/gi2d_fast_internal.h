@@ -275,7 +275,12 @@ __device__ __forceinline__ int partial_slot(int g, int2 box, int tx, int ty, int
 // are read before the count is known; slots past the count hold stale ids that are ignored), the records the second.
 // `ids`: GI2D_FAST_C ints of LDS, `grp`: 32 ints of LDS; both are free again after the caller's next workgroup
 // barrier.  Returns the number of survivors.
-template <class Emit>
+// OPTIMISTIC: a survivor of the ascending part is handed to `emit` at rank = its position BEFORE the workgroup
+// barrier -- right when its record arrives -- which is where it ends up whenever nothing was dropped or appended; only
+// otherwise (tile-uniform, known after the barrier) everything is emitted again at its true rank.  `emit` must then be idempotent LDS staging for rank < GI2D_TILE_LIST_CAP (entries past the cap are only
+// ever emitted once, at the end).  With OPTIMISTIC the staging is complete and visible to the whole workgroup on
+// return (the usual case costs ONE barrier in all); otherwise the caller's barrier after the call closes it.
+template <bool OPTIMISTIC, class Emit>
 __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty,
                                               const float4 *__restrict__ recs, int32_t *__restrict__ lists,
                                               int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Emit emit) {
@@ -337,6 +342,7 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
             grp[16 + wv + 4 * u] = 0;
         }
     }
+    if (OPTIMISTIC && keep[0] && tid < sorted) emit(tid, my_id[0], r0);  // tid < 256 = GI2D_TILE_LIST_CAP
     __syncthreads();
     GI2D_HEAD_TRACE(13);
     // one wave-level scan gives every lane what it needs: lane i < 16 holds group i's ascending survivors, lanes
@@ -348,6 +354,7 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
     int before[GI2D_FAST_EPT];
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) before[u] = wave_read_lane(incl - cnt, wv_u + 4 * u);
+    const bool clean = len == count && sorted == count;  // nothing dropped, nothing appended: every rank == position
     if (tid == 0) {
         // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
         if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {
@@ -356,6 +363,13 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         }
         tile_bins[tile] = make_int2(list_base(tile), list_base(tile) + len);
     }
+    if (OPTIMISTIC && clean) {
+#pragma unroll
+        for (int u = 1; u < GI2D_FAST_EPT; ++u)  // entries past the cap: emitted once, here (rank == position)
+            if (u < rounds && keep[u]) emit(tid + 256 * u, my_id[u], load_record(recs, my_id[u]));
+        return len;
+    }
+    // (the optimistic staging was complete at the barrier above: what follows overwrites it in program order)
 #pragma unroll
     for (int u = 0; u < GI2D_FAST_EPT; ++u) {
         if (u >= rounds || !keep[u]) continue;
@@ -370,6 +384,7 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         if (!(e < sorted && rank == e)) row[GI2D_FAST_HDR + rank] = g;
         emit(rank, g, u == 0 ? r0 : load_record(recs, g));
     }
+    if (OPTIMISTIC) __syncthreads();  // OPTIMISTIC callers need no barrier of their own after the call
     return len;
 }
 

@@ -118,7 +118,7 @@ __device__ __forceinline__ void fused_tile(
     }
     GI2D_TRACE(1);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
-    const int L = tile_list_head(
+    const int L = tile_list_head<true>(
         sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
             const GaussRec &r = br.r;
             const int slot = partial_slot(g, br.box, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
@@ -140,7 +140,8 @@ __device__ __forceinline__ void fused_tile(
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 1 /* development aid: instruction / time budget of the phases */
     if (L >= 0) return;
 #endif
-    __syncthreads();  // records staged; every lane has read sm.ids: the overlay may now hold the forward's buffers
+    // records staged and every lane done with sm.ids (tile_list_head<true> returns behind its last barrier): the overlay
+    // may now hold the forward's buffers
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     GI2D_TRACE(3);
 

@@ -83,7 +83,9 @@ __device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, 
 // phase, so the two addresses of one read never share a bank.  Every forward kernel (plain, fast, single-pass)
 // runs this one routine: identical pixels bit for bit.
 #define GI2D_FWD_DUMMY GI2D_TILE_LIST_CAP /* index of a never-contributing entry used as list padding */
+#ifndef GI2D_FWD_CHUNK
 #define GI2D_FWD_CHUNK 32                 /* list entries per half copied per trip */
+#endif
 #define GI2D_FWD_HALF (GI2D_FWD_CHUNK / 2 * 20 + 32) /* floats from the left buffer to the right one (incl. bank shift) */
 #define GI2D_FWD_PAIRBUF (GI2D_FWD_HALF + GI2D_FWD_CHUNK / 2 * 20) /* floats per wave */
 #define GI2D_FWD_LISTLEN (GI2D_TILE_LIST_CAP + 8)

@@ -5,7 +5,7 @@
     <round>_bench_plain.json          the JSON line of a plain run (no profiler) in the same gpurun call
     <round>_pmc_summary.txt           mean counter value per kernel, one line per kernel and --pmc pass
     traffic.json                      HBM bytes per launch per kernel (read by bench.py for roofline.traffic)
-usage: python tools/make_profiles.py round1"""
+usage: python tools/make_profiles.py round2"""
 import collections
 import csv
 import glob
@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "rp")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
 
 
 def short(name):
