@@ -385,7 +385,10 @@ class HotPath:
             t_avg = f_avg + b_avg
             extra = {"fwd_kernel_us": f_avg, "bwd_tile_kernel_us": b_avg}
         extra.update({"algorithmic_bytes": pair_bytes, "achieved_GBps": pair_bytes / (t_avg * 1e-6) / 1e9,
-                      "pixel_gaussian_pairs_per_s": 2 * 256.0 * m / (t_avg * 1e-6),
+                      # every staged (tile, gaussian) entry against every pixel of its tile, forward + backward: the
+                      # NOMINAL pair count of the reference's loops (forward.cu:650, backward.cu:1258); the kernels
+                      # skip most of these pairs through their cull boxes, so this is not an evaluated-work figure
+                      "nominal_pairs_per_s": 2 * 256.0 * m / (t_avg * 1e-6),
                       "note": "HIP start/stop events of the rasterizer kernel(s) inside the timed loop"})
         return extra
 
