@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  The product package never imports this module.
 
-Parity status: "parity unpinned" by the reference's own tests (SURVEY.md section 8c);
+Parity status: pinned by outputs of the reference's own Python helpers and by float64 autograd
+(tests/golden/ref_vectors.npz), not by a fixture of the reference's tests (it has none for this path);
 see the header of gi2d_oracle.c.
 """
 from __future__ import annotations

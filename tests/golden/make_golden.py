@@ -6,15 +6,16 @@ What it does
      a 6-line `jaxtyping` stand-in is needed because that annotation-only package is absent) and
        a. cross-checks the oracle's helpers against the reference's own CPU code in
           gsplat/gsplat/_torch_impl.py (compute_cov2d_bounds :197, get_tile_bbox :236,
-          map_gaussian_to_intersects :297, get_tile_bin_edges :328)        -> ref_crosscheck.json
+          map_gaussian_to_intersects :297, get_tile_bin_edges :328)        -> printed only; the
+          reference's OUTPUT ARRAYS are committed by make_ref_vectors.py  -> ref_vectors.npz
        b. drives the reference's autograd Functions (_ProjectGaussians2d*, _RasterizeGaussiansSum)
           on CPU with `gsplat.cuda.<op>` pointed at the oracle, recording for every `_C` op the
           positional-argument kinds it receives and for every Function the arity / None pattern
           it returns                                                       -> call_shapes.json
   2. writes seeded input/output vectors of the oracle for small cases      -> case_*.npz
      (the reference has no CPU implementation and no fixture for the 2D projection or the sum
-      rasterizer, so these vectors pin the oracle against regressions, not against the CUDA path:
-      "parity unpinned", see oracle/gi2d_oracle.c).
+      rasterizer, so these vectors pin the oracle against regressions; what pins it against the
+      reference is ref_vectors.npz).
 
 Nothing from /root/reference is copied; only numbers and call shapes are stored.
 """
