@@ -123,6 +123,9 @@ struct CullBox {
 // no finite box exists (non positive definite conic or non-finite inputs) and every pixel must be evaluated.  One
 // gaussian's extents do not depend on the tile, so the fast path computes them once per gaussian in its binning step.
 #define GI2D_CULL_FULL 3.0e38f
+#ifndef GI2D_CULL_MARGIN
+#define GI2D_CULL_MARGIN 0.0625f
+#endif
 __device__ __forceinline__ void cull_extent(float gx, float gy, float a, float b, float c, float opac, float &hx,
                                             float &hy) {
     const float big = GI2D_CULL_FULL;
@@ -134,11 +137,15 @@ __device__ __forceinline__ void cull_extent(float gx, float gy, float a, float b
     }
     const float det = a * c - b * b;
     if (!(a > 0.f) || !(c > 0.f) || !(det > 0.f)) return;  // not PD / NaN: no box
-    // hardware sqrt / reciprocal (1 ulp) are enough: the extents carry a 2e-4 relative and 0.75 px absolute margin
+    // hardware sqrt / reciprocal (1 ulp) are enough: what has to be covered is the rounding of the fp32 quadratic
+    // form next to the cut-off, which is relative to its terms -- 4e-4 relative + 1e-3 absolute on the threshold,
+    // i.e. 2e-4 of the extent -- plus GI2D_CULL_MARGIN pixels of slack (pixels sit at integer coordinates, so every
+    // 1/16 px of margin adds 1/16 of a row and of a column to the average box; 0.75 px, the round-1 value, cost
+    // a third of all evaluated pairs)
     const float tau2 = 2.f * __logf(opac * 255.f) * 1.0002f + 1e-3f;
     const float t = tau2 * __builtin_amdgcn_rcpf(det);
-    const float ex = __builtin_amdgcn_sqrtf(t * c) * 1.0002f + 0.75f;
-    const float ey = __builtin_amdgcn_sqrtf(t * a) * 1.0002f + 0.75f;
+    const float ex = __builtin_amdgcn_sqrtf(t * c) * 1.0002f + GI2D_CULL_MARGIN;
+    const float ey = __builtin_amdgcn_sqrtf(t * a) * 1.0002f + GI2D_CULL_MARGIN;
     if (!(ex < big) || !(ey < big) || !(gx == gx) || !(gy == gy)) return;
     hx = ex;
     hy = ey;

@@ -62,7 +62,7 @@ struct FusedLds {
     unsigned cullw[GI2D_TILE_LIST_CAP]; // cull_word() of the entry
     int slot[GI2D_TILE_LIST_CAP];       // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big)
     float sse_w[4];
-    int scan_w[4];  // per-wave totals of the backward's item scan (outside the overlay: written during the forward phase)
+    int scan_w[8];  // per-wave totals of the backward's item scan (outside the overlay: written during the forward phase)
     int grp[32];    // tile_list_head: survivors per 64 entries (ascending part, appended part)
     union {
         struct {
@@ -76,10 +76,10 @@ struct FusedLds {
             float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];
             float2 pixB[GI2D_TILE * GI2D_BWD_PIXROW];
             unsigned short off[GI2D_TILE_LIST_CAP + 4];
-            unsigned char item[8 * GI2D_TILE_LIST_CAP];
+            unsigned short item[8 * GI2D_TILE_LIST_CAP];
             float part[GI2D_BWD_PART_ROWS * PSTR];
             unsigned short xr[GI2D_TILE_LIST_CAP];
-            int wsum[4];
+            int wsum[8];
         };
     };
 };
@@ -191,13 +191,13 @@ __device__ __forceinline__ void fused_tile(
     }
     // the backward's item scan starts here, ahead of the barrier that is needed anyway
     const unsigned cull = tid < len ? sm.cullw[tid] : 0u;
-    const int scan_incl = bwd_prescan(sm.scan_w, cull);
+    const unsigned long long scan_incl = bwd_prescan(sm.scan_w, cull);
     __syncthreads();  // every wave is done with its list / pair buffer: the overlay becomes the backward's buffers
 
     GI2D_TRACE(6);
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 3
     if (L >= 0) {
-        if (v0 + v1 + v2 + (float)scan_incl == 12345.f) out_img[0] = v0;
+        if (v0 + v1 + v2 + (float)(unsigned)scan_incl == 12345.f) out_img[0] = v0;
         return;
     }
 #endif

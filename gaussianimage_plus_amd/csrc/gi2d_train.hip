@@ -286,10 +286,15 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     AdamRows rows;
     if (!ADAN && g < n) rows = adam_load_rows(P, g);
+    // everything whose address is known now is requested before the barriers of best_decision(): the box is the first
+    // link of the gradient's load chain (box -> partial rows), radius and conic feed the projection backward
+    const int2 box = g < n ? prev_box[g] : make_int2(0, 0);
+    const int radius = g < n ? radii[g] : 0;
+    float conic[3] = {0.f, 0.f, 0.f};
+    if (g < n) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
-               partial_big, acc);
+    reduce_one(g, box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -300,8 +305,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     ProjGrad r;
     r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
     r.v_mean = make_float2(0.f, 0.f);
-    if (radii[g] > 0) {
-        const float conic[3] = {conics[3 * g], conics[3 * g + 1], conics[3 * g + 2]};
+    if (radius > 0) {
         const float vc[3] = {acc[2], acc[3], acc[4]};
         r = project_bwd_one<KIND>(0, par, rot_of<KIND>(par), img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
     }

@@ -444,3 +444,47 @@ def test_backward_reduce_handles_huge_gaussians(C, oracle):
     got = C.rasterize_backward_fast(h, w, gids, bins, t(ref["xys"]), t(ref["radii"]), t(ref["conics"]), t(col), t(op),
                                     t(fidx_o), t(v_out), 1.0)
     _check_backward("huge", got, want[:4], want[4], want[5])
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_cull_box_never_drops_a_contributing_pair(C, oracle, seed):
+    """The kernels skip pixels outside a conservative alpha >= 1/255 box (gi2d_common.h::cull_extent); the oracle
+    evaluates every pixel of every tile.  Extreme shapes -- major axis 0.25 .. 150 px, aspect ratio up to 200, any
+    orientation, opacity 0.003 .. 3 -- where the fp32 quadratic form cancels most: a dropped pair would show as an
+    error of >= 1/255 of a colour, far above the rounding tolerance."""
+    h, w, npts = 112, 176, 3000
+    tb = oracle.tile_bounds(h, w)
+    rng = np.random.default_rng(seed)
+    major = np.exp(rng.uniform(np.log(0.25), np.log(150.0), npts))
+    minor = np.maximum(major / np.exp(rng.uniform(0.0, np.log(200.0), npts)), 0.05)
+    th = rng.uniform(0, np.pi, npts)
+    cs, sn = np.cos(th), np.sin(th)
+    cov = np.stack([cs * cs * major ** 2 + sn * sn * minor ** 2, cs * sn * (major ** 2 - minor ** 2),
+                    sn * sn * major ** 2 + cs * cs * minor ** 2], 1).astype(np.float32)
+    xyz = rng.uniform(-1.05, 1.05, (npts, 2)).astype(np.float32)
+    col = rng.random((npts, 3)).astype(np.float32)
+    op = np.exp(rng.uniform(np.log(0.003), np.log(3.0), (npts, 1))).astype(np.float32)
+    xys, depths, radii, conics, nth = oracle.project_gaussians_2d_covariance_forward(npts, 3.0, xyz, cov, h, w, tb)
+    m, cum = oracle.compute_cumulative_intersects(nth)
+    _, _, _, go, bins = oracle.bin_and_sort_gaussians(npts, m, xys, depths, radii, cum, tb, 1.0)
+    out_o, fT_o, fidx_o, amb, absimg = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, xys, conics,
+                                                                    col, op, with_aux=True)
+    v_out = rng.normal(size=(h, w, 3)).astype(np.float32) * 1e-3
+    want = oracle.rasterize_sum_backward(h, w, 16, 16, go, bins, xys, conics, col, op, None, fT_o, fidx_o, v_out,
+                                         with_aux=True)
+    bg = torch.ones(3, device=DEV)
+    res = C.rasterize_sum_plus_forward(tb, (16, 16, 1), (w, h, 1), t(go), t(bins), t(xys), t(conics), t(col), t(op),
+                                       bg, False)
+    _check_forward("cull stress", res[0], res[1], res[2], out_o, fidx_o, amb, absimg)
+    got = C.rasterize_sum_plus_backward(h, w, 16, 16, t(go), t(bins), t(xys), t(conics), t(col), t(op), bg,
+                                        torch.ones(h, w, device=DEV), t(fidx_o), t(v_out), None)
+    _check_backward("cull stress", got, want[:4], want[4], want[5])
+    # the fused fast path takes its boxes from the per-gaussian records of the binning step
+    import gaussianimage_plus_amd.gsplat as gs
+    xys_t, conics_t, col_t, op_t = [t(a).requires_grad_(True) for a in (xys, conics, col, op)]
+    img = gs.rasterize_gaussians_plus(xys_t, t(depths), t(radii), conics_t, t(nth), col_t, op_t, h, w, 16, 16,
+                                      background=bg)
+    _check_forward("cull stress wrapper", img, torch.ones(h, w, device=DEV), t(fidx_o), out_o, fidx_o, amb, absimg)
+    img.backward(t(v_out))
+    _check_backward("cull stress wrapper", (xys_t.grad, conics_t.grad, col_t.grad, op_t.grad), want[:4], want[4],
+                    want[5])

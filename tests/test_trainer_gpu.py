@@ -358,7 +358,19 @@ def test_one_fused_update_step_equals_the_torch_optimizer_on_the_same_gradient(o
             moved = (p.detach() - before[nm]).abs()
             assert moved.max().item() > 0.1 * lr, (step, nm)      # the step did something
             err = (getattr(fit, nm) - p.detach()).abs()
-            # the update itself (a few lr at most) is reproduced to 1e-6 of its size, the parameter to its last three ulps
-            assert (err <= 1e-6 * moved + 4e-7 * p.detach().abs() + 1e-12).all(), (step, nm, err.max().item())
+            # the update itself is reproduced to 1e-6 of its size, the parameter to the last three ulps of the largest
+            # value its arithmetic passes through: Adan applies two terms one after the other (addcdiv_ twice), which
+            # may be far larger than their sum
+            mag = p.detach().abs() + before[nm].abs()
+            if optimizer == "adan":
+                s_ = opt.state[[q is p for q in params].index(True)]
+                b1, b2, b3 = opt.betas
+                denom = s_["n"].sqrt() / math.sqrt(1.0 - b3 ** step) + eps
+                mag = mag + (lr / (1.0 - b1 ** step)) * (s_["m"] / denom).abs() \
+                    + (lr * b2 / (1.0 - b2 ** step)) * (s_["d"] / denom).abs()
+            tol = 1e-6 * moved + 4e-7 * mag + 1e-12
+            worst = (err - tol).argmax()
+            assert (err <= tol).all(), (step, nm, err.flatten()[worst].item(), tol.flatten()[worst].item(),
+                                        moved.flatten()[worst].item(), p.detach().flatten()[worst].item())
             for got, ref, what in ((getattr(fit, "m_" + nm), got_m[nm], "m"), (getattr(fit, "v_" + nm), got_v[nm], "v")):
                 assert torch.allclose(got, ref, rtol=1e-6, atol=1e-30), (step, nm, what)

@@ -66,3 +66,9 @@ for x in range(8):
     m = (keys >> 16) == x
     if m.any():
         print(f"  xcc {x}: CUs {int(m.sum())}, finish mean {per_cu_end[m].mean():.1f} max {per_cu_end[m].max():.1f}, start mean {t[:, 0][np.isin(inv, np.nonzero(m)[0])].mean():.2f}")
+# which SIMD did wave 0 of each workgroup land on (HW_ID bits 5:4)?  The waves of a workgroup go to consecutive SIMDs,
+# so a phase that loads its waves unevenly (backward items fill waves 0, 1, 2 in that order) loads the SIMDs unevenly
+simd0 = (hw >> 4) & 3
+print("wave 0 on SIMD 0/1/2/3:", np.bincount(simd0, minlength=4))
+per_cu_simd = np.array([np.bincount(simd0[inv == i], minlength=4) for i in range(len(keys))])
+print("per CU, workgroups whose wave 0 sits on the same SIMD: max", per_cu_simd.max(1).mean().round(2), "(mean over CUs)")
