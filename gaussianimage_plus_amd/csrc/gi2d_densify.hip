@@ -148,7 +148,6 @@ __global__ __launch_bounds__(1024) void grow_select_kernel(int npix, const uint3
                                                            int max_points, int budget_cap, int kmax,
                                                            int32_t *__restrict__ sel, int32_t *__restrict__ info) {
     __shared__ int hist[256];
-    __shared__ int wsum[17];
     __shared__ unsigned s_prefix;
     __shared__ int s_want;
     const int tid = threadIdx.x;
@@ -166,9 +165,36 @@ __global__ __launch_bounds__(1024) void grow_select_kernel(int npix, const uint3
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int p = tid; p < npix; p += 1024) {
-            const unsigned v = key[p];
-            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1);
+        // one workgroup reads every key in every pass: eight loads per lane in flight at a time (a load per trip, each
+        // waited for before the next, made this kernel 0.7 ms of pure latency)
+        for (int base = 0; base < npix; base += 8 * 1024) {  // wave-uniform trip count (ballots below)
+            unsigned v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = base + u * 1024 + tid;
+                v8[u] = p < npix ? key[p] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = base + u * 1024 + tid;
+                const unsigned v = v8[u];
+                const bool act = p < npix && (v & mask) == prefix;
+                const unsigned d = (v >> shift) & 255u;
+                if (shift == 24) {
+                    // the top byte of an error in [0, 3] takes a handful of values: one LDS atomic per distinct value
+                    // and wave instead of one per key (64 lanes on one address serialise)
+                    unsigned long long todo = __ballot(act);
+                    while (todo) {
+                        const int src = __ffsll((long long)todo) - 1;
+                        const unsigned d0 = (unsigned)__shfl((int)d, src, 64);
+                        const unsigned long long same = __ballot(act && d == d0);
+                        if ((tid & 63) == src) atomicAdd(&hist[d0], __popcll(same));
+                        todo &= ~same;
+                    }
+                } else if (act) {
+                    atomicAdd(&hist[d], 1);
+                }
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -187,26 +213,50 @@ __global__ __launch_bounds__(1024) void grow_select_kernel(int npix, const uint3
         __syncthreads();
     }
     const unsigned thr = prefix;  // the k-th largest key; `want` of the keys equal to it are taken, lowest index first
-    // every lane owns a contiguous run of pixels: count, one block scan of the counts, then write in index order
-    const int chunk = (npix + 1023) / 1024, p0 = tid * chunk, p1 = min(npix, p0 + chunk);
-    int above = 0, equal = 0;
-    for (int p = p0; p < p1; ++p) {
-        const unsigned v = key[p];
-        above += v > thr ? 1 : 0;
-        equal += v == thr ? 1 : 0;
+    // every WAVE owns a contiguous run of pixels and walks it 64 consecutive keys at a time (coalesced, eight loads per
+    // lane in flight): count, scan the sixteen wave totals, then write in index order -- a selected pixel's position is
+    // everything selected in front of it, which inside a 64-key group is a ballot and a popcount
+    __shared__ int w_above[16], w_equal[16];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int per_wave = (((npix + 15) / 16) + 63) & ~63;
+    const int w0 = min(npix, wave * per_wave), w1 = min(npix, w0 + per_wave);
+    const unsigned long long lt = lanemask_lt();
+    int above = 0, equal = 0;  // wave-uniform
+    for (int base = w0; base < w1; base += 64 * 8) {
+        unsigned v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + 64 * u + lane;
+            v8[u] = p < w1 ? key[p] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = base + 64 * u + lane < w1;
+            above += __popcll(__ballot(in && v8[u] > thr));
+            equal += __popcll(__ballot(in && v8[u] == thr));
+        }
     }
-    int t_above, t_equal;
-    int a_before = block_exclusive_scan(above, wsum, t_above);
-    int e_before = block_exclusive_scan(equal, wsum, t_equal);
-    for (int p = p0; p < p1; ++p) {
-        const unsigned v = key[p];
-        // position = everything selected in front of this pixel, in index order
-        if (v > thr) {
-            sel[a_before + min(e_before, want)] = p;
-            ++a_before;
-        } else if (v == thr) {
-            if (e_before < want) sel[a_before + e_before] = p;
-            ++e_before;
+    if (lane == 0) w_above[wave] = above, w_equal[wave] = equal;
+    __syncthreads();
+    int a_before = 0, e_before = 0;
+    for (int k = 0; k < wave; ++k) a_before += w_above[k], e_before += w_equal[k];
+    for (int base = w0; base < w1; base += 64 * 8) {
+        unsigned v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + 64 * u + lane;
+            v8[u] = p < w1 ? key[p] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool in = p < w1, is_a = in && v8[u] > thr, is_e = in && v8[u] == thr;
+            const unsigned long long ba = __ballot(is_a), be = __ballot(is_e);
+            const int a_cnt = a_before + __popcll(ba & lt), e_cnt = e_before + __popcll(be & lt);
+            if (is_a) sel[a_cnt + min(e_cnt, want)] = p;
+            if (is_e && e_cnt < want) sel[a_cnt + e_cnt] = p;
+            a_before += __popcll(ba);
+            e_before += __popcll(be);
         }
     }
 }

@@ -279,6 +279,14 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
             radius = radii[g];
         }
     }
+    // the projection parameters are requested together with the record, not after the gradient sum they will meet
+    float par[3] = {0.f, 0.f, 0.f};
+    if (g < n) {
+        if (KIND == kScaleRot)
+            par[0] = p0[2 * g], par[1] = p0[2 * g + 1], par[2] = p1[g];
+        else if (KIND == kCholesky)
+            par[0] = p0[3 * g], par[1] = p0[3 * g + 1], par[2] = p0[3 * g + 2];
+    }
     float acc[11];
     reduce_one(g, box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
     if (g >= n) return;
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     r.v_mean = make_float2(0.f, 0.f);
     if (radius > 0) {
         const float vc[3] = {acc[2], acc[3], acc[4]};
-        r = project_bwd_one<KIND>(g, p0, p1, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
+        r = project_bwd_one<KIND>(0, par, par + 2, img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
     }
     store_proj_grad(g, KIND == kScaleRot, r, v_cov2d, v_mean2d, v_p0, v_p1);
 }
