@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__r
     if (g >= n) return;
     // forward.cu:161: culled gaussians are in no tile
     bin_one(g, xys[g], radii[g], true, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g], colors[3 * g],
-            colors[3 * g + 1], colors[3 * g + 2], tiles_x, tiles_y, radius_clip, prev_box, lists, recs);
+            colors[3 * g + 1], colors[3 * g + 2], tiles_x, tiles_y, radius_clip, prev_box[g], prev_box, lists, recs);
 }
 
 // projection of gaussian g + its binning step (g == 0 also resets the per-call status words)
@@ -59,6 +59,9 @@ __device__ __forceinline__ void project_fill_one(
     begin_binning(g, bt.status);
     float4 *recs = recs_for_binning(bt.recs, g == 0);
     if (g >= n) return;
+    // every input is requested before the first store below (the outputs may alias them as far as the compiler knows)
+    const int2 old_box = bt.prev_box[g];
+    const float opac = bt.opacities[g], cr = bt.colors[3 * g], cg = bt.colors[3 * g + 1], cb = bt.colors[3 * g + 2];
     const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
     xys[g] = o.xy;
     depths[g] = 0.f;
@@ -67,8 +70,7 @@ __device__ __forceinline__ void project_fill_one(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, bt.opacities[g], bt.colors[3 * g], bt.colors[3 * g + 1], bt.colors[3 * g + 2], tiles_x, tiles_y,
-                  radius_clip, bt.prev_box, bt.lists, recs);
+    bin_projected(g, o, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, bt.prev_box, bt.lists, recs);
 }
 
 template <int KIND>

@@ -97,11 +97,12 @@ __device__ __forceinline__ int2 pack_box(int mnx, int mny, int mxx, int mxy) {
 }
 // Bin gaussian g with tile box [mnx, mxx) x [mny, mxy) (`member` false: it is in no tile -- culled, clipped or off
 // screen): append it to the rows of the tiles of the new box that were not in the box it was binned with before.
+// `old`: prev_box[g], loaded by the caller together with its other inputs -- read here, after the caller's stores, it
+// would be one more dependent memory round trip at the end of a latency-bound kernel.
 __device__ __forceinline__ void fill_diff(int g, bool member, int mnx, int mny, int mxx, int mxy, int tiles_x,
-                                          int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
+                                          int2 old, int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
     member = member && mxx > mnx && mxy > mny;
     const int2 nw = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
-    const int2 old = prev_box[g];
     if (old.x == nw.x && old.y == nw.y) return;  // the usual case: same tiles as last time, nothing to do
     prev_box[g] = nw;
     if (!member) return;  // its old entries are dropped by the tile pass (they fail the membership test)
@@ -234,19 +235,20 @@ __device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mx
 // appends to the rows of tiles it has entered, and its record.
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
-                                        float radius_clip, int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
-                                        float4 *__restrict__ recs) {
+                                        float radius_clip, int2 old_box, int2 *__restrict__ prev_box,
+                                        int32_t *__restrict__ lists, float4 *__restrict__ recs) {
     int mnx, mny, mxx, mxy;
     const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
-    fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, prev_box, lists);
+    fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
     write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
                  radius);
 }
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
-                                              int tiles_x, int tiles_y, float radius_clip, int2 *__restrict__ prev_box,
-                                              int32_t *__restrict__ lists, float4 *__restrict__ recs) {
+                                              int tiles_x, int tiles_y, float radius_clip, int2 old_box,
+                                              int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+                                              float4 *__restrict__ recs) {
     bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
-            prev_box, lists, recs);
+            old_box, prev_box, lists, recs);
 }
 
 // partial-row code of gaussian g in tile (tx, ty) of its box: >= 0 gaussian-major row, < 0: -(big row) - 1

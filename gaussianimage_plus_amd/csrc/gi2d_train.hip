@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
+    const int2 old_box = prev_box[g];  // with the other inputs, ahead of the stores
+    const Row3 col = load_row3(P.feat, g);
+    const float opac = P.opacity[g];
     float2 mean;
     float par[3];
     activate<KIND>(P, g, mean, par);
@@ -119,8 +122,7 @@ __global__ __launch_bounds__(256) void train_project_fill_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    const Row3 col = load_row3(P.feat, g);
-    bin_projected(g, o, P.opacity[g], col.a, col.b, col.c, tiles_x, tiles_y, radius_clip, prev_box, lists, recs);
+    bin_projected(g, o, opac, col.a, col.b, col.c, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists, recs);
 }
 
 struct AdamStep {
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     const int radius = g < n ? radii[g] : 0;
     float conic[3] = {0.f, 0.f, 0.f};
     if (g < n) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
+    const float opac_next = (FILL_NEXT && g < n) ? P.opacity[g] : 0.f;
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
     reduce_one(g, box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
@@ -366,16 +369,20 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
         conics[3 * g + 1] = o.k1;
         conics[3 * g + 2] = o.k2;
         next.num_tiles_hit[g] = o.tiles_hit;
-        bin_projected(g, o, P.opacity[g], new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip,
+        // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box)
+        bin_projected(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, box,
                       next.prev_box, next.lists, recs);
     }
-    if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned)
-        best.xyz[2 * g] = P.xyz[2 * g];
-        best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
+    if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned):
+        // from the registers the update left, not read back through memory (a store -> load round trip at the end of
+        // nearly every iteration while the fit still improves)
+        best.xyz[2 * g] = new_xy.x;
+        best.xyz[2 * g + 1] = new_xy.y;
+        const float nc[3] = {new_chol.a, new_chol.b, new_chol.c}, nf[3] = {new_feat.a, new_feat.b, new_feat.c};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            best.chol[3 * g + q] = P.chol[3 * g + q];
-            best.feat[3 * g + q] = P.feat[3 * g + q];
+            best.chol[3 * g + q] = nc[q];
+            best.feat[3 * g + q] = nf[q];
             if (best.bound) best.bound[3 * g + q] = P.bound[(size_t)P.bound_stride * g + q];
         }
     }
@@ -458,6 +465,8 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
+    const int2 old_box = prev_box[g];  // with the other inputs, ahead of the stores
+    const float opac = P.opacity[g];
     const QuantVals v = load_quant(Q);
     QuantRow r;
     quantise_row(P, Q, v, g, r);
@@ -473,8 +482,8 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, P.opacity[g], r.col[0].dequant, r.col[1].dequant, r.col[2].dequant, tiles_x, tiles_y,
-                  radius_clip, prev_box, lists, recs);
+    bin_projected(g, o, opac, r.col[0].dequant, r.col[1].dequant, r.col[2].dequant, tiles_x, tiles_y, radius_clip,
+                  old_box, prev_box, lists, recs);
 }
 
 // (min, count) / (max, count) combination: equal extremes add their counts
@@ -790,15 +799,16 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
             store_row3(P.feat, g, f0, f1, f2);
             store_row3(P.m_feat, g, mf.a, mf.b, mf.c);
             store_row3(P.v_feat, g, vf.a, vf.b, vf.c);
-        }
-        if (snapshot) {
-            best.xyz[2 * g] = P.xyz[2 * g];
-            best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
+            if (snapshot) {  // from registers, not read back through memory
+                best.xyz[2 * g] = nx;
+                best.xyz[2 * g + 1] = ny;
+                const float nf[3] = {f0, f1, f2};
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                best.chol[3 * g + q] = P.chol[3 * g + q];  // parked entries are patched by the finish kernel
-                best.feat[3 * g + q] = P.feat[3 * g + q];
-                if (best.bound) best.bound[3 * g + q] = bd[q];
+                for (int q = 0; q < 3; ++q) {
+                    best.chol[3 * g + q] = cn[q];  // parked entries are patched by the finish kernel
+                    best.feat[3 * g + q] = nf[q];
+                    if (best.bound) best.bound[3 * g + q] = bd[q];
+                }
             }
         }
     }
@@ -859,6 +869,8 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
+    const int2 old_box = prev_box[g];  // with the other inputs, ahead of the stores
+    const float opac = P.opacity[g];
     const QuantValsRS v = load_quant_rs(Q);
     QuantRowRS r;
     quantise_row_rs(Q, v, load_row2(P.xyz, g), load_row3(P.chol, g), load_row3(P.feat, g), r);
@@ -873,8 +885,8 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     conics[3 * g + 1] = o.k1;
     conics[3 * g + 2] = o.k2;
     num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, P.opacity[g], r.col[0].dequant, r.col[1].dequant, r.col[2].dequant, tiles_x, tiles_y,
-                  radius_clip, prev_box, lists, recs);
+    bin_projected(g, o, opac, r.col[0].dequant, r.col[1].dequant, r.col[2].dequant, tiles_x, tiles_y, radius_clip,
+                  old_box, prev_box, lists, recs);
 }
 
 __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
@@ -927,13 +939,14 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
         float2 new_xy;
         Row3 new_chol, new_feat;
         adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
-        if (snapshot) {
-            best.xyz[2 * g] = P.xyz[2 * g];
-            best.xyz[2 * g + 1] = P.xyz[2 * g + 1];
+        if (snapshot) {  // from registers, not read back through memory
+            best.xyz[2 * g] = new_xy.x;
+            best.xyz[2 * g + 1] = new_xy.y;
+            const float nc[3] = {new_chol.a, new_chol.b, new_chol.c}, nf[3] = {new_feat.a, new_feat.b, new_feat.c};
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                best.chol[3 * g + q] = P.chol[3 * g + q];
-                best.feat[3 * g + q] = P.feat[3 * g + q];
+                best.chol[3 * g + q] = nc[q];
+                best.feat[3 * g + q] = nf[q];
                 if (best.bound) best.bound[3 * g + q] = P.bound[(size_t)P.bound_stride * g + q];
             }
         }
