@@ -420,6 +420,23 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
         const int2 r = t < num_tiles ? tile_bins[t] : make_int2(0, 0);
         pop[q] = min(max(r.y - r.x, 0), GI2D_ORDER_BINS - 1);
     }
+    // Worth it?  With populations as even as a uniform scene's (fullest tile < 1.75 x the mean; 1.49 at 50 000 uniform
+    // gaussians) dealing them out buys the tile pass 0.1-0.2 us and this workgroup, the longest of the end-of-step
+    // kernel, costs that kernel 1.1 us; on a trained scene (gaussians crowd where the detail is) the same ordering is
+    // worth 3.8 us per iteration.  The order in place stays (any permutation is correct).
+    {
+        __shared__ int red_max[4], red_sum[4];
+        int mx = 0, sm = 0;
+#pragma unroll
+        for (int q = 0; q < PL; ++q) mx = max(mx, pop[q]), sm += pop[q];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64)), sm += __shfl_xor(sm, d, 64);
+        if ((tid & 63) == 0) red_max[tid >> 6] = mx, red_sum[tid >> 6] = sm;
+        __syncthreads();
+        mx = 0, sm = 0;
+        for (int k = 0; k < (bs >> 6); ++k) mx = max(mx, red_max[k]), sm += red_sum[k];
+        if (4 * mx * num_tiles <= 7 * sm) return;  // workgroup-uniform
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PL; ++q)

@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
 #pragma clang fp contract(off)
     if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next iteration's tile order (gi2d_fast_internal.h)
+#ifndef GI2D_NO_TILE_ORDER /* development aid: tools/variant_sweep.sh */
         compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);
+#endif
         return;
     }
     n = live_n(P, n);
