@@ -287,7 +287,10 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 // lane that owns the gaussian through LDS and added in row order.
 #define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
 #ifndef GI2D_BWD_PART_ROWS
-#define GI2D_BWD_PART_ROWS 128 /* item rows of the LDS hand-off buffer (256: one pass per round, +4.5 KB LDS) */
+#define GI2D_BWD_PART_ROWS 176 /* item rows of the LDS hand-off buffer: most tiles of a 50 000-gaussian 768x512 image
+                                  (155 items on average) hand over in one pass; 192 rows (27.1 KB in the single-pass tile
+                                  kernel) cost it the sixth workgroup per CU: 128 / 160 / 176 / 192 rows measure
+                                  20.6 / 20.4 / 20.2 / 21.9 us */
 #endif
 #ifndef GI2D_BWD_OCC
 #define GI2D_BWD_OCC 5 /* waves per SIMD the register allocator must leave room for; measured: 5 (96 VGPRs) beats 6 (80) */
@@ -481,6 +484,9 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
     __syncthreads();
     GI2D_BWD_TRACE(7);
     const int n_items = sm.off[len];
+#if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 4 /* development aid: budget of the item build */
+    if (n_items >= 0) return;
+#endif
 
     // pixel x coordinates of a row's first pair, exactly as the forward forms them: (float)j
     // (small integers: stepping by 2.0 stays exact)
@@ -586,6 +592,12 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             }
         }
         GI2D_BWD_TRACE(8);  // this lane's item is done (lane 0: not the slowest one)
+#if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 5 /* development aid: budget of the item loop */
+        if (n_items >= 0) {
+            if (res[0] + res[PSTR - 1] == 12345.678f) sm.part[0] = res[0];
+            return;
+        }
+#endif
         // hand-off: the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row
         // order.  The LDS exchange buffer holds PART_ROWS item rows, so a round is handed over in
         // GI2D_BWD_ITEMS / PART_ROWS passes (half the buffer = two more barriers, 4.5 KB less LDS per workgroup).
@@ -631,7 +643,11 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             if (!last) __syncthreads();
         }
         GI2D_BWD_TRACE(9);
+#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 4 /* development aid (wrong results): gradient rows are not stored */
+        if (owner && acc[0] == 12345.678f) store_partial_row<PSTR>(dst, acc);
+#else
         if (owner) store_partial_row<PSTR>(dst, acc);
+#endif
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);
 }
