@@ -145,11 +145,20 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
             if (NEED_FIDX) bdst[18] = __int_as_float(k);
         }
         __builtin_amdgcn_wave_barrier();
+#if defined(GI2D_FWD_KNOCK) && GI2D_FWD_KNOCK == 2 /* development aid (wrong results): one trip per chunk */
+        const int m = min(2, n_max - c0);
+#else
         const int m = min(GI2D_FWD_CHUNK, n_max - c0);
+#endif
         for (int t = 0; t < m; t += 2) {
             const float4 *q = reinterpret_cast<const float4 *>(mine + t * 10);
+#if defined(GI2D_FWD_KNOCK) && GI2D_FWD_KNOCK == 1 /* development aid (wrong results): 3 of the 5 LDS reads per trip */
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q1;
+            const v2f cb = {q0.x, q0.y};
+#else
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
+#endif
             const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
             const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
             const v2f dx = gx - px2, dy = gy - py2;
