@@ -436,6 +436,10 @@ __device__ __forceinline__ BwdItemsOf bwd_items_of(unsigned cull) {
 // and pass the result to bwd_run_tile (PRESCANNED), which then needs one barrier less; wsum must not live in memory
 // other waves still use.
 __device__ __forceinline__ unsigned long long bwd_prescan(int *wsum, unsigned cull) {
+    if (__ballot((cull & 15u) != 0u) == 0ull) {  // a wave without items (short lists leave three of four like that)
+        if ((threadIdx.x & 63) == 63) wsum[2 * (threadIdx.x >> 6)] = 0, wsum[2 * (threadIdx.x >> 6) + 1] = 0;
+        return 0ull;
+    }
     const unsigned long long c = bwd_items_of(cull).counts;
     // the 16-bit fields never carry into each other: a tile has at most 8 * 256 items
     const unsigned lo = (unsigned)wave_inclusive_scan((int)(unsigned)c);
@@ -453,17 +457,17 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                                              const int *prescan_wsum = nullptr) {
     constexpr int PSTR = Lds::PSTR;
     const int tid = threadIdx.x, wv = tid >> 6;
-    {
+    unsigned long long incl = prescan_incl;
+    const int *wsum = prescan_wsum;
+    if (!PRESCANNED) {
+        incl = bwd_prescan(sm.wsum, cull);
+        wsum = sm.wsum;
+        __syncthreads();
+    }
+    if ((tid & ~63) < len || wv == 0) {  // waves without entries have nothing to place (wave 0 also closes off[])
         // one item per row pair this gaussian reaches; its row / pixel-pair ranges ride along in sm.xr
         const BwdItemsOf mine = bwd_items_of(cull);
         if (tid < len) sm.xr[tid] = (cull >> 8) & 0xffffu;  // r0 | r1 << 4 | q0 << 8 | q1 << 12
-        unsigned long long incl = prescan_incl;
-        const int *wsum = prescan_wsum;
-        if (!PRESCANNED) {
-            incl = bwd_prescan(sm.wsum, cull);
-            wsum = sm.wsum;
-            __syncthreads();
-        }
         unsigned long long before = 0ull, total = 0ull;  // items of the waves before this one / of the tile, per class
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -474,7 +478,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         const unsigned long long excl = before + incl - mine.counts;  // per class: items of the gaussians before mine
         const int orig0 = bwd_field_sum(excl);                        // first item of mine in gaussian order
         if (tid < len) sm.off[tid] = (unsigned short)orig0;
-        if (tid == 255) sm.off[len] = (unsigned short)(orig0 + mine.n);  // lanes >= len carry 0 items
+        if (tid == 0) sm.off[len] = (unsigned short)bwd_field_sum(total);
         // where the items go: class by class when the whole tile fits one round, in gaussian order otherwise
         // (then an item's round must be the round of its row in the hand-off buffer)
 #ifdef GI2D_BWD_GAUSSIAN_ORDER /* development aid: what the ordering by length buys */
