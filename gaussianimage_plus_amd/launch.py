@@ -358,8 +358,10 @@ def main(argv=None):
         print(f"Average: {size}, PSNR:{out['avg_psnr']:.4f}, Training:{out['avg_train_s']:.4f}s, "
               f"Eval:{out['avg_eval_s']:.8f}s, FPS:{1.0 / max(out['avg_eval_s'], 1e-12):.4f}, "
               f"images:{out['images']}, gpus:{world}, wall:{wall:.2f}s, images/sec:{out['images'] / wall:.4f}" +
-              (f", bpp:{out['avg_bpp']:.4f}, bpp_wc (estimate):{out['avg_bpp_wc']:.4f}, "
-               f"decoded PSNR:{out['avg_psnr_decoded']:.4f}" if args.quantize else ""), flush=True)
+              (f", bpp:{out['avg_bpp']:.4f}" +
+               # the rotation-scale model has no entropy-coded size (models/gaussianimage_rs.py has no analysis_wc)
+               (f", bpp_wc (estimate):{out['avg_bpp_wc']:.4f}" if out["avg_bpp_wc"] > 0 else "") +
+               f", decoded PSNR:{out['avg_psnr_decoded']:.4f}" if args.quantize else ""), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
