@@ -245,6 +245,13 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
     def fit_group(idx, imgs):
         return launch.fit_images_native([im.to(dev) for im in imgs], num_points, iters, threaded=True, **kw)
 
+    # untimed warm-up, the counterpart of --warmup for the step metric: one small image through the same schedule, so that
+    # every kernel of the loop (tile pass, update, prune / growth, render) has its code object loaded -- tens of ms each on
+    # first use, a fixed cost per process that would otherwise be charged to the 3 images a rank fits at N = 8
+    launch.fit_image_native(launch.synthetic_image(96, 144, 99).to(dev), 500, 300, lr=0.018, seed=3047,
+                            kind="covariance", max_points=1500, prune_iter=100, grow_iter=100, eps=1e-15,
+                            optimizer="adam", eval_renders=1)
+    torch.cuda.synchronize(dev)
     barrier()
     t0 = time.perf_counter()
     out = launch.run_sharded(pics, fit_one, rank, world, device=red_dev, group=max(1, args.images_per_gpu),
@@ -257,6 +264,7 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
     return {"value": out["images"] / wall, "unit": "images/s", "images": out["images"], "wall_s": wall,
             "iterations_per_image": iters, "avg_psnr": out["avg_psnr"], "avg_num_gaussians": out["avg_num_gaussians"],
             "images_concurrent_per_gpu": max(1, args.images_per_gpu),
+            "warmup": "one 144x96 image, 300 iterations of the same schedule, untimed (code objects loaded)",
             "workload": f"{args.images} synthetic 768x512 images (Kodak-24 shape), covariance model {num_points}->"
                         f"{max_points} gaussians, {iters} iterations/image (reference default 50000), prune every "
                         f"{prune_iter}, grow every {grow_iter}; image i -> rank i mod {world}"}
