@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     }
     if (FILL_NEXT) {
         // same code path as train_project_fill_kernel, on the values just written
+        // (The record-set lookup stays HERE.  Hoisted to the top of the kernel together with begin_binning -- either
+        // one alone is fine -- the build keeps one more SGPR alive across the whole kernel, spills SGPRs to VGPR lanes,
+        // and a stretch of iterations stops being equal to the same iterations issued one by one: measured,
+        // deterministic, and worth nothing in time.)
         begin_binning(g, next.status);
         float4 *recs = recs_for_binning(next.recs, g == 0);
         // From the rows just written, still in registers (no store -> load round trip).  The empty asm makes them
