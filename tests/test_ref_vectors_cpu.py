@@ -157,3 +157,71 @@ def test_rasterizer_forward_and_backward_equal_float64_autograd(oracle, rv):
         if nm == "v_conic":  # the kernels hand on HALF the gradient of the off-diagonal entry (backward.cu:952-955:
             got = got * np.array([1.0, 2.0, 1.0])  # 0.5 v_sigma dx dy); cov2d_to_conic_vjp doubles it back
         check_close(nm, got, want, mag, mask=np.repeat(okg[:, None], want.shape[1], 1), rtol=1e-5, atol=1e-12)
+
+
+# ---- the reference's OWN CPU rasterizer (_torch_impl.py:354-421 `rasterize_forward`), one gaussian per call, summed;
+# ---- gradients by autograd through the same calls (tests/golden/make_refras_vectors.py -> refras_vectors.npz)
+
+@pytest.fixture(scope="module")
+def rr(golden_dir):
+    return np.load(os.path.join(golden_dir, "refras_vectors.npz"))
+
+
+def refras_lists(oracle, rr):
+    h, w = (int(v) for v in rr["refras_hw"])
+    tb = oracle.tile_bounds(h, w)
+    n = len(rr["refras_radii"])
+    m, cum = oracle.compute_cumulative_intersects(rr["refras_nth"])
+    _, _, so, go, bins = oracle.bin_and_sort_gaussians(n, m, rr["refras_xys"], np.zeros(n, np.float32), rr["refras_radii"],
+                                                       cum, tb, 1.0)
+    return h, w, tb, n, go, bins
+
+
+REFRAS_GRADS = ["v_xy", "v_conic", "v_rgb", "v_opacity"]
+
+
+def check_refras_grads(tag, rr, grads, rtol=1e-5):
+    """Held to BOTH runs of the reference function: float64 tensors (rounding removed) and float32 tensors (as it
+    runs); no mask -- the scene has no pair within 1e-5 of a cut-off (refras_gap_alpha / refras_gap_sigma)."""
+    worst = {}
+    for got, nm in zip(grads, REFRAS_GRADS):
+        mag = rr[f"refras_mag_{nm[2:]}"]
+        got = np.asarray(got, np.float64).reshape(mag.shape)
+        if nm == "v_conic":  # the kernels hand on HALF the gradient of the off-diagonal entry (backward.cu:952-955)
+            got = got * np.array([1.0, 2.0, 1.0])
+        for pre in ("refras", "refras32"):
+            worst[f"{pre}_{nm}"] = check_close(f"{tag} {nm} vs {pre}", got, rr[f"{pre}_{nm}"], mag, rtol=rtol, atol=1e-12)
+    return worst
+
+
+def test_refras_scene_is_unambiguous_and_exercises_both_cutoffs(rr):
+    assert float(rr["refras_gap_alpha"]) > 1e-5 and float(rr["refras_gap_sigma"]) > 1e-5
+    # neither clamp binds (min(0.999, .) there, min(1, .) here): the generator asserts alpha <= 0.999 on every landing pair
+    assert rr["refras_opacity"].max() <= np.float32(0.999)
+    n = len(rr["refras_radii"])
+    h, w = (int(v) for v in rr["refras_hw"])
+    landed = np.unpackbits(rr["refras_landed"])[:n * h * w].reshape(n, h, w).astype(bool)
+    assert int(landed.sum()) == int(rr["refras_pairs_landing"]) > 2000
+    det = rr["refras_conics"][:, 0] * rr["refras_conics"][:, 2] - rr["refras_conics"][:, 1] ** 2
+    assert (det < 0).sum() == 2 and landed[det < 0].any()  # non positive definite conics that still land pairs
+
+
+def test_lists_equal_the_reference_helpers_membership(oracle, rr):
+    h, w, tb, n, go, bins = refras_lists(oracle, rr)
+    member = np.zeros_like(rr["refras_member"])
+    for t in range(tb[0] * tb[1]):
+        member[t, go[bins[t, 0]:bins[t, 1]]] = True
+    assert np.array_equal(member, rr["refras_member"])
+
+
+def test_oracle_rasterizer_equals_the_reference_cpu_rasterizer(oracle, rr):
+    """oracle/gi2d_oracle.c forward (forward.cu:570-691) and backward (backward.cu:1168-1350) against the image and the
+    gradients `_torch_impl.rasterize_forward` + autograd produced, at 1e-5 of the summed absolute terms, every element."""
+    h, w, tb, n, go, bins = refras_lists(oracle, rr)
+    out, fT, fidx = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, rr["refras_xys"],
+                                                 rr["refras_conics"], rr["refras_colors"], rr["refras_opacity"])
+    for pre in ("refras", "refras32"):
+        check_close(f"out_img vs {pre}", out, rr[f"{pre}_out_img"], rr["refras_abs_img"], rtol=1e-5)
+    g = oracle.rasterize_sum_backward(h, w, 16, 16, go, bins, rr["refras_xys"], rr["refras_conics"], rr["refras_colors"],
+                                      rr["refras_opacity"], None, fT, fidx, rr["refras_v_out"])
+    print(check_refras_grads("oracle", rr, g[:4]))

@@ -161,3 +161,76 @@ def test_rasterizer_forward_and_backward_equal_float64_autograd(C, rv):
     assert n(ws.status)[1] == 0
     check_close("fast out_img", n(out_f), rv["ras_out_img"], rv["ras_abs_img"], mask=okp, rtol=1e-5)
     check("fast", C.fast_backward(ws, xys, radii, t(rv["ras_v_out"]), h, w, 1.0)[:4])
+
+
+# ---- the reference's OWN CPU rasterizer (_torch_impl.py:354-421 `rasterize_forward`, one gaussian per call, summed;
+# ---- gradients by autograd through the same calls): tests/golden/refras_vectors.npz
+
+@pytest.fixture(scope="module")
+def rr(golden_dir):
+    return np.load(os.path.join(golden_dir, "refras_vectors.npz"))
+
+
+def test_hip_rasterizers_equal_the_reference_cpu_rasterizer(C, rr):
+    """Every form of the product's tile rasterizer -- the ops that mirror the reference bindings
+    (rasterize_sum_forward/backward, rasterize_sum_plus_forward/backward), the two-kernel fast path of the autograd
+    wrappers and the single-pass forward+backward kernel that bench.py and the fitting loop run -- against the image and
+    the gradients the reference's `rasterize_forward` + autograd produced: 1e-5 of the summed absolute terms, every
+    element, no mask (the scene keeps 1e-5 clear of both cut-offs), against the float64-tensor run and the float32 one."""
+    from gaussianimage_plus_amd import _lib
+    from test_ref_vectors_cpu import check_refras_grads
+    h, w = (int(v) for v in rr["refras_hw"])
+    tb = ((w + 15) // 16, (h + 15) // 16, 1)
+    cnt = len(rr["refras_radii"])
+    m = int(rr["refras_nth"].sum())
+    xys, conics, colors, opac = t(rr["refras_xys"]), t(rr["refras_conics"]), t(rr["refras_colors"]), t(rr["refras_opacity"])
+    radii, v_out = t(rr["refras_radii"]), t(rr["refras_v_out"])
+    gids, bins, status = C.bin_gaussians(xys, radii, tb, 1.0, m + 64)
+    assert n(status)[:2].tolist() == [m, 0]
+    gids = gids[:m].contiguous()
+    member = np.zeros_like(rr["refras_member"])
+    go, tbn = n(gids), n(bins)
+    for tile in range(tb[0] * tb[1]):
+        member[tile, go[tbn[tile, 0]:tbn[tile, 1]]] = True
+    assert np.array_equal(member, rr["refras_member"])  # lists == the reference helpers' membership
+    bg = torch.zeros(3, device=DEV)
+
+    def check_img(tag, img):
+        return {pre: check_close(f"{tag} out_img vs {pre}", n(img), rr[f"{pre}_out_img"], rr["refras_abs_img"], rtol=1e-5)
+                for pre in ("refras", "refras32")}
+
+    worst = {}
+    # (1) the ops behind the reference's binding names
+    out, fT, fidx = C.rasterize_sum_plus_forward(tb, (16, 16, 1), (w, h, 1), gids, bins, xys, conics, colors, opac, bg,
+                                                 False)
+    worst["plus img"] = check_img("plus", out)
+    res = C.rasterize_sum_plus_backward(h, w, 16, 16, gids, bins, xys, conics, colors, opac, bg, fT, fidx, v_out, None)
+    worst["plus"] = check_refras_grads("plus", rr, [n(g) for g in res[:4]])
+    out_s = C.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), gids, bins, xys, conics, colors, opac, bg, False)
+    assert torch.equal(out_s[0], out)
+    res_s = C.rasterize_sum_backward(h, w, 16, 16, gids, bins, xys, conics, colors, opac, bg, out_s[1], out_s[2], v_out,
+                                     None)
+    for a, b in zip(res_s[:4], res[:4]):
+        assert torch.equal(a, b)
+    # (2) the two-kernel fast path (what the autograd wrappers run)
+    ws = C.FastWorkspace(cnt, tb, xys)
+    out_f = C.fast_forward(ws, xys, radii, conics, colors, opac, h, w, 1.0)
+    assert n(ws.status)[1] == 0
+    worst["fast img"] = check_img("fast", out_f)
+    worst["fast"] = check_refras_grads("fast", rr, [n(g) for g in C.fast_backward(ws, xys, radii, v_out, h, w, 1.0)[:4]])
+    # (3) the single-pass kernel (fast_fwdbwd_kernel, the dominant kernel of bench.py) through the C ABI
+    ws1 = C.FastWorkspace(cnt, tb, xys)
+    out1 = torch.empty(h, w, 3, device=DEV)
+    grads = [torch.empty(cnt, k, device=DEV) for k in (2, 3, 3, 1)]
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("gi2d_fast_bin", cnt, xys.data_ptr(), radii.data_ptr(), conics.data_ptr(), colors.data_ptr(),
+              opac.data_ptr(), tb[0], tb[1], 1.0, ws1.buf.data_ptr(), ws1.buf.numel(), ws1.status.data_ptr(), st)
+    _lib.call("gi2d_fast_rasterize_forward_backward", cnt, tb[0], tb[1], w, h, None, v_out.data_ptr(), None, 0.0, None,
+              ws1.buf.data_ptr(), ws1.buf.numel(), ws1.status.data_ptr(), out1.data_ptr(), st)
+    _lib.call("gi2d_fast_rasterize_backward_reduce", cnt, tb[0], tb[1], ws1.buf.data_ptr(), ws1.buf.numel(),
+              grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), None, st)
+    torch.cuda.synchronize()
+    assert n(ws1.status)[1] == 0
+    worst["single-pass img"] = check_img("single-pass", out1)
+    worst["single-pass"] = check_refras_grads("single-pass", rr, [n(g) for g in grads])
+    print(worst)
