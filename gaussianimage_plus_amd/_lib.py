@@ -57,6 +57,9 @@ SIGNATURES.update({
     "gi2d_train_render": [_p, _p],
     "gi2d_train_step": [_p, _p, C.c_double, C.c_double, _f, _i, _p],
     "gi2d_train_steps": [_p, _p, C.c_double, C.c_double, _f, _i, _i, _p],
+    # several images per launch: host array of struct gi2d_train_state* / of struct gi2d_fast_image
+    "gi2d_train_steps_batched": [_i, _p, _p, _sz, _p, C.c_double, C.c_double, _f, _i, _i, _p],
+    "gi2d_fast_rasterize_forward_backward_batched": [_i, _p, _p, _sz, _p],
     "gi2d_train_prune": [_p, _p, _sz, _p, _p],
     "gi2d_train_grow": [_p, _i, _i, _p, _i, _p, _sz, _p, _p],
     # quantisers: struct gi2d_quant_spec* (gaussianimage_plus_amd/quantize.py::_QuantSpec)
@@ -74,6 +77,7 @@ SIZE_FUNCS = {
     "gi2d_bin_workspace_bytes": [_i, _i],
     "gi2d_quant_workspace_bytes": [_i],
     "gi2d_densify_scratch_bytes": [_p, _i],
+    "gi2d_batch_bytes": [_i],
 }
 STRING_FUNCS = ["gi2d_version", "gi2d_last_error_string"]
 

@@ -24,9 +24,13 @@
 // Capacity contract: at most GI2D_FAST_C (1024) candidates per tile row, of which the 256 lowest ids are
 // rasterized (forward.cu:553).  A fuller row sets status[1] and the caller must fall back to the exact path
 // (gi2d_bin_gaussians + plain ops) and re-initialise the workspace.
+#include <cstring>
+#include <vector>
+
 #include <hip/hip_ext.h>
 
 #include "gi2d_fused_core.h"
+#include "gi2d_batch.h"
 
 namespace gi2d {
 
@@ -200,15 +204,32 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 
 // ----------------------------------------------------------------- forward + backward in one pass
 template <int MODE>
-__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(
-    int tiles_x, int tiles_y, int img_w, int img_h, RecSets rs, int32_t *__restrict__ lists,
-    int2 *__restrict__ tile_bins, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
-    int32_t *__restrict__ status, float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale,
-    float *__restrict__ tile_sse, const int32_t *__restrict__ tile_order) {
+__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(TilePassArgs a) {
     __shared__ FusedLds sm;
-    const float4 *recs = recs_for_tile_pass(rs, blockIdx.x == 0 && threadIdx.x == 0);
-    fused_tile<MODE>(sm, tile_order[blockIdx.x], tiles_x, tiles_y, img_w, img_h, recs, lists, tile_bins, partial_g,
-                     partial_big, status, out_img, vsrc, grad_scale, tile_sse);
+    const float4 *recs = recs_for_tile_pass(a.rs, blockIdx.x == 0 && threadIdx.x == 0);
+    fused_tile<MODE>(sm, a.tile_order[blockIdx.x], a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins,
+                     a.partial_g, a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse);
+}
+
+// The same pass over the tiles of K images in ONE launch (gi2d_batch.h): workgroup b belongs to image k with
+// tile_start[k] <= b < tile_start[k + 1] and handles that image's tile tile_order[b - tile_start[k]]; everything else
+// is the single-image kernel's code, so every image's results are those of its own launch bit for bit.
+template <int MODE>
+__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kernel(
+    const BatchImage *__restrict__ imgs, const int *__restrict__ tile_start, int k_images, int uniform_tiles) {
+    __shared__ FusedLds sm;
+    int k, local;
+    if (uniform_tiles > 0) {
+        k = (int)blockIdx.x / uniform_tiles;
+        local = (int)blockIdx.x - k * uniform_tiles;
+    } else {
+        k = batch_find(tile_start, k_images, (int)blockIdx.x);
+        local = (int)blockIdx.x - tile_start[k];
+    }
+    const TilePassArgs &a = imgs[k].t;
+    const float4 *recs = recs_for_tile_pass(a.rs, local == 0 && threadIdx.x == 0);
+    fused_tile<MODE>(sm, a.tile_order[local], a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins,
+                     a.partial_g, a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse);
 }
 
 // --------------------------------------------------------------------------------------- reduce
@@ -341,6 +362,20 @@ static thread_local KernelTimer *g_armed_timer = nullptr;
             hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                       \
         }                                                                                                          \
     } while (0)
+
+namespace gi2d {
+int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
+                             hipStream_t st) {
+    if (total_blocks <= 0) return GI2D_OK;
+    if (mode == 0)
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<0>, dim3((unsigned)total_blocks), dim3(256), st,
+                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles);
+    else
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<1>, dim3((unsigned)total_blocks), dim3(256), st,
+                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles);
+    return check_launch("batched tile pass");
+}
+}  // namespace gi2d
 
 extern "C" {
 
@@ -502,19 +537,66 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
-    float *no_sse = nullptr;
+    TilePassArgs a = tile_pass_args(w, n, tiles_x, tiles_y, (int)w_, (int)h, status, out_img,
+                                    v_output ? v_output : target, v_output ? 0.f : grad_scale,
+                                    v_output ? nullptr : tile_sse);
     if (v_output)
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, rec_sets(w, n), w.lists, (int2 *)w.tile_bins, w.partial_g,
-                          w.partial_big, status, out_img, v_output, 0.f, no_sse, (const int32_t *)w.tile_order);
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, a);
     else
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, tiles_x, tiles_y,
-                          (int)w_, (int)h, rec_sets(w, n), w.lists, (int2 *)w.tile_bins, w.partial_g,
-                          w.partial_big, status, out_img, target, grad_scale, tile_sse, (const int32_t *)w.tile_order);
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, a);
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);
     return check_launch("fast rasterize forward+backward");
+}
+
+int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast_image *images, void *batch,
+                                                 size_t batch_bytes, gi2d_stream_t st) {
+    if (num_images < 1 || num_images > GI2D_BATCH_MAX || !images) {
+        set_error("fast rasterize forward+backward (batched): 1 .. 64 images per launch");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (!batch || batch_bytes < carve_batch(nullptr, num_images).bytes || ((uintptr_t)batch & 15)) {
+        set_error("fast rasterize forward+backward (batched): batch table too small (gi2d_batch_bytes) or misaligned");
+        return GI2D_ERR_WORKSPACE_TOO_SMALL;
+    }
+    BatchHead head;
+    std::memset(&head, 0, sizeof(head));
+    std::vector<BatchImage> host_imgs((size_t)num_images);
+    std::memset(host_imgs.data(), 0, host_imgs.size() * sizeof(BatchImage));
+    int blocks = 0, tiles0 = 0;
+    bool uniform = true;
+    const bool given = images[0].v_output != nullptr;
+    for (int k = 0; k < num_images; ++k) {
+        const gi2d_fast_image &im = images[k];
+        int rc = check_ws("fast rasterize forward+backward (batched): workspace too small", im.workspace,
+                          im.workspace_bytes, im.num_points, im.tiles_x, im.tiles_y);
+        if (rc != GI2D_OK) return rc;
+        const long long t = (long long)im.tiles_x * im.tiles_y;
+        if (t == 0 || im.img_width == 0 || im.img_height == 0 || (unsigned)im.tiles_x * GI2D_TILE < im.img_width ||
+            (unsigned)im.tiles_y * GI2D_TILE < im.img_height) {
+            set_error("fast rasterize forward+backward (batched): empty image or tile grid that does not cover it");
+            return GI2D_ERR_INVALID_ARGUMENT;
+        }
+        if (!im.status || !im.out_img || ((im.v_output != nullptr) == (im.target != nullptr)) ||
+            (im.target && !im.tile_sse) || (im.v_output != nullptr) != given) {
+            set_error("fast rasterize forward+backward (batched): exactly one of v_output / target per image, the same "
+                      "kind for the whole batch; tile_sse with target");
+            return GI2D_ERR_INVALID_ARGUMENT;
+        }
+        FastWs w = carve_fast(im.workspace, im.num_points, (int)t);
+        host_imgs[k].t = tile_pass_args(w, im.num_points, im.tiles_x, im.tiles_y, (int)im.img_width, (int)im.img_height,
+                                        im.status, im.out_img, given ? im.v_output : im.target,
+                                        given ? 0.f : im.grad_scale, given ? nullptr : im.tile_sse);
+        head.tile_start[k] = blocks;
+        blocks += (int)t;
+        if (k == 0) tiles0 = (int)t;
+        uniform = uniform && (int)t == tiles0;
+    }
+    head.tile_start[num_images] = blocks;
+    BatchTable b = carve_batch(batch, num_images);
+    write_batch_table(b, host_imgs.data(), num_images, head, (hipStream_t)st);
+    return launch_tile_pass_batched(given ? 0 : 1, b, num_images, blocks, uniform ? tiles0 : 0, (hipStream_t)st);
 }
 
 int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h,

@@ -13,37 +13,16 @@
 //
 // The glue the reference runs as ~25 small PyTorch kernels plus two host syncs per iteration
 // (models/gaussianimage_cholesky.py:302-317) is folded into the kernels either side of the rasterizer.
-#include "gi2d_fast_internal.h"
+#include <cstring>
+#include <vector>
+
+#include "gi2d_batch.h"
 #include "gi2d_quant_core.h"
 
 namespace gi2d {
 
-struct TrainParams {
-    // model state (updated in place)
-    float *xyz;       // [N,2] raw (pre-tanh) for kind 0, pixel coordinates for kind 1
-    float *chol;      // [N,3] raw cholesky (kind 0) / covariance (kind 1), before the additive bound
-    float *feat;      // [N,3] colours
-    const float *opacity;  // [N]   (a buffer of ones in the reference models; not optimised)
-    const float *bound;    // [3] or [N,3]: additive bound (cholesky_bound / cov bound)
-    int bound_stride;      // 0 or 3
-    const int32_t *n_dev;  // live population on the device, or null (gi2d_train_state::num_points_dev)
-    // Adam / Adan state: first moment, second moment; Adan only: moment of the gradient difference, previous gradient
-    float *m_xyz, *v_xyz, *m_chol, *v_chol, *m_feat, *v_feat;
-    float *d_xyz, *d_chol, *d_feat, *pg_xyz, *pg_chol, *pg_feat;
-};
-
 // The live population: the host's `n` is an upper bound when the count lives on the device.
 __device__ __forceinline__ int live_n(const TrainParams &P, int n) { return P.n_dev ? min(n, *P.n_dev) : n; }
-
-// Best-model snapshot kept on the device (train.py:133-139 deep-copies the state dict on the host whenever the
-// PSNR improves): best_sse[2] ping-pongs between steps so every workgroup of a launch reads the same value.
-struct BestSnap {
-    float *xyz, *chol, *feat, *bound;  // [N,2], [N,3], [N,3], [N,3] or null (bound_stride 0)
-    float *sse;                        // [2]
-    int32_t *info;                     // [2]: num_points, step of the snapshot
-    const float *tile_sse;
-    int num_tiles, step;
-};
 
 // Whole-row accesses of the [N,2] / [N,3] parameter and moment arrays: one 8- or 12-byte memory instruction per row
 // instead of one per float (the arrays may alias as far as the compiler knows, which keeps it from merging them).
@@ -97,42 +76,47 @@ __device__ __forceinline__ const float *rot_of(const float (&par)[3]) {
     return KIND == kScaleRot ? &par[2] : nullptr;
 }
 
+// Activations + projection + binning step of gaussian `g` of one image (`u.next`: the lists / boxes / records / status
+// the binning step works on).
 template <int KIND>
-__global__ __launch_bounds__(256) void train_project_fill_kernel(
-    int n, float clip_coe, TrainParams P, float img_w, float img_h, int tiles_x, int tiles_y, float radius_clip,
-    float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
-    int32_t *__restrict__ status) {
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    begin_binning(g, status);
-    float4 *recs = recs_for_binning(rs, g == 0);
+__device__ __forceinline__ void train_project_fill_body(int g, const UpdateArgs &u) {
+    const TrainParams &P = u.P;
+    const int n = live_n(P, u.n);
+    begin_binning(g, u.next.status);
+    float4 *recs = recs_for_binning(u.next.recs, g == 0);
     if (g >= n) return;
-    const int2 old_box = prev_box[g];  // with the other inputs, ahead of the stores
+    const int2 old_box = u.next.prev_box[g];  // with the other inputs, ahead of the stores
     const Row3 col = load_row3(P.feat, g);
     const float opac = P.opacity[g];
     float2 mean;
     float par[3];
     activate<KIND>(P, g, mean, par);
-    const ProjOut o =
-        project_one<KIND>(0, clip_coe, &mean, par, rot_of<KIND>(par), img_w, img_h, tiles_x, tiles_y, radius_clip);
-    xys[g] = o.xy;
-    radii[g] = o.radius;
-    conics[3 * g] = o.k0;
-    conics[3 * g + 1] = o.k1;
-    conics[3 * g + 2] = o.k2;
-    num_tiles_hit[g] = o.tiles_hit;
-    bin_projected(g, o, opac, col.a, col.b, col.c, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists, recs);
+    const ProjOut o = project_one<KIND>(0, u.next.clip_coe, &mean, par, rot_of<KIND>(par), u.img_w, u.img_h, u.tiles_x,
+                                        u.tiles_y, u.radius_clip);
+    u.xys[g] = o.xy;
+    u.radii[g] = o.radius;
+    u.conics[3 * g] = o.k0;
+    u.conics[3 * g + 1] = o.k1;
+    u.conics[3 * g + 2] = o.k2;
+    u.next.num_tiles_hit[g] = o.tiles_hit;
+    bin_projected(g, o, opac, col.a, col.b, col.c, u.tiles_x, u.tiles_y, u.radius_clip, old_box, u.next.prev_box,
+                  u.next.lists, recs);
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void train_project_fill_kernel(UpdateArgs u) {
+    train_project_fill_body<KIND>(blockIdx.x * blockDim.x + threadIdx.x, u);
+}
+// K images in one launch (gi2d_batch.h): workgroup b works on image k with pg_start[k] <= b < pg_start[k + 1]; an
+// image's last workgroup is the tile-ordering one of the update kernel and has nothing to do here.
+template <int KIND>
+__global__ __launch_bounds__(256) void train_project_fill_batched_kernel(const BatchImage *__restrict__ imgs,
+                                                                         const int *__restrict__ pg_start,
+                                                                         int k_images) {
+    const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
+    const int local = (int)blockIdx.x - pg_start[k];
+    train_project_fill_body<KIND>(local * blockDim.x + threadIdx.x, imgs[k].u);
 }
 
-struct AdamStep {
-    float step_size;       // lr / (1 - beta1^t)
-    float bc2_sqrt;        // sqrt(1 - beta2^t)            (Adan: sqrt(1 - beta3^t))
-    float one_minus_b1, b2, one_minus_b2, eps;
-    // Adan only
-    float b1, b3, one_minus_b3, step_size_diff;  // lr * beta2 / (1 - beta2^t)
-    int first;                                     // Adam step count == 1: the previous gradient is this one
-};
 // torch/optim/adam.py::_single_tensor_adam (non-capturable, no amsgrad, no weight decay)
 __device__ __forceinline__ float adam(float p, float g, float &m, float &v, const AdamStep &a) {
     m = m + (g - m) * a.one_minus_b1;                 // exp_avg.lerp_(grad, 1 - beta1)
@@ -213,16 +197,6 @@ __device__ __forceinline__ void adan_rows(const TrainParams &P, int g, float gx,
     store_row3(P.pg_feat, g, pf.a, pf.b, pf.c);
 }
 
-// What the update kernel needs to start the NEXT iteration itself (FILL_NEXT): the freshly updated parameters
-// are still in registers, so their activation + projection + bucket fill ride along and the next iteration
-// begins with its tile pass -- one launch and one parameter round trip less per iteration.
-struct NextFill {
-    float clip_coe;
-    int32_t *num_tiles_hit, *lists, *status, *tile_order;
-    int2 *prev_box;
-    RecSets recs;
-};
-
 // optimizer.py::_multi_tensor_adan / _single_tensor_adan (weight_decay 0, no gradient clipping), operation by
 // operation in fp32.  `pg` holds the previous gradient (the reference keeps its negative, neg_pre_grad).
 __device__ __forceinline__ float adan(float p, float g, float &m, float &n, float &d, float &pg, const AdamStep &a) {
@@ -244,20 +218,39 @@ __device__ __forceinline__ bool best_decision(const BestSnap &best, int n, int g
     bool snapshot = false;
     if (best.sse != nullptr) {
         __shared__ float red[256];
-        // 16-byte loads, several in flight per lane (a lane-serial chain of 4-byte loads cost 8 us per step)
-        float part = 0.f;
+        // 16-byte loads, several in flight per lane (a lane-serial chain of 4-byte loads cost 8 us per step).  The order
+        // of the sum does not depend on the workgroup size (64 or 256 lanes): 256 "virtual lanes" v each add the
+        // float4s t = v, v + 256, ... in ascending order, then one tree over the 256 partial sums -- so a launch with
+        // 64-lane workgroups, one with 256 and a batched one take the same decision and store the same best error.
         const float4 *sse4 = reinterpret_cast<const float4 *>(best.tile_sse);
-        const int n4 = best.num_tiles >> 2;
-#pragma unroll 8
-        for (int t = threadIdx.x; t < n4; t += (int)blockDim.x) {
-            const float4 v = sse4[t];
-            part += (v.x + v.y) + (v.z + v.w);
+        const int n4 = best.num_tiles >> 2, bs = (int)blockDim.x;
+        const int nv = 256 / bs;  // virtual lanes per lane: 4 or 1
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r * 256 < n4; r += 2) {  // two rounds x up to four virtual lanes: eight loads in flight
+            float4 val[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = (int)threadIdx.x + q * bs + 256 * (r + rr);
+                    val[rr][q] = (q < nv && t < n4) ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part[q] += (val[rr][q].x + val[rr][q].y) + (val[rr][q].z + val[rr][q].w);
         }
-        for (int t = (n4 << 2) + threadIdx.x; t < best.num_tiles; t += (int)blockDim.x) part += best.tile_sse[t];
-        red[threadIdx.x] = part;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= nv) break;
+            const int v = (int)threadIdx.x + q * bs;
+            float p = part[q];
+            for (int t = (n4 << 2) + v; t < best.num_tiles; t += 256) p += best.tile_sse[t];
+            red[v] = p;
+        }
         __syncthreads();
-        for (int d = (int)blockDim.x / 2; d >= 1; d >>= 1) {  // blockDim.x is 64 or 256
-            if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        for (int d = 128; d >= 1; d >>= 1) {
+            for (int i = threadIdx.x; i < d; i += bs) red[i] += red[i + d];
             __syncthreads();
         }
         const float total = red[0], prev = best.sse[best.step & 1];
@@ -273,21 +266,33 @@ __device__ __forceinline__ bool best_decision(const BestSnap &best, int n, int g
     return snapshot;
 }
 
+// Gradient reduce + projection backward + activation backward + optimizer update (+ next iteration's activation,
+// projection and binning step) of one image's gaussians: workgroup `block` of the image's launch share, or its extra
+// workgroup (`order_block`) that computes the next iteration's tile order (gi2d_fast_internal.h).
 template <int KIND, bool FILL_NEXT, bool ADAN>
-__global__ __launch_bounds__(256) void train_reduce_update_kernel(
-    int n, TrainParams P, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
-    const int2 *prev_box, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
-    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
-    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best, NextFill next) {
+__device__ __forceinline__ void train_reduce_update_body(int block, bool order_block, const UpdateArgs &u,
+                                                         const AdamStep &a_xyz, const AdamStep &a_chol,
+                                                         const AdamStep &a_feat, int step) {
 #pragma clang fp contract(off)
-    if (blockIdx.x == gridDim.x - 1) {  // the extra workgroup: next iteration's tile order (gi2d_fast_internal.h)
+    const int tiles_x = u.tiles_x, tiles_y = u.tiles_y;
+    if (order_block) {
 #ifndef GI2D_NO_TILE_ORDER /* development aid: tools/variant_sweep.sh */
-        compute_tile_order(tile_bins, tiles_x * tiles_y, next.tile_order);
+        compute_tile_order(u.tile_bins, tiles_x * tiles_y, u.next.tile_order);
 #endif
         return;
     }
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const TrainParams &P = u.P;
+    const NextFill &next = u.next;
+    const int2 *prev_box = u.next.prev_box;
+    float2 *xys = u.xys;
+    int32_t *radii = u.radii;
+    float *conics = u.conics;
+    const float img_w = u.img_w, img_h = u.img_h, radius_clip = u.radius_clip;
+    float *dbg_grads = u.dbg_grads;
+    BestSnap best = u.best;
+    best.step = step;
+    const int n = live_n(P, u.n);
+    const int g = block * blockDim.x + threadIdx.x;
     AdamRows rows;
     if (!ADAN && g < n) rows = adam_load_rows(P, g);
     // everything whose address is known now is requested before the barriers of best_decision(): the box is the first
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
     const float opac_next = (FILL_NEXT && g < n) ? P.opacity[g] : 0.f;
     const bool snapshot = best_decision(best, n, g);
     float acc[11];
-    reduce_one(g, box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, box, tiles_x, u.gids_sorted, u.tile_bins, tiles_x * tiles_y, u.partial_g, u.partial_big, acc);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -392,6 +397,25 @@ __global__ __launch_bounds__(256) void train_reduce_update_kernel(
             if (best.bound) best.bound[3 * g + q] = P.bound[(size_t)P.bound_stride * g + q];
         }
     }
+}
+
+template <int KIND, bool FILL_NEXT, bool ADAN>
+__global__ __launch_bounds__(256) void train_reduce_update_kernel(UpdateArgs u, AdamStep a_xyz, AdamStep a_chol,
+                                                                  AdamStep a_feat, int step) {
+    train_reduce_update_body<KIND, FILL_NEXT, ADAN>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz, a_chol,
+                                                    a_feat, step);
+}
+// K images in one launch (gi2d_batch.h): image k owns workgroups [pg_start[k], pg_start[k + 1]), the last of them its
+// tile-ordering workgroup.  All images are at the same optimizer step with the same learning rates.
+template <int KIND, bool FILL_NEXT, bool ADAN>
+__global__ __launch_bounds__(256) void train_reduce_update_batched_kernel(const BatchImage *__restrict__ imgs,
+                                                                          const int *__restrict__ pg_start,
+                                                                          int k_images, AdamStep a_xyz, AdamStep a_chol,
+                                                                          AdamStep a_feat, int step) {
+    const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
+    const int local = (int)blockIdx.x - pg_start[k];
+    const int last = pg_start[k + 1] - pg_start[k] - 1;
+    train_reduce_update_body<KIND, FILL_NEXT, ADAN>(local, local == last, imgs[k].u, a_xyz, a_chol, a_feat, step);
 }
 
 
@@ -1028,9 +1052,66 @@ __global__ __launch_bounds__(256) void train_quant_finish_rs_kernel(int blocks, 
     }
 }
 
+// The batch table is written by kernels that carry the argument blocks as kernel arguments: stream-ordered, no host
+// buffer whose lifetime anybody has to think about, capturable in a graph.
+#define GI2D_BATCH_PACK 6 /* argument blocks per writer launch (kernel arguments are limited to 4 KB) */
+struct BatchPack {
+    BatchImage img[GI2D_BATCH_PACK];
+};
+static_assert(sizeof(BatchPack) <= 3840, "BatchPack must fit the kernel-argument segment");
+__global__ __launch_bounds__(256) void batch_write_images_kernel(BatchPack p, int count, BatchImage *__restrict__ dst) {
+    constexpr int WORDS = (int)(sizeof(BatchImage) / sizeof(int));
+    static_assert(sizeof(BatchImage) % sizeof(int) == 0, "BatchImage is copied word by word");
+    const int *src = reinterpret_cast<const int *>(&p);
+    int *out = reinterpret_cast<int *>(dst);
+    for (int i = threadIdx.x; i < count * WORDS; i += blockDim.x) out[i] = src[i];
+}
+__global__ __launch_bounds__(256) void batch_write_head_kernel(BatchHead h, BatchHead *__restrict__ dst) {
+    const int *src = reinterpret_cast<const int *>(&h);
+    int *out = reinterpret_cast<int *>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(BatchHead) / sizeof(int)); i += blockDim.x) out[i] = src[i];
+}
+
+// Host side of the writers: `imgs` (host) -> table.img[0 .. k_images), `head` -> table.head.
+void write_batch_table(const BatchTable &table, const BatchImage *imgs, int k_images, const BatchHead &head,
+                       hipStream_t st) {
+    BatchPack pack;
+    for (int k0 = 0; k0 < k_images; k0 += GI2D_BATCH_PACK) {
+        const int cnt = k_images - k0 < GI2D_BATCH_PACK ? k_images - k0 : GI2D_BATCH_PACK;
+        for (int i = 0; i < cnt; ++i) pack.img[i] = imgs[k0 + i];
+        hipLaunchKernelGGL(batch_write_images_kernel, dim3(1), dim3(256), 0, st, pack, cnt, table.img + k0);
+    }
+    hipLaunchKernelGGL(batch_write_head_kernel, dim3(1), dim3(256), 0, st, head, table.head);
+}
+
 }  // namespace gi2d
 
 using namespace gi2d;
+
+// kind x (more iterations follow: the update kernel also starts the next one) x optimizer -> GI2D_LAUNCH_RU(K, F, A)
+#define GI2D_DISPATCH_RU2(K, more, adan) \
+    do {                                  \
+        if (more) {                       \
+            if (adan)                     \
+                GI2D_LAUNCH_RU(K, true, true);   \
+            else                          \
+                GI2D_LAUNCH_RU(K, true, false);  \
+        } else {                          \
+            if (adan)                     \
+                GI2D_LAUNCH_RU(K, false, true);  \
+            else                          \
+                GI2D_LAUNCH_RU(K, false, false); \
+        }                                 \
+    } while (0)
+#define GI2D_DISPATCH_RU(kind, more, adan)           \
+    do {                                             \
+        if ((kind) == 2)                             \
+            GI2D_DISPATCH_RU2(kScaleRot, more, adan);   \
+        else if ((kind) == 0)                        \
+            GI2D_DISPATCH_RU2(kCholesky, more, adan);   \
+        else                                         \
+            GI2D_DISPATCH_RU2(kCovariance, more, adan); \
+    } while (0)
 
 extern "C" {
 
@@ -1078,23 +1159,54 @@ static int train_check(const gi2d_train_state *s, int &tx, int &ty) {
     return GI2D_OK;
 }
 
-static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w, const TrainParams &P, int tx,
+// One image's argument block of the per-gaussian fitting kernels (gi2d_batch.h).
+static UpdateArgs update_args_of(const gi2d_train_state *s, const FastWs &w, int tx, int ty) {
+    UpdateArgs u;
+    const int n = s->num_points;
+    u.n = n;
+    u.P = params_of(s);
+    u.xys = (float2 *)s->xys;
+    u.radii = s->radii;
+    u.conics = s->conics;
+    u.tiles_x = tx, u.tiles_y = ty;
+    u.radius_clip = s->radius_clip;
+    u.gids_sorted = w.gids_sorted;
+    u.tile_bins = (const int2 *)w.tile_bins;
+    u.partial_g = w.partial_g;
+    u.partial_big = w.partial_big;
+    u.img_w = (float)s->img_width, u.img_h = (float)s->img_height;
+    u.dbg_grads = s->dbg_grads;
+    u.best.xyz = s->best_xyz;
+    u.best.chol = s->best_chol;
+    u.best.feat = s->best_feat;
+    u.best.bound = s->bound_stride ? s->best_bound : nullptr;
+    u.best.sse = s->best_sse;
+    u.best.info = s->best_info;
+    u.best.tile_sse = s->tile_sse;
+    u.best.num_tiles = tx * ty;
+    u.best.step = 0;
+    u.next.clip_coe = s->clip_coe;
+    u.next.num_tiles_hit = s->num_tiles_hit;
+    u.next.lists = w.lists;
+    u.next.prev_box = w.prev_box;
+    u.next.recs = rec_sets(w, n);
+    u.next.status = s->status;
+    u.next.tile_order = w.tile_order;
+    return u;
+}
+
+static void train_launch_project_fill(const gi2d_train_state *s, const FastWs &w, const TrainParams &, int tx,
                                       int ty, hipStream_t st) {
     const int n = s->num_points;
     const int bs = per_gaussian_block(n);
     const dim3 gg((n + bs - 1) / bs), bb(bs);
+    const UpdateArgs u = update_args_of(s, w, tx, ty);
     if (s->kind == 2)
-        hipLaunchKernelGGL(train_project_fill_kernel<kScaleRot>, gg, bb, 0, st, n, s->clip_coe, P,
-                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
+        hipLaunchKernelGGL(train_project_fill_kernel<kScaleRot>, gg, bb, 0, st, u);
     else if (s->kind == 0)
-        hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, n, s->clip_coe, P,
-                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
+        hipLaunchKernelGGL(train_project_fill_kernel<kCholesky>, gg, bb, 0, st, u);
     else
-        hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, n, s->clip_coe, P,
-                           (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys,
-                           s->radii, s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
+        hipLaunchKernelGGL(train_project_fill_kernel<kCovariance>, gg, bb, 0, st, u);
 }
 
 
@@ -1306,14 +1418,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         }
         return check_launch("train steps (quantised)");
     }
-    NextFill next;
-    next.clip_coe = s->clip_coe;
-    next.num_tiles_hit = s->num_tiles_hit;
-    next.lists = w.lists;
-    next.prev_box = w.prev_box;
-    next.recs = rec_sets(w, n);
-    next.status = s->status;
-    next.tile_order = w.tile_order;
+    const UpdateArgs u = update_args_of(s, w, tx, ty);
     const int bs = per_gaussian_block(n);
     const dim3 gg((n + bs - 1) / bs + 1), bb(bs);  // + 1: the workgroup that orders the tiles
     train_launch_project_fill(s, w, P, tx, ty, st);
@@ -1325,38 +1430,10 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         if (rc != GI2D_OK) return rc;
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s->beta3, eps, step, adan_opt);
-        best.step = step;
         const bool more = it + 1 < count;
-#define GI2D_LAUNCH_RU(K, F, A)                                                                                      \
-    hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A>), gg, bb, 0, st, n, P, (float2 *)s->xys, s->radii,        \
-                       s->conics, tx, ty, s->radius_clip, (const int2 *)w.prev_box, w.gids_sorted,                    \
-                       (const int2 *)w.tile_bins, w.partial_g,                                                        \
-                       w.partial_big, (float)s->img_width, (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, \
-                       next)
-#define GI2D_LAUNCH_RU2(K, F) \
-    do {                      \
-        if (adan_opt)         \
-            GI2D_LAUNCH_RU(K, F, true); \
-        else                  \
-            GI2D_LAUNCH_RU(K, F, false); \
-    } while (0)
-        if (s->kind == 2) {
-            if (more)
-                GI2D_LAUNCH_RU2(kScaleRot, true);
-            else
-                GI2D_LAUNCH_RU2(kScaleRot, false);
-        } else if (s->kind == 0) {
-            if (more)
-                GI2D_LAUNCH_RU2(kCholesky, true);
-            else
-                GI2D_LAUNCH_RU2(kCholesky, false);
-        } else {
-            if (more)
-                GI2D_LAUNCH_RU2(kCovariance, true);
-            else
-                GI2D_LAUNCH_RU2(kCovariance, false);
-        }
-#undef GI2D_LAUNCH_RU2
+#define GI2D_LAUNCH_RU(K, F, A) \
+    hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A>), gg, bb, 0, st, u, a[0], a[1], a[2], step)
+        GI2D_DISPATCH_RU(s->kind, more, adan_opt);
 #undef GI2D_LAUNCH_RU
     }
     return check_launch("train steps");
@@ -1365,6 +1442,104 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
 int gi2d_train_step(const gi2d_train_state *s, const double *lr, double beta1, double beta2, float eps, int step,
                     gi2d_stream_t st) {
     return gi2d_train_steps(s, lr, beta1, beta2, eps, step, 1, st);
+}
+
+// ---------------------------------------------------------------------------------------------- several images per launch
+size_t gi2d_batch_bytes(int num_images) { return carve_batch(nullptr, num_images).bytes; }
+
+int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *states, void *batch, size_t batch_bytes,
+                             const double *lr, double beta1, double beta2, float eps, int first_step, int count,
+                             gi2d_stream_t st_) {
+    hipStream_t st = (hipStream_t)st_;
+    if (num_images < 1 || num_images > GI2D_BATCH_MAX || !states) {
+        set_error("train steps (batched): 1 .. 64 images per launch");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    if (!batch || batch_bytes < gi2d_batch_bytes(num_images) || ((uintptr_t)batch & 15)) {
+        set_error("train steps (batched): batch table too small (gi2d_batch_bytes) or not 16-byte aligned");
+        return GI2D_ERR_WORKSPACE_TOO_SMALL;
+    }
+    if (count <= 0) return GI2D_OK;
+    if (!lr || first_step < 1) {
+        set_error("train steps (batched): bad lr/step");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    const gi2d_train_state *s0 = states[0];
+    BatchHead head;
+    std::memset(&head, 0, sizeof(head));
+    long long total_n = 0;
+    bool uniform = true;
+    int tiles0 = 0;
+    for (int k = 0; k < num_images; ++k) {
+        const gi2d_train_state *s = states[k];
+        int tx, ty;
+        int rc = train_check(s, tx, ty);
+        if (rc != GI2D_OK) return rc;
+        if (s->kind != s0->kind || s->optimizer != s0->optimizer || s->beta3 != s0->beta3 || s->quant ||
+            s->optimizer < 0 || s->optimizer > 1) {
+            set_error("train steps (batched): the images of a batch share model kind and optimizer; quantisation-aware "
+                      "iterations are single-image calls");
+            return GI2D_ERR_UNSUPPORTED;
+        }
+        if (s->optimizer == 1 && (!s->d_xyz || !s->d_chol || !s->d_feat || !s->pg_xyz || !s->pg_chol || !s->pg_feat)) {
+            set_error("train steps (batched): Adan without its extra state (d_*, pg_*)");
+            return GI2D_ERR_INVALID_ARGUMENT;
+        }
+        if (s->best_sse && (!s->best_xyz || !s->best_chol || !s->best_feat || !s->best_info ||
+                            (s->bound_stride && !s->best_bound))) {
+            set_error("train steps (batched): best_sse given without the snapshot buffers");
+            return GI2D_ERR_INVALID_ARGUMENT;
+        }
+        total_n += s->num_points;
+        if (k == 0) tiles0 = tx * ty;
+        uniform = uniform && tx * ty == tiles0;
+    }
+    const bool adan_opt = s0->optimizer == 1;
+    const int bs = per_gaussian_block((int)(total_n > 0x7fffffff ? 0x7fffffff : total_n));
+    BatchTable b = carve_batch(batch, num_images);
+    // the table: tile-pass and per-gaussian workgroup ranges, one argument block per image
+    int tile_blocks = 0, pg_blocks = 0;
+    std::vector<BatchImage> host_imgs((size_t)num_images);
+    for (int k = 0; k < num_images; ++k) {
+        const gi2d_train_state *s = states[k];
+        const int tx = (s->img_width + GI2D_TILE - 1) / GI2D_TILE, ty = (s->img_height + GI2D_TILE - 1) / GI2D_TILE;
+        const int n = s->num_points;
+        FastWs w = carve_fast(s->workspace, n, tx * ty);
+        const float grad_scale = 2.f / (3.f * (float)s->img_height * (float)s->img_width);
+        host_imgs[k].t = tile_pass_args(w, n, tx, ty, s->img_width, s->img_height, s->status, s->out_img, s->gt,
+                                        grad_scale, s->tile_sse);
+        host_imgs[k].u = update_args_of(s, w, tx, ty);
+        head.tile_start[k] = tile_blocks;
+        head.pg_start[k] = pg_blocks;
+        tile_blocks += tx * ty;
+        pg_blocks += (n + bs - 1) / bs + 1;  // + 1: the workgroup that orders the tiles
+    }
+    head.tile_start[num_images] = tile_blocks;
+    head.pg_start[num_images] = pg_blocks;
+    write_batch_table(b, host_imgs.data(), num_images, head, st);
+    const BatchImage *imgs = b.img;
+    const int *pg_start = b.head->pg_start;
+    const dim3 gg((unsigned)pg_blocks), bb(bs);
+    if (s0->kind == 2)
+        hipLaunchKernelGGL(train_project_fill_batched_kernel<kScaleRot>, gg, bb, 0, st, imgs, pg_start, num_images);
+    else if (s0->kind == 0)
+        hipLaunchKernelGGL(train_project_fill_batched_kernel<kCholesky>, gg, bb, 0, st, imgs, pg_start, num_images);
+    else
+        hipLaunchKernelGGL(train_project_fill_batched_kernel<kCovariance>, gg, bb, 0, st, imgs, pg_start, num_images);
+    for (int it = 0; it < count; ++it) {
+        const int step = first_step + it;
+        int rc = launch_tile_pass_batched(1, b, num_images, tile_blocks, uniform ? tiles0 : 0, st);
+        if (rc != GI2D_OK) return rc;
+        AdamStep a[3];
+        for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s0->beta3, eps, step, adan_opt);
+        const bool more = it + 1 < count;
+#define GI2D_LAUNCH_RU(K, F, A)                                                                                       \
+    hipLaunchKernelGGL((train_reduce_update_batched_kernel<K, F, A>), gg, bb, 0, st, imgs, pg_start, num_images, a[0], \
+                       a[1], a[2], step)
+        GI2D_DISPATCH_RU(s0->kind, more, adan_opt);
+#undef GI2D_LAUNCH_RU
+    }
+    return check_launch("train steps (batched)");
 }
 
 }  // extern "C"

@@ -79,10 +79,13 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
                       seed: int = 3047, eval_renders: int = 10, kind: str = "cholesky", max_points: int = 0,
                       prune_iter: int = 100, grow_iter: int = 5000, eps: float = 1e-8,
                       chunk: int = 16, optimizer: str = "adam", quantize: bool = False, warmup_iter: int = 6000,
-                      bits=(12, 10, 6), threaded: bool = False) -> List[Dict[str, float]]:
-    """Fit the images of `gts` CONCURRENTLY on one GPU, one HIP stream each, on the fused training iteration
-    (trainer.NativeFitter -> gi2d_train_step: one C-ABI call, three kernel launches, no host synchronisation per
-    iteration).  One image's kernels leave most of the chip idle between their dependent phases, so
+                      bits=(12, 10, 6), threaded: bool = False, batched: bool = False) -> List[Dict[str, float]]:
+    """Fit the images of `gts` CONCURRENTLY on one GPU on the fused training iteration (trainer.NativeFitter ->
+    gi2d_train_step: one C-ABI call, three kernel launches, no host synchronisation per iteration).  With `batched`
+    (plain fitting, not the quantised loop) the images run in lockstep and every kernel of an iteration is launched ONCE
+    for all of them (trainer.BatchFitter -> gi2d_train_steps_batched): their tile passes overlap inside one launch,
+    which separate launches on separate streams do not (a 768x512 tile pass fills every wave slot of the chip).
+    Otherwise one HIP stream per image:  One image's kernels leave most of the chip idle between their dependent phases, so
     two to four independent images per GPU raise the aggregate iteration rate by 1.4-3.6x (the smaller the model,
     the more); `chunk` iterations of one image are enqueued before the host turns to the next, or, with `threaded`,
     every image has its own host thread (the C-ABI calls release the GIL).  With `max_points` > `num_points` (covariance model)
@@ -91,7 +94,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
     With `quantize` (covariance model) the loop is train_quantize.py's: plain fitting up to `warmup_iter`, then
     quantisation-aware iterations with `bits` = (xy, covariance, colour) bit depths; the result rows then also carry
     the size of the encoding in bits per pixel (analysis_wo_ec) and the PSNR of the decoded image."""
-    from .trainer import NativeFitter
+    from .trainer import BatchFitter, NativeFitter
 
     dev = gts[0].device
     adaptive = kind == "covariance" and max_points > num_points
@@ -102,17 +105,26 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
                             max_points=max_points if adaptive else None, track_best=adaptive or quantize,
                             device_resident=adaptive)
                for gt in gts]
-    streams = [torch.cuda.Stream(device=dev) for _ in fitters] if len(fitters) > 1 else [torch.cuda.current_stream(dev)]
+    batched = bool(batched) and len(fitters) > 1 and not quantize
+    streams = ([torch.cuda.Stream(device=dev) for _ in fitters] if len(fitters) > 1 and not batched
+               else [torch.cuda.current_stream(dev)] * len(fitters))
     torch.cuda.synchronize(dev)
     t0 = time.time()
     sched_kw = dict(prune_iter=prune_iter, grow_iter=grow_iter, adaptive_add=adaptive,
                     max_points=max_points if adaptive else None,
                     chunk=chunk if (len(fitters) > 1 and not threaded) else None)
-    if quantize:
+    if batched:
+        sched_kw["chunk"] = None
+        runs = []
+        with torch.cuda.device(dev):
+            BatchFitter(fitters).fit(iterations, **sched_kw)
+    elif quantize:
         runs = [f.fit_quantize_schedule(iterations, warmup_iter, bits=bits, **sched_kw) for f in fitters]
     else:
         runs = [f.fit_schedule(iterations, **sched_kw) for f in fitters]
-    if threaded and len(fitters) > 1:
+    if batched:
+        pass
+    elif threaded and len(fitters) > 1:
         # one host thread per image: the C-ABI calls release the GIL, so the launches of different images are issued
         # in parallel instead of round-robin from one thread (which becomes the limit beyond ~4 small images)
         import threading
@@ -271,9 +283,13 @@ def main(argv=None):
     ap.add_argument("--prune_iter", type=int, default=100)
     ap.add_argument("--grow_iter", type=int, default=5000)
     ap.add_argument("--images_per_gpu", type=int, default=1,
-                    help="images fitted concurrently on each GPU (one HIP stream and one host thread each; native loop)")
+                    help="images fitted concurrently on each GPU (native loop): in lockstep with one launch per kernel for "
+                         "all of them, or, with --streams / --quantize, one HIP stream and one host thread each")
     ap.add_argument("--single_host_thread", action="store_true",
                     help="issue the concurrent images' launches round-robin from one host thread instead")
+    ap.add_argument("--streams", action="store_true",
+                    help="fit the --images_per_gpu concurrent images on one HIP stream each instead of in batched launches "
+                         "(gi2d_train_steps_batched: one launch per kernel for all of them, the default for plain fitting)")
     ap.add_argument("--quantize", action="store_true",
                     help="train_quantize.py's loop (covariance model, or scale_rot with that model's quantiser set): "
                          "plain fitting up to --warmup_iter, then quantisation-aware iterations; reports bits per pixel "
@@ -341,7 +357,7 @@ def main(argv=None):
 
     def fit_group(idx, imgs):
         res = fit_images_native([im.to(dev) for im in imgs], args.num_points, args.iterations,
-                                threaded=not args.single_host_thread, **native_kw)
+                                threaded=not args.single_host_thread, batched=not args.streams, **native_kw)
         for i, im, r in zip(idx, imgs, res):
             report(i, im, r)
         return res

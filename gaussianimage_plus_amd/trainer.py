@@ -696,6 +696,41 @@ class NativeFitter:
                                                 torch.ones(n, 1, device=self.dev), self.h, self.w, 16, 16)
         return out.clamp(0, 1)
 
+    def _next_stop(self, local: int, end_local: int, prune_iter: int, grow_iter: int, adaptive_add: bool,
+                   chunk: Optional[int]) -> int:
+        """Iteration (counted from the start of the schedule) up to which training can be issued back to back: the next
+        prune check, growth step, chunk boundary or the end."""
+        nxt = end_local
+        if self.kind == "covariance":
+            nxt = min(nxt, (local // prune_iter + 1) * prune_iter)
+            if adaptive_add:
+                nxt = min(nxt, (local // grow_iter + 1) * grow_iter)
+        if chunk:
+            nxt = min(nxt, local + int(chunk))
+        return nxt
+
+    def _schedule_events(self, local: int, total: int, prune_iter: int, grow_iter: int, adaptive_add: bool,
+                         max_points: Optional[int], log) -> None:
+        """What train.py:147-152 does after iteration `local`: prune every `prune_iter`, grow every `grow_iter`."""
+        if self.kind != "covariance":
+            return
+        if local % prune_iter == 0:
+            pruned = self.prune_non_definite()
+            if pruned and log:
+                log(f"iter {local}: pruned {pruned} non-definite, {self.n} left")
+        if adaptive_add and local % grow_iter == 0 and local < total:
+            added = self.add_sample_positions(local, total, grow_iter, max_points)
+            if log:
+                log(f"iter {local}: growth step, at most {self.n} gaussians now" if added is None else
+                    f"iter {local}: added {added} gaussians, now {self.n}")
+
+    def _schedule_end(self, log) -> None:
+        if self.device_resident:
+            self.sync_population()
+            if log:
+                pruned, added = self.dens_counts.tolist()
+                log(f"population on the device: {self.n} gaussians live ({added} added, {pruned} pruned in all)")
+
     def fit_schedule(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
                      max_points: Optional[int] = None, log=None, chunk: Optional[int] = None,
                      total_iterations: Optional[int] = None):
@@ -708,33 +743,13 @@ class NativeFitter:
         start = self.iteration
         end = start + int(iterations)
         total = int(iterations) if total_iterations is None else int(total_iterations)
-        adaptive = self.kind == "covariance"
         while self.iteration < end:
             local = self.iteration - start
-            nxt = end - start
-            if adaptive:
-                nxt = min(nxt, (local // prune_iter + 1) * prune_iter)
-                if adaptive_add:
-                    nxt = min(nxt, (local // grow_iter + 1) * grow_iter)
-            if chunk:
-                nxt = min(nxt, local + int(chunk))
-            self.train(nxt - local)
+            self.train(self._next_stop(local, end - start, prune_iter, grow_iter, adaptive_add, chunk) - local)
             local = self.iteration - start
-            if adaptive and local % prune_iter == 0:
-                pruned = self.prune_non_definite()
-                if pruned and log:
-                    log(f"iter {local}: pruned {pruned} non-definite, {self.n} left")
-            if adaptive and adaptive_add and local % grow_iter == 0 and local < total:
-                added = self.add_sample_positions(local, total, grow_iter, max_points)
-                if log:
-                    log(f"iter {local}: growth step, at most {self.n} gaussians now" if added is None else
-                        f"iter {local}: added {added} gaussians, now {self.n}")
+            self._schedule_events(local, total, prune_iter, grow_iter, adaptive_add, max_points, log)
             yield local
-        if self.device_resident:
-            self.sync_population()
-            if log:
-                pruned, added = self.dens_counts.tolist()
-                log(f"population on the device: {self.n} gaussians live ({added} added, {pruned} pruned in all)")
+        self._schedule_end(log)
 
     def fit_quantize_schedule(self, iterations: int, warmup_iter: int, bits=(12, 10, 6), chunk: Optional[int] = None,
                               log=None, **kw):
@@ -770,5 +785,77 @@ class NativeFitter:
 
     def fit(self, iterations: int, **kw) -> None:
         """Run fit_schedule to the end (same keyword arguments)."""
+        for _ in self.fit_schedule(iterations, **kw):
+            pass
+
+
+class BatchFitter:
+    """K NativeFitters in lockstep, every kernel of an iteration launched ONCE for the whole batch
+    (gi2d_train_steps_batched; csrc/gi2d_batch.h): the per-image loop of train.py:294-308 for several images at a time.
+    One 768x512 image is exactly one residency round of tile workgroups, all in the same phase at once; K images in one
+    launch overlap each other's load latency and arithmetic, and the per-gaussian kernels (less than a wave per SIMD for
+    one image) fill the chip.  Every fitter's results are those of fitting it alone, bit for bit; prune / grow stay
+    per-image calls between the batched stretches.  The fitters share model kind, optimizer, learning-rate schedule and
+    iteration count; image sizes and populations may differ."""
+
+    def __init__(self, fitters):
+        assert 1 <= len(fitters) <= 64
+        f0 = fitters[0]
+        for f in fitters:
+            assert (f.kind, f.optimizer, f.lr, f.betas, f.eps, f.lr_step, f.lr_gamma, f.iteration, f.opt_start) == \
+                   (f0.kind, f0.optimizer, f0.lr, f0.betas, f0.eps, f0.lr_step, f0.lr_gamma, f0.iteration, f0.opt_start)
+            assert f.quant is None and f.dev == f0.dev
+        self.fitters = list(fitters)
+        self.lib, self.dev = f0.lib, f0.dev
+        k = len(self.fitters)
+        self.table = torch.empty(int(self.lib.gi2d_batch_bytes(k)), dtype=torch.uint8, device=self.dev)
+        self._states = (C.c_void_p * k)(*[C.addressof(f.state) for f in self.fitters])
+        self._lr3 = (C.c_double * 3)()
+        self._fn = self.lib.gi2d_train_steps_batched
+        self.max_call = 256
+
+    iteration = property(lambda self: self.fitters[0].iteration)
+
+    def train(self, iterations: int) -> None:
+        """`iterations` training iterations of every image (asynchronous: only kernel launches)."""
+        f0 = self.fitters[0]
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        b1, b2 = f0.betas[0], f0.betas[1]
+        left = int(iterations)
+        with torch.cuda.device(self.dev):
+            while left > 0:
+                lr = f0.current_lr()
+                self._lr3[0] = self._lr3[1] = self._lr3[2] = lr
+                done = f0.iteration - f0.opt_start
+                count = min(left, f0.lr_step - done % f0.lr_step, self.max_call)
+                rc = self._fn(len(self.fitters), self._states, self.table.data_ptr(), self.table.numel(), self._lr3,
+                              b1, b2, f0.eps, done + 1, count, st)
+                if rc != 0:
+                    f0._check(rc, "gi2d_train_steps_batched")
+                for f in self.fitters:
+                    f.iteration += count
+                left -= count
+
+    def fit_schedule(self, iterations: int, prune_iter: int = 100, grow_iter: int = 5000, adaptive_add: bool = True,
+                     max_points: Optional[int] = None, log=None, chunk: Optional[int] = None,
+                     total_iterations: Optional[int] = None):
+        """NativeFitter.fit_schedule for the whole batch (same arguments): the stretches between two events are batched
+        calls, the events (prune every `prune_iter`, grow every `grow_iter`) per-image calls on the same stream."""
+        f0 = self.fitters[0]
+        start = f0.iteration
+        end = start + int(iterations)
+        total = int(iterations) if total_iterations is None else int(total_iterations)
+        while f0.iteration < end:
+            local = f0.iteration - start
+            self.train(f0._next_stop(local, end - start, prune_iter, grow_iter, adaptive_add, chunk) - local)
+            local = f0.iteration - start
+            for i, f in enumerate(self.fitters):
+                f._schedule_events(local, total, prune_iter, grow_iter, adaptive_add, max_points,
+                                   (lambda m, i=i: log(f"[image {i}] {m}")) if log else None)
+            yield local
+        for f in self.fitters:
+            f._schedule_end(log)
+
+    def fit(self, iterations: int, **kw) -> None:
         for _ in self.fit_schedule(iterations, **kw):
             pass

@@ -299,6 +299,30 @@ int gi2d_fast_rasterize_forward_backward(int num_points, int tiles_x, int tiles_
                                          const float *v_output, const float *target, float grad_scale,
                                          float *tile_sse, void *workspace, size_t workspace_bytes,
                                          int32_t *status, float *out_img, gi2d_stream_t stream);
+/* Several images per launch.  The reference fits its images one after the other (train.py:294-308); BASELINE config 3
+ * is a batch of 24.  One 768x512 image is 1536 tile workgroups -- exactly one residency round of the chip, all in the
+ * same phase at the same time -- so K independent images in ONE launch (grid = sum of the images' tiles; a workgroup
+ * looks its image up in a table in HBM) overlap each other's load latency and arithmetic.  Every image's results are
+ * those of its own single-image call, bit for bit.
+ *   images  host array of per-image arguments, meaning as in gi2d_fast_rasterize_forward_backward (one binning call per
+ *           image before the pass, one workspace per image); exactly one of v_output / target per image, the same
+ *           kind for the whole batch
+ *   batch   device scratch of gi2d_batch_bytes(num_images) bytes (16-byte aligned): the table, rewritten by every call
+ *           with stream-ordered kernels; num_images <= 64. */
+typedef struct gi2d_fast_image {
+    int num_points, tiles_x, tiles_y;
+    unsigned img_width, img_height;
+    float grad_scale;
+    const float *v_output, *target;
+    float *tile_sse;
+    void *workspace;
+    size_t workspace_bytes;
+    int32_t *status;
+    float *out_img;
+} gi2d_fast_image;
+size_t gi2d_batch_bytes(int num_images);
+int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast_image *images, void *batch,
+                                                 size_t batch_bytes, gi2d_stream_t stream);
 int gi2d_fast_rasterize_backward_tiles(int num_points, int tiles_x, int tiles_y, unsigned img_width,
                                        unsigned img_height, const int32_t *final_idx,
                                        const float *v_output, int with_abs, void *workspace,
@@ -447,6 +471,15 @@ int gi2d_train_step(const gi2d_train_state *state, const double *lr_host, double
  * gaussians for the next one, so the call issues 2*count + 1 launches instead of 3*count. */
 int gi2d_train_steps(const gi2d_train_state *state, const double *lr_host, double beta1, double beta2,
                      float eps, int first_step, int count, gi2d_stream_t stream);
+/* The same iterations for `num_images` independent images in lockstep, every kernel launched ONCE for the whole batch
+ * (2*count + 1 launches plus the table writes, whatever num_images is): states[k] is image k's state (its own
+ * parameters, optimizer moments, target, workspace, best-model snapshot, device-resident population); all images share
+ * kind, optimizer, learning rates and step count; image sizes and populations may differ.  Results per image are those
+ * of gi2d_train_steps on that image alone, bit for bit.  Quantisation-aware iterations are single-image calls.
+ * batch: device scratch of gi2d_batch_bytes(num_images) bytes, rewritten by every call; num_images <= 64. */
+int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *states, void *batch, size_t batch_bytes,
+                             const double *lr_host, double beta1, double beta2, float eps, int first_step, int count,
+                             gi2d_stream_t stream);
 
 /* Population changes of a fit on the device (covariance model; state->num_points_dev required):
  *   gi2d_train_prune  non_semi_definite_prune (models/gaussianimage_covariance.py:352-382): rows whose covariance +

@@ -1,0 +1,185 @@
+"""GPU: several images per launch (gi2d_train_steps_batched, gi2d_fast_rasterize_forward_backward_batched;
+csrc/gi2d_batch.h) -- every image's results must be those of its own single-image calls, BIT FOR BIT: the batched
+kernels run the single-image kernels' code on an argument block picked by workgroup index."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+STATE_ROWS = ("xyz", "chol", "feat", "m_xyz", "v_xyz", "m_chol", "v_chol", "m_feat", "v_feat")
+
+
+def _fitters(kind, optimizer, sizes, track_best=True, **kw):
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    out = []
+    for i, (h, w, n) in enumerate(sizes):
+        gt = synthetic_image(h, w, 60 + i).to(DEV)
+        out.append(NativeFitter(gt, n, kind=kind, lr=0.01, seed=11 + i, optimizer=optimizer, track_best=track_best,
+                                eps=1e-15 if optimizer == "adan" else 1e-8, **kw))
+    return out
+
+
+def _assert_same(a, b, tag):
+    assert a.n == b.n and a.iteration == b.iteration, tag
+    for nm in STATE_ROWS + (("_d_xyz", "_pg_chol") if a.optimizer == "adan" else ()):
+        ta, tb = getattr(a, nm)[:a.n], getattr(b, nm)[:b.n]
+        assert torch.equal(ta, tb), f"{tag}: {nm} differs in {int((ta != tb).sum())} elements"
+    assert torch.equal(a.out_img, b.out_img), f"{tag}: render"
+    assert torch.equal(a.tile_sse, b.tile_sse), f"{tag}: per-tile squared errors"
+    assert torch.equal(a.xys[:a.n], b.xys[:b.n]) and torch.equal(a.radii[:a.n], b.radii[:b.n]), f"{tag}: projection"
+    if a.track_best:
+        assert torch.equal(a.best_sse, b.best_sse) and torch.equal(a.best_info, b.best_info), f"{tag}: best snapshot"
+        nb = int(a.best_info[0])
+        for nm in ("best_xyz", "best_chol", "best_feat"):
+            assert torch.equal(getattr(a, nm)[:nb], getattr(b, nm)[:nb]), f"{tag}: {nm}"
+
+
+# same tile count for every image (portrait + landscape: the batched kernel divides), and ragged mixes (table lookup)
+UNIFORM = [(96, 160, 1500), (160, 96, 2100), (96, 160, 700)]
+MIXED = [(96, 160, 1500), (50, 70, 400), (128, 128, 2500), (33, 200, 900)]
+
+
+@pytest.mark.parametrize("kind,optimizer,sizes", [("cholesky", "adan", UNIFORM), ("covariance", "adam", MIXED),
+                                                  ("scale_rot", "adam", MIXED), ("cholesky", "adam", MIXED[:1])])
+def test_batched_iterations_equal_single_image_calls(kind, optimizer, sizes):
+    """9 iterations as 1 + 3 + 5 (stretches: the update kernel also starts the next iteration) of K images in one
+    launch per kernel == the same iterations of every image alone."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    alone, together = _fitters(kind, optimizer, sizes), _fitters(kind, optimizer, sizes)
+    batch = BatchFitter(together)
+    for count in (1, 3, 5):
+        for f in alone:
+            f.train(count)
+        batch.train(count)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(alone, together)):
+        a.check_status(), b.check_status()
+        _assert_same(a, b, f"{kind}/{optimizer} image {i}")
+        assert int(a.best_info[1]) > 0  # a snapshot was taken: the decision logic ran
+
+
+def test_batched_adaptive_schedule_equals_single_image_schedules():
+    """The per-image loop of train.py:120-160 (prune every 10, grow every 20, population on the device) for three images
+    in lockstep == the three loops alone: populations, parameters, snapshots."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    sizes = [(96, 144, 400), (144, 96, 300), (64, 80, 350)]
+    kw = dict(max_points=3000, device_resident=True)
+    alone, together = _fitters("covariance", "adam", sizes, **kw), _fitters("covariance", "adam", sizes, **kw)
+    for f in alone:
+        f.fit(90, prune_iter=10, grow_iter=20)
+    BatchFitter(together).fit(90, prune_iter=10, grow_iter=20)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(alone, together)):
+        a.check_status(), b.check_status()
+        assert a.n > sizes[i][2], "the schedule must have grown the population"
+        _assert_same(a, b, f"adaptive image {i}")
+        assert torch.equal(a.dens_counts, b.dens_counts)
+
+
+def test_batched_launcher_equals_streams_launcher():
+    """launch.fit_images_native with batched=True (one launch per kernel for all images) gives every image the result of
+    the K-streams form."""
+    from gaussianimage_plus_amd.launch import fit_images_native, synthetic_image
+    gts = [synthetic_image(96, 144, 40 + i).to(DEV) for i in range(3)]
+    kw = dict(lr=0.018, kind="covariance", max_points=1800, prune_iter=50, grow_iter=100, eps=1e-15, eval_renders=1)
+    a = fit_images_native(gts, 1200, 350, batched=False, **kw)
+    b = fit_images_native(gts, 1200, 350, batched=True, **kw)
+    for ra, rb in zip(a, b):
+        assert ra["mse"] == rb["mse"] and ra["num_gaussians"] == rb["num_gaussians"]
+        assert ra["psnr"] > 20
+
+
+class _FastImage(C.Structure):
+    """struct gi2d_fast_image (include/gi2d.h), field for field."""
+    _fields_ = [("num_points", C.c_int), ("tiles_x", C.c_int), ("tiles_y", C.c_int), ("img_width", C.c_uint),
+                ("img_height", C.c_uint), ("grad_scale", C.c_float), ("v_output", C.c_void_p), ("target", C.c_void_p),
+                ("tile_sse", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("status", C.c_void_p), ("out_img", C.c_void_p)]
+
+
+@pytest.mark.parametrize("given", [True, False])
+def test_batched_tile_pass_equals_single_image_passes(given):
+    """gi2d_fast_rasterize_forward_backward_batched on three scenes == three gi2d_fast_rasterize_forward_backward calls:
+    images, per-tile errors and (after the reduce) all four gradients, with the gradient image given and with the L2
+    gradient formed from a target."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from helpers import synth_cholesky, synth_gt
+    from oracle import oracle as O
+    import gaussianimage_plus_amd.gsplat.cuda as _C
+    from gaussianimage_plus_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    scenes = []
+    for i, (h, w, n) in enumerate([(96, 160, 3000), (70, 50, 500), (128, 144, 6000)]):
+        xyz, L, col, op = synth_cholesky(n, h, w, 3 + i)
+        tb = O.tile_bounds(h, w)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+        xys, depths, radii, conics, nth = _C.project_gaussians_2d_forward(n, 3.0, t(xyz), t(L), h, w, tb, 0.01, 1.0, False)
+        rng = np.random.default_rng(i)
+        aux = t(rng.normal(size=(h, w, 3)).astype(np.float32) / (h * w)) if given else t(synth_gt(h, w, 9 + i))
+        scenes.append(dict(h=h, w=w, n=n, tb=tb, xys=xys, radii=radii, conics=conics, col=t(col), op=t(op), aux=aux))
+
+    def run(batched):
+        res, imgs = [], (_FastImage * len(scenes))()
+        for k, sc in enumerate(scenes):
+            ws = _C.FastWorkspace(sc["n"], sc["tb"], sc["xys"])
+            out = torch.empty(sc["h"], sc["w"], 3, device=DEV)
+            sse = torch.zeros(sc["tb"][0] * sc["tb"][1], device=DEV)
+            _lib.call("gi2d_fast_bin", sc["n"], sc["xys"].data_ptr(), sc["radii"].data_ptr(), sc["conics"].data_ptr(),
+                      sc["col"].data_ptr(), sc["op"].data_ptr(), sc["tb"][0], sc["tb"][1], 1.0, ws.buf.data_ptr(),
+                      ws.buf.numel(), ws.status.data_ptr(), st)
+            gs = 2.0 / (3.0 * sc["h"] * sc["w"])
+            if batched:
+                imgs[k] = _FastImage(sc["n"], sc["tb"][0], sc["tb"][1], sc["w"], sc["h"], 0.0 if given else gs,
+                                     sc["aux"].data_ptr() if given else None, None if given else sc["aux"].data_ptr(),
+                                     None if given else sse.data_ptr(), ws.buf.data_ptr(), ws.buf.numel(),
+                                     ws.status.data_ptr(), out.data_ptr())
+            else:
+                _lib.call("gi2d_fast_rasterize_forward_backward", sc["n"], sc["tb"][0], sc["tb"][1], sc["w"], sc["h"],
+                          None, sc["aux"].data_ptr() if given else None, None if given else sc["aux"].data_ptr(),
+                          0.0 if given else gs, None if given else sse.data_ptr(), ws.buf.data_ptr(), ws.buf.numel(),
+                          ws.status.data_ptr(), out.data_ptr(), st)
+            res.append(dict(ws=ws, out=out, sse=sse))
+        if batched:
+            table = torch.empty(int(lib.gi2d_batch_bytes(len(scenes))), dtype=torch.uint8, device=DEV)
+            _lib.call("gi2d_fast_rasterize_forward_backward_batched", len(scenes), imgs, table.data_ptr(), table.numel(),
+                      st)
+        for sc, r in zip(scenes, res):
+            g = [torch.empty(sc["n"], c, device=DEV) for c in (2, 3, 3, 1)]
+            _lib.call("gi2d_fast_rasterize_backward_reduce", sc["n"], sc["tb"][0], sc["tb"][1], r["ws"].buf.data_ptr(),
+                      r["ws"].buf.numel(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), None, st)
+            r["grads"] = g
+        torch.cuda.synchronize()
+        return res
+
+    for k, (a, b) in enumerate(zip(run(False), run(True))):
+        assert a["ws"].status.tolist()[:2] == b["ws"].status.tolist()[:2] == [1, 0]
+        assert torch.equal(a["out"], b["out"]), f"scene {k}: image"
+        assert torch.equal(a["sse"], b["sse"]), f"scene {k}: tile errors"
+        for ga, gb in zip(a["grads"], b["grads"]):
+            assert torch.equal(ga, gb) and bool(torch.isfinite(ga).all()), f"scene {k}: gradients"
+        assert float(a["grads"][2].abs().sum()) > 0
+
+
+def test_batched_entry_rejects_bad_batches():
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    a = _fitters("cholesky", "adam", [(64, 64, 200)])[0]
+    b = _fitters("covariance", "adam", [(64, 64, 200)])[0]
+    lib = _lib.load()
+    table = torch.empty(int(lib.gi2d_batch_bytes(2)), dtype=torch.uint8, device=DEV)
+    states = (C.c_void_p * 2)(C.addressof(a.state), C.addressof(b.state))
+    lr3 = (C.c_double * 3)(1e-3, 1e-3, 1e-3)
+    rc = lib.gi2d_train_steps_batched(2, states, table.data_ptr(), table.numel(), lr3, 0.9, 0.999, 1e-8, 1, 1, None)
+    assert rc != 0 and b"share model kind" in lib.gi2d_last_error_string()
+    rc = lib.gi2d_train_steps_batched(2, states, table.data_ptr(), 64, lr3, 0.9, 0.999, 1e-8, 1, 1, None)
+    assert rc != 0 and b"batch table" in lib.gi2d_last_error_string()
+    with pytest.raises(AssertionError):
+        BatchFitter([a, b])

@@ -81,6 +81,8 @@ class _ScheduleProbe:
         from gaussianimage_plus_amd.trainer import NativeFitter
         self.iteration, self.n, self.events, self.switched_at = 0, n0, [], None
         self.fit_schedule = NativeFitter.fit_schedule.__get__(self)
+        for nm in ("_next_stop", "_schedule_events", "_schedule_end"):  # the pieces fit_schedule is made of
+            setattr(self, nm, getattr(NativeFitter, nm).__get__(self))
         self.fit_quantize_schedule = NativeFitter.fit_quantize_schedule.__get__(self)
 
     def train(self, k):
