@@ -1,16 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- the driver's measurement contract for the 2D-Gaussian hot path.
 
-One STEP = one pass of the hot path over one image's gaussians, everything resident in HBM:
-    project_gaussians_2d (fwd) -> tile binning -> rasterize_sum forward
-    -> L2-loss gradient of the rendered image -> rasterize_sum backward -> project_gaussians_2d (bwd)
-i.e. the work one training iteration of models/gaussianimage_cholesky.py:302-317 hands to the `gsplat`
-operator surface, with the gradient image derived from the step's own render exactly as loss.backward() does
-(clamp + MSE against a fixed synthetic target).  tanh / +bound / the optimizer are not part of the metric
-(BASELINE.json: "training iters/sec (fwd+bwd rasterize)"); they are in the separate `train_step` figure.
-In the timed loop a step is two launches, as in the training loop: the tile pass, then one kernel that finishes the
-step (gradient reduce + project backward) and projects + bins the gaussians for the next one (HotPath.step); every
-timed step contains exactly one of each operation.
+One STEP = one training iteration of models/gaussianimage_cholesky.py:302-317 for one image, everything resident in HBM
+and every parameter MOVING (the optimizer is on):
+    tanh / +bound -> project_gaussians_2d (fwd) -> tile binning -> rasterize_sum forward
+    -> L2-loss gradient of the render -> rasterize_sum backward -> project_gaussians_2d (bwd) -> tanh' -> Adam
+as gi2d_train_steps issues it: per step two launches -- the tile pass (rasterize forward + loss gradient + backward), then
+one kernel that finishes the step (gradient reduce, projection backward, Adam) and projects + bins the updated gaussians
+for the next one.  The timed region is ONE call of exactly K iterations.  (Rounds 1-2 timed a loop over FROZEN
+parameters, where the incremental binning has nothing to append; that figure is still reported, as
+`static_scene_step`.)
 
 N GPUs (`--gpus N`): one process per GPU, one independent image per rank (images shard embarrassingly,
 no data-path collective) -> weak scaling; value = ranks * K / max-over-ranks time.  Launched by the driver under
@@ -18,9 +17,14 @@ torch.distributed.run the ranks come from RANK/LOCAL_RANK/WORLD_SIZE; launched b
 WORLD_SIZE unset) this file starts the N ranks itself as child processes -- the parent never touches the GPU -- and
 relays rank 0's JSON line.
 
+`batched`: the same iteration for K = 4 / 8 / 24 images in lockstep, every kernel launched once for all of them
+(gi2d_train_steps_batched) -- how BASELINE config 3 (a 24-image batch) is fitted; roofline on K x algorithmic bytes.
+
 The second BASELINE metric, "Kodak images/sec at 1/2/4/8 GPU", is the `images_per_s` block of the same line: the
-per-image loop of train.py:294-340 (covariance model, prune / grow schedule, best model on the device) over 24
-Kodak-shaped synthetic images sharded image i -> rank i mod N, one all-reduce for the "Average:" figures.
+per-image loop of train.py:294-340 (covariance model, prune / grow schedule, best model on the device) over the 24
+Kodak pictures (tests/golden/kodak24.npz: pixels of datasets/kodak/kodim01..24.png), 50 000 iterations each
+(train.py:204), sharded image i -> rank i mod N, each rank's images fitted as one batch, one all-reduce for the
+"Average:" figures.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -51,16 +55,19 @@ def parse(argv=None):
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--images", type=int, default=24,
-                   help="images of the images/sec leg (Kodak-24 shaped: 768x512 synthetic pictures); 0 skips the leg")
-    p.add_argument("--image-iterations", type=int, default=10000,
-                   help="training iterations per image in the images/sec leg (the reference's default is 50000)")
-    p.add_argument("--images-per-gpu", type=int, default=4,
-                   help="images fitted concurrently on each GPU in the images/sec leg (one HIP stream + host thread each)")
+                   help="images of the images/sec leg (the first so many of Kodak-24); 0 skips the leg")
+    p.add_argument("--image-iterations", type=int, default=50000,
+                   help="training iterations per image in the images/sec leg (train.py:204: 50000)")
+    p.add_argument("--images-per-gpu", type=int, default=24,
+                   help="images of a rank fitted as ONE batch in the images/sec leg (gi2d_train_steps_batched)")
+    p.add_argument("--synthetic-images", action="store_true",
+                   help="images/sec leg on Kodak-shaped synthetic pictures instead of the Kodak fixture")
+    p.add_argument("--no-batched", action="store_true", help="skip the `batched` block")
     p.add_argument("--images-per-gpu-probe", action="store_true",
                    help="also report the aggregate step rate of 2, 3 and 4 independent images stepped concurrently on "
                         "separate HIP streams of this GPU (extra information, not `value`)")
     p.add_argument("--train-step", action="store_true",
-                   help="also time the whole training iteration (gi2d_train_step) after the timed region")
+                   help="also time the quantisation-aware iterations of BASELINE config 5 after the timed region")
     return p.parse_args(argv)
 
 
@@ -123,19 +130,19 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
+    import math
     from helpers import synth_cholesky, synth_gt
-    from gaussianimage_plus_amd.hotpath import HotPath
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.trainer import NativeFitter
 
     n, h, w = args.num_points, args.height, args.width
-    xyz, L, col, op = synth_cholesky(n, h, w, 3047 + rank)  # reference default seed (train.py:225) + rank
-    hp = HotPath(n, h, w, device=dev)
-    hp.set_inputs(xyz, L, col, op)
-    # every step renders, forms the L2 gradient against a seeded smooth target and back-propagates it
-    gt_np = synth_gt(h, w, 1 + rank)
+    # positions atanh(U), Cholesky rows U[0,1) + the low-pass bound, colours U[0,1) (the reference starts
+    # them at zero; random ones exercise every branch from the first step), opacity 1; reference default seed + rank
+    xyz, L, col, op = synth_cholesky(n, h, w, 3047 + rank)
+    gt_np = synth_gt(h, w, 1 + rank)  # seeded smooth target image
     gt = torch.from_numpy(gt_np).to(dev)
-    hp.set_target(gt)
-    hp.forward()
-    m = hp.num_intersects()
+    fit = make_fitter(gt, xyz, L, col, n, h, w)
+    fit.max_call = 1 << 30  # the timed region is one C-ABI call
 
     def barrier():
         if world > 1:
@@ -145,22 +152,22 @@ def run_rank(args):
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        hp.step()
+    if args.warmup > 0:
+        fit.train(args.warmup)
     barrier()
-    # HIP start/stop events attached to the rasterizer tile-pass dispatch (gi2d_timer_*: the kernel's own begin/end
-    # timestamps on the launch stream), on every EVENT_STRIDE-th step of the timed region
-    n_timed = max(1, args.steps // EVENT_STRIDE)
-    ev = hp.kernel_timers(n_timed)
+    # HIP start/stop events attached to the tile-pass dispatch (gi2d_timer_*: the kernel's own begin/end timestamps on
+    # the launch stream), on every EVENT_STRIDE-th iteration of the timed region
+    timers = _lib.TilePassTimers(max(1, args.steps // EVENT_STRIDE))
+    timers.arm(EVENT_STRIDE)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % EVENT_STRIDE == 0 and i // EVENT_STRIDE < n_timed:
-            hp.step(timer=ev, index=i // EVENT_STRIDE)
-        else:
-            hp.step()
+    fit.train(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    hp.check_status()
+    timers.cancel()
+    fit.check_status()
+    kernel_us = timers.us()
+    timers.close()
+    m = int(fit.nth[:n].sum().item())  # tile intersections of the last projection (drifts as the gaussians move)
 
     red_dev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -174,10 +181,11 @@ def run_rank(args):
     images = images_per_s(args, rank, world, dev, red_dev, barrier) if args.images > 0 else None
 
     if rank == 0:
-        dom = hp.dominant_kernel_stats(ev)  # name, avg_us, algorithmic bytes per launch
-        achieved = dom["bytes"] / (dom["avg_us"] * 1e-6) / 1e9
+        avg_us = float(np.mean(kernel_us))
         pair_bytes = 80 * m + 36 * h * w + 36 * n  # SURVEY 8d north-star figure (fwd + bwd rasterize)
-        traffic, traffic_src = pmc_traffic(dom["name"], n, h, w)
+        achieved = pair_bytes / (avg_us * 1e-6) / 1e9
+        kernel = "gi2d::fast_fwdbwd_kernel<1>"
+        traffic, traffic_src = pmc_traffic(kernel, n, h, w)
         line = {
             "metric": f"training iters/sec (fwd+bwd rasterize) at N Gaussians, {w}x{h}",
             "value": value,
@@ -190,26 +198,39 @@ def run_rank(args):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if (args.images <= 0 or args.synthetic_images) else
+                    "synthetic (step metric, batched); kodak (images_per_s)",
             "config": {
-                "workload": f"Cholesky model, N={n} Gaussians, {w}x{h}, one image per GPU: project fwd + tile binning + "
-                            f"rasterize_sum fwd + L2 gradient of the render + rasterize_sum bwd + project bwd per step",
+                "workload": f"Cholesky model, N={n} Gaussians, {w}x{h}, one image per GPU, whole training iterations with "
+                            f"the optimizer ON (moving gaussians): tanh/+bound + project fwd + incremental tile binning + "
+                            f"rasterize_sum fwd + L2 gradient of the render + rasterize_sum bwd + project bwd + Adam per "
+                            f"step",
                 "num_points": n, "height": h, "width": w, "num_intersects_rank0": m,
                 "num_intersects_mean": float(ms.item()) / world, "seed": 3047,
-                "host_path": hp.describe(),
+                "host_path": "gi2d_train_steps: ONE C-ABI call for the timed region, 2 launches per iteration (tile pass; "
+                             "gradient reduce + project bwd + Adam of this iteration fused with activations + project + "
+                             "binning of the next) on persistent HBM buffers, eager launches on the current HIP stream",
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": dom["bytes"], "avg_kernel_us": dom["avg_us"],
+                "algorithmic_bytes_per_launch": pair_bytes, "avg_kernel_us": avg_us,
+                "min_kernel_us": float(np.min(kernel_us)), "kernel_samples": len(kernel_us),
                 "note": "VALU-bound by construction (each staged gaussian is reused by up to 256 pixels); see DESIGN.md",
             },
-            "rasterize_pair": hp.pair_stats(ev, pair_bytes),
+            "rasterize_pair": {
+                "fwdbwd_kernel_us": avg_us, "algorithmic_bytes": pair_bytes, "achieved_GBps": achieved,
+                # every staged (tile, gaussian) entry against every pixel of its tile, forward + backward: the NOMINAL
+                # pair count of the reference's loops (forward.cu:650, backward.cu:1258), not evaluated work
+                "nominal_pairs_per_s": 2 * 256.0 * m / (avg_us * 1e-6),
+                "note": "HIP start/stop events of the tile-pass kernel inside the timed call"},
+            "static_scene_step": static_scene_rate(xyz, L, col, op, gt, n, h, w, dev),
         }
+        if not args.no_batched:
+            line["batched"] = batched_rate(n, h, w, dev)
         if images is not None:
             line["images_per_s"] = images
         if args.train_step:
-            line["train_step"] = train_step_rate(gt, n, dev)
             line["quantized_train_step"] = quantized_train_step_rate(gt, dev)
         if args.images_per_gpu_probe:
             line["concurrent_images"] = concurrent_images_rate(n, h, w, dev)
@@ -221,36 +242,147 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
+def make_fitter(gt, xyz, L, col, n, h, w, **kw):
+    """The Cholesky model on the synthetic inputs of SURVEY 8d: raw positions atanh(xyz), raw Cholesky rows L - bound
+    (the fitter adds the low-pass bound back), colours as given; torch.optim.Adam, lr 1e-3."""
+    import math
+    import numpy as np
+    import torch
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    lp = min(h * w / (9 * math.pi * n), 300)
+    init = {"xyz": torch.from_numpy(np.arctanh(xyz.astype(np.float64)).astype(np.float32)),
+            "chol": torch.from_numpy(L - np.array([lp, 0, lp], np.float32)), "feat": torch.from_numpy(col)}
+    return NativeFitter(gt.contiguous(), n, kind="cholesky", lr=1e-3, seed=3047, init=init, **kw)
+
+
+def median_stretch_us(train, iters, reps=5):
+    """Microseconds per iteration, median over `reps` stretches of `iters` iterations: the shared boxes show a host
+    stall of tens of ms once in a few hundred ms of runtime, which would multiply a 10 ms measurement."""
+    import torch
+    times = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        train(iters)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    return sorted(times)[len(times) // 2] / iters * 1e6
+
+
+def static_scene_rate(xyz, L, col, op, gt, n, h, w, dev, steps=200):
+    """What rounds 1-2 reported as `value`: HotPath.step() in a loop over FROZEN parameters (same inputs every step, so
+    the incremental binning appends nothing and no parameter is written): project + bin + rasterize fwd + L2 gradient +
+    rasterize bwd + project bwd, no activations, no optimizer."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    hp = HotPath(n, h, w, device=dev)
+    hp.set_inputs(xyz, L, col, op)
+    hp.set_target(gt)
+    hp.forward()
+    for _ in range(20):
+        hp.step()
+
+    def run(k):
+        for _ in range(k):
+            hp.step()
+    us = median_stretch_us(run, steps)
+    hp.check_status()
+    return {"steps_per_s": 1e6 / us, "us_per_step": us, "num_intersects": hp.num_intersects(),
+            "what": "frozen parameters: no appends to the tile lists, no optimizer (the round-1/2 headline loop)"}
+
+
+def batched_rate(n, h, w, dev, ks=(4, 8, 24), iters=60):
+    """K images per launch (gi2d_train_steps_batched): the headline's training iteration for K independent images in
+    lockstep.  Per K: image-iterations/s, the batched tile-pass kernel's own time (HIP events on its dispatch) and the
+    roofline fraction on K x algorithmic bytes."""
+    import numpy as np
+    import torch
+    from helpers import synth_cholesky, synth_gt
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    out = []
+    for k in ks:
+        fits = []
+        for i in range(k):
+            xyz, L, col, _ = synth_cholesky(n, h, w, 5000 + i)
+            fits.append(make_fitter(torch.from_numpy(synth_gt(h, w, 50 + i)).to(dev), xyz, L, col, n, h, w))
+        b = BatchFitter(fits)
+        b.max_call = 1 << 30
+        b.train(20)
+        us = median_stretch_us(b.train, iters)
+        timers = _lib.TilePassTimers(8)
+        timers.arm(4)
+        b.train(32)
+        torch.cuda.synchronize(dev)
+        kus = timers.us()
+        timers.close()
+        for f in fits:
+            f.check_status()
+        m = [int(f.nth[:n].sum().item()) for f in fits]
+        nbytes = sum(80 * mi + 36 * h * w + 36 * n for mi in m)
+        avg = float(np.median(kus))
+        out.append({"images_per_launch": k, "image_iters_per_s": k * 1e6 / us, "us_per_batch_iteration": us,
+                    "us_per_image_iteration": us / k, "tile_pass_kernel_us": avg,
+                    "tile_pass_us_per_image": avg / k, "algorithmic_bytes_per_launch": nbytes,
+                    "roofline": {"bound": "hbm", "kernel": "gi2d::fast_fwdbwd_batched_kernel<1>",
+                                 "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                    "num_intersects_mean": float(np.mean(m))})
+        del b, fits
+        torch.cuda.empty_cache()
+    return {"workload": f"the headline's training iteration (Cholesky model, N={n}, {w}x{h}, Adam) for K images in "
+                        f"lockstep, every kernel launched once for all of them; median of 5 stretches of {iters} "
+                        f"iterations", "per_k": out}
+
+
+def load_kodak(count):
+    """The Kodak pictures as float [H, W, 3] tensors in [0, 1] (utils.py:21-26: PIL -> ToTensor) from the data fixture
+    tests/golden/kodak24.npz (pixels of datasets/kodak/kodim01..24.png; tests/golden/make_kodak_fixture.py)."""
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(ROOT, "tests", "golden", "kodak24.npz"))
+    names = sorted(z.files)[:count]
+    return names, [torch.from_numpy(z[k].astype(np.float32) / 255.0) for k in names]
+
+
 def images_per_s(args, rank, world, dev, red_dev, barrier):
-    """BASELINE.json's second metric: the per-image fitting loop of train.py:294-340 over a Kodak-24-shaped batch,
-    image i on rank i mod N (launch.run_sharded), whole-job images / wall second (max over ranks by the closing
-    barrier).  Model and schedule are train.py's defaults scaled to a stated iteration count: covariance model, Adam
-    lr 0.018, 5000 -> 50000 gaussians (BASELINE config 3: densification on), prune every 100 iterations, growth every
-    iterations/10 with the whole remaining budget released at the last growth step (train.py:91-99)."""
+    """BASELINE.json's second metric: the per-image fitting loop of train.py:294-340 over Kodak-24, image i on rank
+    i mod N (launch.run_sharded), whole-job images / wall second (max over ranks by the closing barrier).  Model and
+    schedule are train.py's defaults: covariance model, Adam lr 0.018 / eps 1e-15, 5000 -> 50000 gaussians (BASELINE
+    config 3: densification on), 50 000 iterations, prune every 100, growth every 5000 with the whole remaining budget
+    released at the last growth step (train.py:91-99,204-215).  A rank fits its images as one batch
+    (gi2d_train_steps_batched: every kernel of an iteration launched once for all of them)."""
     import torch
     import torch.distributed as dist
     from gaussianimage_plus_amd import launch
 
     iters = int(args.image_iterations)
-    h, w = 512, 768  # Kodak: 18 landscape + 6 portrait pictures of 768x512 pixels; the synthetic batch is all landscape
     num_points, max_points = 5000, 50000
-    grow_iter, prune_iter = max(iters // 10, 1), 100
-    pics = [launch.synthetic_image(h, w, 100 + i) for i in range(args.images)]
+    grow_iter, prune_iter = (5000 if iters >= 20000 else max(iters // 10, 1)), 100
+    if args.synthetic_images:
+        names = [f"synthetic{i:02d}" for i in range(args.images)]
+        pics = [launch.synthetic_image(512, 768, 100 + i) for i in range(args.images)]
+    else:
+        names, pics = load_kodak(args.images)
     kw = dict(lr=0.018, seed=3047, kind="covariance", max_points=max_points, prune_iter=prune_iter, grow_iter=grow_iter,
               eps=1e-15, optimizer="adam", eval_renders=1)
+    rows = {}
 
     def fit_one(i, img):
-        return launch.fit_image_native(img.to(dev), num_points, iters, **kw)
+        rows[i] = launch.fit_image_native(img.to(dev), num_points, iters, **kw)
+        return rows[i]
 
     def fit_group(idx, imgs):
-        return launch.fit_images_native([im.to(dev) for im in imgs], num_points, iters, threaded=True, **kw)
+        res = launch.fit_images_native([im.to(dev) for im in imgs], num_points, iters, batched=True, **kw)
+        rows.update(zip(idx, res))
+        return res
 
-    # untimed warm-up, the counterpart of --warmup for the step metric: one small image through the same schedule, so that
-    # every kernel of the loop (tile pass, update, prune / growth, render) has its code object loaded -- tens of ms each on
-    # first use, a fixed cost per process that would otherwise be charged to the 3 images a rank fits at N = 8
-    launch.fit_image_native(launch.synthetic_image(96, 144, 99).to(dev), 500, 300, lr=0.018, seed=3047,
-                            kind="covariance", max_points=1500, prune_iter=100, grow_iter=100, eps=1e-15,
-                            optimizer="adam", eval_renders=1)
+    # untimed warm-up, the counterpart of --warmup for the step metric: two small images through the same schedule as a
+    # batch, so that every kernel of the loop (batched tile pass and update, prune / growth, render) has its code object
+    # loaded -- tens of ms each on first use, a fixed cost per process that would otherwise be charged to the 3 images a
+    # rank fits at N = 8
+    warm = [launch.synthetic_image(96, 144, 98 + i).to(dev) for i in range(2)]
+    launch.fit_images_native(warm, 500, 300, lr=0.018, seed=3047, kind="covariance", max_points=1500, prune_iter=100,
+                             grow_iter=100, eps=1e-15, optimizer="adam", eval_renders=1, batched=True)
     torch.cuda.synchronize(dev)
     barrier()
     t0 = time.perf_counter()
@@ -261,13 +393,24 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
     if world > 1:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall = float(wall.item())
+    mine = sorted(rows)
+    portrait = sum(1 for p in pics if p.shape[0] > p.shape[1])
     return {"value": out["images"] / wall, "unit": "images/s", "images": out["images"], "wall_s": wall,
-            "iterations_per_image": iters, "avg_psnr": out["avg_psnr"], "avg_num_gaussians": out["avg_num_gaussians"],
-            "images_concurrent_per_gpu": max(1, args.images_per_gpu),
-            "warmup": "one 144x96 image, 300 iterations of the same schedule, untimed (code objects loaded)",
-            "workload": f"{args.images} synthetic 768x512 images (Kodak-24 shape), covariance model {num_points}->"
-                        f"{max_points} gaussians, {iters} iterations/image (reference default 50000), prune every "
-                        f"{prune_iter}, grow every {grow_iter}; image i -> rank i mod {world}"}
+            "data": "synthetic" if args.synthetic_images else "kodak",
+            "images_landscape_768x512": len(pics) - portrait, "images_portrait_512x768": portrait,
+            "iterations_per_image": iters, "avg_psnr": out["avg_psnr"],
+            "avg_num_gaussians": out["avg_num_gaussians"],
+            "avg_num_gaussians_note": "gaussians of the evaluated (best-PSNR) model, as train.py:157-160 reports them",
+            "rank0_images": [{"image": names[i], "psnr": round(rows[i]["psnr"], 3),
+                              "best_model_gaussians": int(rows[i]["num_gaussians"]),
+                              "final_model_gaussians": int(rows[i].get("final_num_gaussians", rows[i]["num_gaussians"]))}
+                             for i in mine],
+            "images_per_batch_per_gpu": min(max(1, args.images_per_gpu), max(1, len(mine))),
+            "warmup": "two 144x96 images, 300 iterations of the same schedule as one batch, untimed (code objects loaded)",
+            "workload": f"{len(pics)} {'synthetic 768x512' if args.synthetic_images else 'Kodak'} images, covariance "
+                        f"model {num_points}->{max_points} gaussians, {iters} iterations/image (train.py:204: 50000), "
+                        f"prune every {prune_iter}, grow every {grow_iter}; image i -> rank i mod {world}, a rank's images "
+                        f"fitted in lockstep as one batch"}
 
 
 def pmc_traffic(kernel, n, h, w):
@@ -324,24 +467,6 @@ def concurrent_images_rate(n, h, w, dev, rounds=300):
             hp.check_status()
         out.append({"images": k, "steps_per_s": k * rounds / dt, "us_per_round": dt / rounds * 1e6})
     return out
-
-
-def train_step_rate(gt, n, dev, iters=400):
-    """Extra information, not `value`: the whole training iteration (hot path + L2 loss gradient + Adam update,
-    gi2d_train_step = 3 launches, no host sync) on the same image size / gaussian count, measured after the
-    timed region."""
-    import torch
-    from gaussianimage_plus_amd.trainer import NativeFitter
-    fit = NativeFitter(gt.contiguous(), n, kind="cholesky", lr=1e-3, seed=3047)
-    fit.train(40)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    fit.train(iters)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    fit.check_status()
-    return {"iters_per_s": iters / dt, "us_per_iter": dt / iters * 1e6, "num_intersects": int(fit.nth.sum().item()),
-            "what": "full training iteration incl. activations, L2 loss gradient and Adam (gi2d_train_step)"}
 
 
 def quantized_train_step_rate(gt, dev, n=30000, iters=400):

@@ -53,6 +53,7 @@ SIGNATURES.update({
                                                       _f, _p, _sz, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "gi2d_fast_tile_capacity": [],
     "gi2d_timer_create": [_p], "gi2d_timer_destroy": [_p], "gi2d_timer_arm": [_p], "gi2d_timer_elapsed_us": [_p, _p],
+    "gi2d_timer_arm_many": [_p, _i, _i],
     # struct gi2d_train_state* (gaussianimage_plus_amd/trainer.py::_TrainState)
     "gi2d_train_render": [_p, _p],
     "gi2d_train_step": [_p, _p, C.c_double, C.c_double, _f, _i, _p],
@@ -122,3 +123,36 @@ def call(name: str, *args) -> None:
 
 def version() -> str:
     return load().gi2d_version().decode()
+
+
+class TilePassTimers:
+    """`count` kernel timers (gi2d_timer_*) for the tile-pass launches the calling thread issues next: launch
+    0, stride, 2 stride, ... carries one (gi2d_timer_arm_many), also inside gi2d_train_steps[_batched] calls.  us() waits
+    for the kernels and returns their own execution times -- the figure a rocprofv3 kernel trace reports."""
+
+    def __init__(self, count: int):
+        self.handles = []
+        for _ in range(int(count)):
+            h = C.c_void_p()
+            call("gi2d_timer_create", C.byref(h))
+            self.handles.append(h)
+        self.array = (C.c_void_p * len(self.handles))(*[h.value for h in self.handles])
+
+    def arm(self, stride: int = 1) -> None:
+        call("gi2d_timer_arm_many", self.array, len(self.handles), int(stride))
+
+    def cancel(self) -> None:
+        call("gi2d_timer_arm_many", None, 0, 1)
+
+    def us(self):
+        out = []
+        for h in self.handles:
+            v = C.c_float()
+            call("gi2d_timer_elapsed_us", h, C.byref(v))
+            out.append(v.value)
+        return out
+
+    def close(self) -> None:
+        for h in self.handles:
+            load().gi2d_timer_destroy(h)
+        self.handles = []

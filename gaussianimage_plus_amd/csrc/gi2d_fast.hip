@@ -352,15 +352,31 @@ struct KernelTimer {
     hipEvent_t begin, end;
 };
 static thread_local KernelTimer *g_armed_timer = nullptr;
-#define GI2D_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                                        \
-    do {                                                                                                           \
-        if (g_armed_timer) {                                                                                       \
-            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, g_armed_timer->begin, g_armed_timer->end, 0,     \
-                                  __VA_ARGS__);                                                                    \
-            g_armed_timer = nullptr;                                                                               \
-        } else {                                                                                                   \
-            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                       \
-        }                                                                                                          \
+// gi2d_timer_arm_many: timers for every `stride`-th of the following tile-pass launches of this thread
+static thread_local struct {
+    KernelTimer **list;
+    int count, stride, seen;
+} g_timer_plan = {nullptr, 0, 1, 0};
+static KernelTimer *next_timer() {
+    KernelTimer *t = g_armed_timer;
+    g_armed_timer = nullptr;
+    if (!t && g_timer_plan.list) {
+        const int i = g_timer_plan.seen++;
+        if (i % g_timer_plan.stride == 0) {
+            t = g_timer_plan.list[i / g_timer_plan.stride];
+            if (i / g_timer_plan.stride + 1 >= g_timer_plan.count) g_timer_plan.list = nullptr;  // the last one
+        }
+    }
+    return t;
+}
+#define GI2D_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                               \
+    do {                                                                                                  \
+        if (KernelTimer *gi2d_t = next_timer()) {                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, gi2d_t->begin, gi2d_t->end, 0,          \
+                                  __VA_ARGS__);                                                           \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                              \
+        }                                                                                                 \
     } while (0)
 
 namespace gi2d {
@@ -403,6 +419,17 @@ int gi2d_timer_destroy(void *timer) {
 }
 int gi2d_timer_arm(void *timer) {
     g_armed_timer = (KernelTimer *)timer;
+    return GI2D_OK;
+}
+int gi2d_timer_arm_many(void **timers, int count, int stride) {
+    if (count < 0 || stride < 1 || (count > 0 && !timers)) {
+        set_error("timer arm many: bad argument");
+        return GI2D_ERR_INVALID_ARGUMENT;
+    }
+    g_timer_plan.list = count > 0 ? (KernelTimer **)timers : nullptr;
+    g_timer_plan.count = count;
+    g_timer_plan.stride = stride;
+    g_timer_plan.seen = 0;
     return GI2D_OK;
 }
 int gi2d_timer_elapsed_us(void *timer, float *us) {

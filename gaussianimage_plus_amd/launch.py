@@ -159,6 +159,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
     for f, st in zip(fitters, streams):
         with torch.cuda.stream(st):
             f.check_status()
+            final_n = f.n  # population of the last iteration's model (the evaluated one below is the best-PSNR snapshot)
             if adaptive or quantize:
                 f.load_best()
             # the render-only kernels have not run yet (training uses the single-pass tile kernel): their code object
@@ -173,7 +174,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
             eval_s = (time.time() - t0) / max(int(eval_renders), 1)
             mse = torch.nn.functional.mse_loss(img, f.gt).item()
         row = {"psnr": 10 * math.log10(1.0 / max(mse, 1e-12)), "train_s": train_s, "eval_s": eval_s,
-               "num_gaussians": f.n, "mse": mse}
+               "num_gaussians": f.n, "final_num_gaussians": final_n, "mse": mse}
         if quantize:  # train_quantize.py:239-270 encode(): codes, decoded render, size
             with torch.cuda.stream(st):
                 enc = f.compress_wo_ec()

@@ -361,6 +361,10 @@ int gi2d_fast_reduce_project_backward_project_bin(
 int gi2d_timer_create(void **timer);
 int gi2d_timer_destroy(void *timer);
 int gi2d_timer_arm(void *timer);
+/* The same for a loop inside ONE call (gi2d_train_steps, gi2d_train_steps_batched): of the tile-pass launches the
+ * calling thread issues from now on, launch i (0, stride, 2 stride, ...) carries timers[i / stride], `count` timers in
+ * all; the caller keeps the array alive until the last of them has been used.  count = 0 cancels. */
+int gi2d_timer_arm_many(void **timers, int count, int stride);
 int gi2d_timer_elapsed_us(void *timer, float *microseconds);
 
 /* ------------------------------------------------------------------ fused fitting iteration

@@ -23,7 +23,9 @@ def test_bench_line_has_the_contract_fields():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 4 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["data"].startswith("synthetic") and "kodak" in d["data"]
+    assert "optimizer ON" in d["config"]["workload"]  # the timed loop trains: parameters move every step
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     r = d["roofline"]
@@ -34,9 +36,20 @@ def test_bench_line_has_the_contract_fields():
     assert r["traffic"] is None  # the committed counters are for the default workload, not this one
     assert r["traffic_source"].startswith("none:")
     assert d["metric"].endswith("144x96")
+    assert r["kernel_samples"] == 3 and r["avg_kernel_us"] >= r["min_kernel_us"] > 0  # 24 steps, every 8th timed
     im = d["images_per_s"]
     assert im["unit"] == "images/s" and im["images"] == 2 and im["iterations_per_image"] == 200 and im["value"] > 0
     assert abs(im["value"] - im["images"] / im["wall_s"]) <= 1e-9 * im["value"]
+    assert im["data"] == "kodak" and im["images_landscape_768x512"] == 2 and im["images_portrait_512x768"] == 0
+    assert [row["image"] for row in im["rank0_images"]] == ["kodim01", "kodim02"]
+    assert all(10 < row["psnr"] < 60 and row["best_model_gaussians"] > 0 for row in im["rank0_images"])
+    st = d["static_scene_step"]
+    assert st["steps_per_s"] > 0 and st["num_intersects"] > 0
+    ks = d["batched"]["per_k"]
+    assert [b["images_per_launch"] for b in ks] == [4, 8, 24]
+    for b in ks:
+        assert b["image_iters_per_s"] > 0 and b["tile_pass_kernel_us"] > 0
+        assert abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / 8000.0) < 1e-12
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
@@ -50,7 +63,7 @@ def test_gpus_flag_starts_the_ranks_itself():
     the box, rendezvous over gloo) and relays rank 0's line, which must say n_gpus = 2 and carry the whole-job rate."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4",
            "--num-points", "3000", "--height", "96", "--width", "144", "--images", "2", "--image-iterations", "100",
-           "--images-per-gpu", "1"]
+           "--images-per-gpu", "1", "--no-batched"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["GI2D_BENCH_BACKEND"] = "gloo"
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
