@@ -216,10 +216,20 @@ __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(TilePa
 // is the single-image kernel's code, so every image's results are those of its own launch bit for bit.
 template <int MODE>
 __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kernel(
-    const BatchImage *__restrict__ imgs, const int *__restrict__ tile_start, int k_images, int uniform_tiles) {
+    const BatchImage *__restrict__ imgs, const int *__restrict__ tile_start, int k_images, int uniform_tiles,
+    int xcd_map) {
     __shared__ FusedLds sm;
     int k, local;
-    if (uniform_tiles > 0) {
+    if (xcd_map) {
+        // Images with the same tile count, K >= 8: image k's tiles go to the workgroups b with b % 8 == k % 8.  Workgroups
+        // are dealt to the eight XCDs round-robin, so one image's records, tile rows and gradient rows stay in ONE XCD's
+        // 4 MiB L2 instead of being fetched into all eight (placement is a speed choice only: any mapping is correct).
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int slot = j / uniform_tiles;
+        k = slot * 8 + x;
+        local = j - slot * uniform_tiles;
+        if (k >= k_images) return;  // the last slot of an XCD whose share of the images is one short
+    } else if (uniform_tiles > 0) {
         k = (int)blockIdx.x / uniform_tiles;
         local = (int)blockIdx.x - k * uniform_tiles;
     } else {
@@ -383,12 +393,19 @@ namespace gi2d {
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
                              hipStream_t st) {
     if (total_blocks <= 0) return GI2D_OK;
+    int xcd_map = 0;
+#ifndef GI2D_NO_XCD_MAP /* development aid: what the XCD-aware mapping buys */
+    if (uniform_tiles > 0 && k_images >= 8) {
+        xcd_map = 1;
+        total_blocks = 8 * ((k_images + 7) / 8) * uniform_tiles;
+    }
+#endif
     if (mode == 0)
         GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<0>, dim3((unsigned)total_blocks), dim3(256), st,
-                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles);
+                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles, xcd_map);
     else
         GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<1>, dim3((unsigned)total_blocks), dim3(256), st,
-                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles);
+                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles, xcd_map);
     return check_launch("batched tile pass");
 }
 }  // namespace gi2d

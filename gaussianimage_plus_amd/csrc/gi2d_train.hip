@@ -212,48 +212,49 @@ __device__ __forceinline__ float adan(float p, float g, float &m, float &n, floa
     return p;
 }
 
-// Is the render of THIS step (made with the pre-update parameters) the best so far?  Every workgroup sums the
-// per-tile squared errors in the same fixed order, so all take the same decision without a host round trip.
-__device__ __forceinline__ bool best_decision(const BestSnap &best, int n, int g) {
+// Is the render of THIS step (made with the pre-update parameters) the best so far?  Every WAVE sums the per-tile
+// squared errors itself, in the same fixed order -- lane l adds the float4s l, l + 64, ... in ascending order, then one
+// DPP wave sum -- so all waves of all workgroups take the same decision without a barrier, an LDS round or a host round
+// trip, whatever the workgroup size (64 or 256 lanes, single-image or batched launch).  (The workgroup-wide tree this
+// replaces -- one LDS array, nine barriers -- cost the update kernel 3 of its 14 us.)
+// best_sse_loads: the loads, issued with the kernel's other first-round loads; best_decision: the sum and the verdict.
+#define GI2D_SSE_ROUND 8 /* float4 loads a lane keeps in flight: 8 x 64 x 4 = 2048 tiles per round */
+struct SseLoads {
+    float4 v[GI2D_SSE_ROUND];
+};
+__device__ __forceinline__ SseLoads best_sse_loads(const BestSnap &best) {
+    SseLoads s;
+    if (best.sse != nullptr) {
+        const float4 *sse4 = reinterpret_cast<const float4 *>(best.tile_sse);
+        const int n4 = best.num_tiles >> 2, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int q = 0; q < GI2D_SSE_ROUND; ++q) {
+            const int t = lane + 64 * q;
+            s.v[q] = t < n4 ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ bool best_decision(const BestSnap &best, const SseLoads &first, int n, int g) {
     bool snapshot = false;
     if (best.sse != nullptr) {
-        __shared__ float red[256];
-        // 16-byte loads, several in flight per lane (a lane-serial chain of 4-byte loads cost 8 us per step).  The order
-        // of the sum does not depend on the workgroup size (64 or 256 lanes): 256 "virtual lanes" v each add the
-        // float4s t = v, v + 256, ... in ascending order, then one tree over the 256 partial sums -- so a launch with
-        // 64-lane workgroups, one with 256 and a batched one take the same decision and store the same best error.
         const float4 *sse4 = reinterpret_cast<const float4 *>(best.tile_sse);
-        const int n4 = best.num_tiles >> 2, bs = (int)blockDim.x;
-        const int nv = 256 / bs;  // virtual lanes per lane: 4 or 1
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r * 256 < n4; r += 2) {  // two rounds x up to four virtual lanes: eight loads in flight
-            float4 val[2][4];
+        const int n4 = best.num_tiles >> 2, lane = threadIdx.x & 63;
+        float part = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
+        for (int q = 0; q < GI2D_SSE_ROUND; ++q) part += (first.v[q].x + first.v[q].y) + (first.v[q].z + first.v[q].w);
+        for (int t0 = 64 * GI2D_SSE_ROUND; t0 < n4; t0 += 64 * GI2D_SSE_ROUND) {  // images beyond 2048 tiles
+            float4 v[GI2D_SSE_ROUND];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int t = (int)threadIdx.x + q * bs + 256 * (r + rr);
-                    val[rr][q] = (q < nv && t < n4) ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            for (int q = 0; q < GI2D_SSE_ROUND; ++q) {
+                const int t = t0 + lane + 64 * q;
+                v[q] = t < n4 ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) part[q] += (val[rr][q].x + val[rr][q].y) + (val[rr][q].z + val[rr][q].w);
+            for (int q = 0; q < GI2D_SSE_ROUND; ++q) part += (v[q].x + v[q].y) + (v[q].z + v[q].w);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q >= nv) break;
-            const int v = (int)threadIdx.x + q * bs;
-            float p = part[q];
-            for (int t = (n4 << 2) + v; t < best.num_tiles; t += 256) p += best.tile_sse[t];
-            red[v] = p;
-        }
-        __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
-            for (int i = threadIdx.x; i < d; i += bs) red[i] += red[i + d];
-            __syncthreads();
-        }
-        const float total = red[0], prev = best.sse[best.step & 1];
+        for (int t = (n4 << 2) + lane; t < best.num_tiles; t += 64) part += best.tile_sse[t];
+        const float total = wave_sum_dpp(part), prev = best.sse[best.step & 1];
         snapshot = total < prev;  // train.py:134 `best_psnr < psnr`
         if (g == 0) {
             best.sse[(best.step + 1) & 1] = snapshot ? total : prev;
@@ -291,27 +292,43 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     float *dbg_grads = u.dbg_grads;
     BestSnap best = u.best;
     best.step = step;
-    const int n = live_n(P, u.n);
     const int g = block * blockDim.x + threadIdx.x;
+    // First round of loads: everything whose address is known now, for every row below the host's upper bound `u.n` (the
+    // arrays are that long; with the population on the device the live count is itself one of these loads, and waiting
+    // for it first would put a round trip in front of all the others).  The box is the first link of the gradient's
+    // load chain (box -> partial rows), radius and conic feed the projection backward.
+    const bool in_rows = g < u.n;
     AdamRows rows;
-    if (!ADAN && g < n) rows = adam_load_rows(P, g);
-    // everything whose address is known now is requested before the barriers of best_decision(): the box is the first
-    // link of the gradient's load chain (box -> partial rows), radius and conic feed the projection backward
-    const int2 box = g < n ? prev_box[g] : make_int2(0, 0);
-    const int radius = g < n ? radii[g] : 0;
+    if (!ADAN && in_rows) rows = adam_load_rows(P, g);
+    const int2 box_ld = in_rows ? prev_box[g] : make_int2(0, 0);
+    const int radius = in_rows ? radii[g] : 0;
     float conic[3] = {0.f, 0.f, 0.f};
-    if (g < n) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
-    const float opac_next = (FILL_NEXT && g < n) ? P.opacity[g] : 0.f;
-    const bool snapshot = best_decision(best, n, g);
+    if (in_rows) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
+    const float opac_next = (FILL_NEXT && in_rows) ? P.opacity[g] : 0.f;
+    // the additive bound of this gaussian (one row for all when bound_stride == 0): used by both activations and the snapshot
+    const Row3 bound_row = in_rows ? load_row3(P.bound, P.bound_stride ? g : 0) : Row3{0.f, 0.f, 0.f};
+    const float bound3[3] = {bound_row.a, bound_row.b, bound_row.c};
+    const int n = live_n(P, u.n);
+    const int2 box = g < n ? box_ld : make_int2(0, 0);
+#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 1) /* development aid (wrong results): no best-model decision */
+    const bool snapshot = false;
+#else
+    const SseLoads sse_first = best_sse_loads(best);
+    const bool snapshot = best_decision(best, sse_first, n, g);
+#endif
     float acc[11];
+#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 2) /* development aid (wrong results): no gradient gather */
+    for (int q = 0; q < 11; ++q) acc[q] = 1e-9f * (float)(box.x + q);
+#else
     reduce_one(g, box, tiles_x, u.gids_sorted, u.tile_bins, tiles_x * tiles_y, u.partial_g, u.partial_big, acc);
+#endif
     if (g >= n) return;
     float2 mean;
     float par[3];
     if (ADAN)
         activate<KIND>(P, g, mean, par);
     else
-        activate_rows<KIND>(rows.x, rows.c, P.bound + (size_t)P.bound_stride * g, mean, par);
+        activate_rows<KIND>(rows.x, rows.c, bound3, mean, par);
     ProjGrad r;
     r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
     r.v_mean = make_float2(0.f, 0.f);
@@ -327,7 +344,7 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     }
     float gp[3] = {r.o0, r.o1, r.o2};
     if (KIND == kScaleRot) {  // through |.| (torch.abs: sign, 0 at 0) and sigmoid * 2 pi
-        const float *bd = P.bound + (size_t)P.bound_stride * g;
+        const float *bd = bound3;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const float pre = P.chol[3 * g + q] + bd[q];
@@ -355,7 +372,11 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     } else {
         adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
     }
+#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 4) /* development aid (wrong results): the next iteration is not prepared */
+    if (FILL_NEXT && new_xy.x == 12345.678f) {
+#else
     if (FILL_NEXT) {
+#endif
         // same code path as train_project_fill_kernel, on the values just written
         // (The record-set lookup stays HERE.  Hoisted to the top of the kernel together with begin_binning -- either
         // one alone is fine -- the build keeps one more SGPR alive across the whole kernel, spills SGPRs to VGPR lanes,
@@ -370,15 +391,13 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         asm volatile("" : "+v"(new_xy.x), "+v"(new_xy.y), "+v"(new_chol.a), "+v"(new_chol.b), "+v"(new_chol.c));
         float2 mean2;
         float par2[3];
-        activate_rows<KIND>(new_xy, new_chol, P.bound + (size_t)P.bound_stride * g, mean2, par2);
+        activate_rows<KIND>(new_xy, new_chol, bound3, mean2, par2);
         const ProjOut o =
             project_one<KIND>(0, next.clip_coe, &mean2, par2, rot_of<KIND>(par2), img_w, img_h, tiles_x, tiles_y,
                               radius_clip);
         xys[g] = o.xy;
         radii[g] = o.radius;
-        conics[3 * g] = o.k0;
-        conics[3 * g + 1] = o.k1;
-        conics[3 * g + 2] = o.k2;
+        store_row3(conics, g, o.k0, o.k1, o.k2);
         next.num_tiles_hit[g] = o.tiles_hit;
         // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box)
         bin_projected(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, box,
@@ -387,15 +406,12 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned):
         // from the registers the update left, not read back through memory (a store -> load round trip at the end of
         // nearly every iteration while the fit still improves)
-        best.xyz[2 * g] = new_xy.x;
-        best.xyz[2 * g + 1] = new_xy.y;
-        const float nc[3] = {new_chol.a, new_chol.b, new_chol.c}, nf[3] = {new_feat.a, new_feat.b, new_feat.c};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            best.chol[3 * g + q] = nc[q];
-            best.feat[3 * g + q] = nf[q];
-            if (best.bound) best.bound[3 * g + q] = P.bound[(size_t)P.bound_stride * g + q];
-        }
+        // whole rows: one 8- or 12-byte store per row instead of one per float (the update kernel ends when its last
+        // store is acknowledged, and three dword stores to one row write its cache lines three times)
+        store_row2(best.xyz, g, new_xy.x, new_xy.y);
+        store_row3(best.chol, g, new_chol.a, new_chol.b, new_chol.c);
+        store_row3(best.feat, g, new_feat.a, new_feat.b, new_feat.c);
+        if (best.bound) store_row3(best.bound, g, bound3[0], bound3[1], bound3[2]);
     }
 }
 
@@ -745,7 +761,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
 #pragma clang fp contract(off)
     n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool snapshot = best_decision(best, n, g);
+    const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
     reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
                partial_big, acc);
@@ -930,7 +946,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     AdamRows rows;
     if (g < n) rows = adam_load_rows(P, g);
-    const bool snapshot = best_decision(best, n, g);
+    const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
     reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
                partial_big, acc);
