@@ -50,6 +50,17 @@ def check_close(name, got, want, scale, mask=None, rtol=RTOL, atol=1e-9, max_bad
     nbad = int(bad.sum())
     total = int(mask.sum()) if mask is not None else bad.size
     worst = float((err / tol)[bad].max()) if nbad else float((err / tol)[mask].max() if mask is not None else (err / tol).max())
+    if rtol != RTOL or max_bad_frac > 0:
+        # a comparison that asks for more room than the 1e-5 bar: say how much of it is used (pytest -s / -rP shows it)
+        tol5 = RTOL * np.maximum(scale, np.abs(want)) + atol
+        over = err > tol5
+        if mask is not None:
+            over &= mask
+        where = np.argwhere(over)
+        print(f"[tolerance] {name}: {int(over.sum())}/{total} elements beyond rtol=1e-5 "
+              f"(worst err/tol(1e-5) = {float((err / tol5)[over].max()) if over.any() else float((err / tol5)[mask].max() if mask is not None else (err / tol5).max()):.3g}"
+              f"{'; first at ' + str(where[:4].tolist()) if over.any() else ''}); asked: rtol={rtol}, "
+              f"max_bad_frac={max_bad_frac}")
     assert nbad <= max_bad_frac * total, (
         f"{name}: {nbad}/{total} elements beyond rtol={rtol} (worst err/tol = {worst:.3g})")
     return worst

@@ -447,21 +447,18 @@ def test_backward_reduce_handles_huge_gaussians(C, oracle):
 
 
 def _check_backward_extreme(name, got, want, gamb, abs9):
-    """As _check_backward for shapes far outside a fit's range: the fp32 quadratic form of a gaussian 200 times longer
-    than wide cancels so much that a pair can sit on the other side of the 1/255 cut-off on two machines without being
-    within the ambiguity margin of it -- 2 or 3 gradient elements in 8 700 (the same ones whatever the cull margin, 1/16
-    ... 4 px: measured), each off by at most one pair's share."""
+    """As _check_backward, for shapes far outside a fit's range (gaussians 200 times longer than wide, where the fp32
+    quadratic form cancels most): 1e-5 of the conditioning-weighted absolute terms, EVERY element of every gaussian the
+    oracle does not flag.  (Rounds 1-2 let one element in a thousand be off here; the stragglers were gaussians with a
+    pair a hair below the 1/255 cut-off that the oracle's backward skipped at its final_idx gate before flagging it --
+    fixed in oracle/gi2d_oracle.c in round 3, 42 seeds run with no element out.)"""
     ok = gamb == 0
     v_xy, v_conic, v_rgb, v_op = [n(x) for x in got[:4]]
     cols = [(v_xy, want[0], abs9[:, 0:2]), (v_conic, want[1], abs9[:, 2:5]), (v_rgb, want[2], abs9[:, 5:8]),
             (v_op.reshape(-1, 1), want[3].reshape(-1, 1), abs9[:, 8:9])]
     for (a, b, sc), nm in zip(cols, ["v_xy", "v_conic", "v_rgb", "v_opacity"]):
-        mask = np.repeat(ok[:, None], a.shape[1], 1)
-        check_close(f"{name} {nm}", a, b, sc, mask=mask, atol=1e-12, max_bad_frac=1e-3)
-        # ... and nowhere by more than one borderline pair can carry (its weight is 1/255 of a colour; for v_opacity,
-        # with opacities down to 0.003, that is up to a percent of the column's largest gradient)
-        err = np.abs(a.astype(np.float64) - b)[mask]
-        assert err.max() <= 2e-2 * np.abs(b).max() + 1e-12, (name, nm, err.max(), np.abs(b).max())
+        check_close(f"{name} {nm}", a, b, sc, mask=np.repeat(ok[:, None], a.shape[1], 1), atol=1e-12)
+    assert ok.mean() > 0.7  # gaussians up to 150 px long have thousands of pairs each: a fifth of them has one inside the band
 
 
 @pytest.mark.parametrize("seed", [11, 12] + list(range(100, 100 + int(os.environ.get("GI2D_CULL_STRESS_SEEDS", "0")))))

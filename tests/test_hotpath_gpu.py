@@ -128,8 +128,8 @@ def test_more_than_256_per_tile_keeps_lowest_ids(oracle, n):
     ref = oracle.render_cholesky(xyz, L, col, op, h, w, with_aux=True)
     assert ref["M"] > 256
     out_o, fT, fidx, amb, absimg = ref["ras"]
-    check_close("capped out_img", img.cpu().numpy(), out_o, absimg, mask=np.repeat((amb == 0)[..., None], 3, -1),
-                rtol=3e-5)
+    # sums of up to 256 terms in a different fp32 order than the oracle's: measured 0.06 of the 1e-5 bar
+    check_close("capped out_img", img.cpu().numpy(), out_o, absimg, mask=np.repeat((amb == 0)[..., None], 3, -1))
     hp.set_v_out(_v_out(h, w, 3))
     hp.backward()
     dropped = ref["gids_sorted"][256:]
@@ -233,11 +233,13 @@ def test_2k_image_config4_against_the_oracle(oracle):
     for got, wv, sl, nm in ((hp.v_xy, want[0], slice(0, 2), "v_xy"), (hp.v_conic, want[1], slice(2, 5), "v_conic"),
                             (hp.v_rgb, want[2], slice(5, 8), "v_rgb"), (hp.v_opac, want[3], slice(8, 9), "v_opacity")):
         g = got.cpu().numpy().reshape(wv.shape)
-        # 1e-5 of the summed absolute contributions; a gaussian whose weakest pair sits within the last ulps of the
-        # alpha cut-off escapes the oracle's ambiguity flag once in ~10^5 (one pair of weight 1/255 then shows): bounded
-        worst = check_close("2K " + nm, g, wv, want[5][:, sl], mask=np.repeat(okg[:, None], g.shape[1], 1), atol=1e-12,
-                            max_bad_frac=5e-5)
-        assert worst < 50, (nm, worst)
+        # 1e-5 of the summed absolute contributions, every element of every unflagged gaussian.  (Until round 3 this
+        # comparison allowed 5e-5 of the elements to be off: gaussian 48340 of this scene has a pair whose alpha is
+        # 1/255 - 7e-10 at pixel (575, 1261) -- below the cut-off in the oracle's fp32 form, above it in the device's --
+        # and the oracle's backward skipped that pair at its final_idx gate BEFORE looking at its alpha, so the gaussian
+        # was not flagged ambiguous.  The flag is now raised ahead of the gate, oracle/gi2d_oracle.c.)
+        check_close("2K " + nm, g, wv, want[5][:, sl], mask=np.repeat(okg[:, None], g.shape[1], 1), atol=1e-12)
+    assert okg.mean() > 0.98  # the flags stay rare (measured: 1.05 % of the gaussians have a pair inside the band)
 
 
 def test_2k_image_config4_size_properties():
@@ -353,7 +355,7 @@ def test_single_pass_edge_geometries(oracle):
         ref = oracle.render_cholesky(xyz, L, col, op, h, w, with_aux=True)
         out_o, fT, fidx, amb, absimg = ref["ras"]
         check_close("edge out_img", one.out_img.cpu().numpy(), out_o, absimg,
-                    mask=np.repeat((amb == 0)[..., None], 3, -1), rtol=3e-5)
+                    mask=np.repeat((amb == 0)[..., None], 3, -1))  # measured: 0.06 of the 1e-5 bar
 
 
 def test_pipelined_step_equals_unpipelined_and_survives_input_changes():

@@ -98,3 +98,52 @@ def test_codec_metrics_are_averaged_with_the_rest():
     assert abs(out["avg_bpp_wc"] - 0.4) < 1e-12
     plain = run_sharded(items, lambda i, it: {"psnr": 30.0, "train_s": 1.0, "eval_s": 0.01, "num_gaussians": 1}, 0, 1)
     assert plain["avg_bpp"] == 0.0  # rows without a codec report nothing
+
+
+def _worker8(rank, world, port, q, counts):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for count in counts:  # several "datasets" through the same process group, one after the other
+        seen = []
+
+        def fit_one(i, item):
+            seen.append(i)
+            return {"psnr": 20.0 + i, "train_s": 0.25 * (i + 1), "eval_s": 0.002, "num_gaussians": 1000 + i}
+
+        out = run_sharded(list(range(count)), fit_one, rank, world, device="cpu")
+        res.append((seen, {k: v for k, v in out.items() if k != "rows"}))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_rehearsal_even_uneven_and_idle_ranks():
+    """The N = 8 layout of SURVEY 8e rehearsed on CPU (gloo): Kodak-24 gives every rank 3 images; 21 images give
+    3,3,3,3,3,2,2,2; 5 images leave three ranks with NOTHING to fit -- they still join the one all-reduce (no deadlock)
+    and contribute zeros, so the average is over the images, not over the ranks."""
+    world, counts = 8, (24, 21, 5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, counts)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for ci, count in enumerate(counts):
+        shards = [res[r][ci][0] for r in range(world)]
+        assert shards == [list(range(r, count, world)) for r in range(world)]  # image i -> rank i mod 8
+        want_sizes = {24: [3] * 8, 21: [3, 3, 3, 3, 3, 2, 2, 2], 5: [1, 1, 1, 1, 1, 0, 0, 0]}[count]
+        assert [len(s) for s in shards] == want_sizes
+        reduced = [res[r][ci][1] for r in range(world)]
+        assert all(m == reduced[0] for m in reduced)  # every rank, the idle ones too, holds the same figures
+        m = reduced[0]
+        assert m["images"] == count
+        assert abs(m["avg_psnr"] - (20.0 + (count - 1) / 2)) < 1e-9
+        assert abs(m["sum_train_s"] - sum(0.25 * (i + 1) for i in range(count))) < 1e-9
+        assert abs(m["avg_num_gaussians"] - (1000 + (count - 1) / 2)) < 1e-9
+        assert abs(m["avg_eval_s"] - 0.002) < 1e-12

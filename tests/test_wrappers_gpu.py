@@ -143,10 +143,10 @@ def test_bucket_overflow_falls_back_to_the_capacity_free_ops(gs, oracle):
     xys, depths, radii, conics, nth = gs.project_gaussians_2d(x_t, L_t, h, w, tb)
     img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, c_t, o_t, h, w, background=torch.ones(3, device=DEV))
     ok = np.repeat((g["pix_ambig"] == 0)[..., None], 3, -1)
-    check_close("overflow out_img", img.detach().cpu().numpy(), g["out_img"], g["pix_abs"], mask=ok, rtol=3e-5)
+    check_close("overflow out_img", img.detach().cpu().numpy(), g["out_img"], g["pix_abs"], mask=ok)  # measured: 0.12 of the 1e-5 bar
     (img * torch.from_numpy(g["v_out"]).to(DEV)).sum().backward()
     okg = np.repeat((g["g_ambig"] == 0)[:, None], 3, 1)
-    check_close("overflow v_rgb", c_t.grad.cpu().numpy(), g["v_rgb"], g["g_abs9"][:, 5:8], mask=okg, rtol=3e-5, atol=1e-12)
+    check_close("overflow v_rgb", c_t.grad.cpu().numpy(), g["v_rgb"], g["g_abs9"][:, 5:8], mask=okg, atol=1e-12)
 
 
 def test_no_grad_render_and_training_forward_can_interleave(gs, oracle):
