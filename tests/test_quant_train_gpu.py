@@ -103,7 +103,8 @@ def test_quantised_iteration_matches_torch_loop():
     # gradients of the twelve quantiser values
     q_native, q_ref = fit.dbg_qgrads[:12], want[4]["q"]
     qerr = ((q_native - q_ref).abs() / (q_ref.abs() + 1e-3 * q_ref.abs().max())).max().item()
-    assert qerr < 2e-2, (q_native, q_ref)
+    print(f"[trajectory] quantiser-value gradients: worst relative error {qerr:.3g}")
+    assert qerr < 1e-5, (q_native, q_ref)  # measured: 8e-8 .. 2e-7 (sums closed in double on both sides)
     fit.train(iters - 1)
     fit.check_status()
     torch.cuda.synchronize()
@@ -113,11 +114,12 @@ def test_quantised_iteration_matches_torch_loop():
     # (measured: 4e-6 after two, 7e-4 .. 4e-3 after three, 2e-2 after five); the end-to-end test covers long runs.
     for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "cov2d"), (fit.feat, want[2], "feat")):
         diff = (got - ref).abs()
-        # a handful of elements whose gradient sits at a rounding boundary may already have taken a different
-        # Adam step (up to lr each); the bulk must agree closely
-        assert diff.max().item() < 1.5 * lr, (nm, diff.max().item())
-        assert (diff > 0.1 * lr).float().mean().item() < 5e-3, (nm, (diff > 0.1 * lr).float().mean().item())
-        assert diff.mean().item() < 2e-3 * lr, (nm, diff.mean().item())
+        # an element whose gradient sits at a rounding boundary could take a different Adam step (up to lr); on this
+        # seeded scene none does -- measured: max 8e-4 lr (positions), 1e-5 lr (covariances), 3e-6 lr (colours)
+        print(f"[trajectory] {nm}: max diff {diff.max().item() / lr:.3g} lr, mean {diff.mean().item() / lr:.3g} lr, share "
+              f"beyond 0.1 lr {(diff > 0.1 * lr).float().mean().item():.3g}")
+        assert diff.max().item() < 1e-2 * lr, (nm, diff.max().item())
+        assert diff.mean().item() < 1e-5 * lr, (nm, diff.mean().item())  # measured: 5e-9 .. 1.3e-7 lr
     assert (fit.qparams - want[3]).abs().max().item() < 2e-5, (fit.qparams, want[3])
     assert not torch.equal(fit.qparams, qp0)
     psnr_native = fit.last_step_psnr()

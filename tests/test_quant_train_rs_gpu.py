@@ -94,14 +94,16 @@ def _compare(fit, gt, n, iters=2, grad_tol=1e-5):
     assert rel.mean().item() < 2e-6
     q_native, q_ref = fit.dbg_qgrads[:16], first["q"]
     qerr = ((q_native - q_ref).abs() / (q_ref.abs() + 1e-3 * q_ref.abs().max())).max().item()
-    assert qerr < 2e-2, (q_native, q_ref)
+    print(f"[trajectory] quantiser-value gradients: worst relative error {qerr:.3g}")
+    assert qerr < 1e-5, (q_native, q_ref)  # measured: 8e-8 .. 2e-7 (sums closed in double on both sides)
     fit.train(iters - 1)
     fit.check_status()
     torch.cuda.synchronize()
     diff = (_native_params(fit) - want_p).abs()
-    assert diff.max().item() < 2.5 * lr, diff.max().item()          # a flipped code costs at most an Adam step or two
-    assert (diff > 0.1 * lr).float().mean().item() < 5e-3
-    assert diff.mean().item() < 2e-3 * lr, diff.mean().item()
+    print(f"[trajectory] parameters after {iters} iterations: max diff {diff.max().item() / lr:.3g} lr, mean {diff.mean().item() / lr:.3g} lr, "
+          f"share beyond 0.1 lr {(diff > 0.1 * lr).float().mean().item():.3g}")
+    assert diff.max().item() < 0.1 * lr, diff.max().item()  # measured: 5e-5 lr (N = 3 000), 6e-3 lr (N = 30 000); no code flipped
+    assert diff.mean().item() < 1e-5 * lr, diff.mean().item()  # measured: 1e-8 .. 7e-8 lr
     assert (fit.qparams - want_q).abs().max().item() < 2e-5, (fit.qparams, want_q)
     assert not torch.equal(fit.qparams, qp0)
     assert abs(fit.last_step_psnr() - 10 * math.log10(1.0 / losses[-1])) < 0.1

@@ -79,6 +79,7 @@ def test_native_iteration_matches_torch_adam_loop(kind):
     for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "chol"), (fit.feat, want[2], "feat")):
         d = (got - ref).abs().max().item()
         # 12 Adam steps of size lr: identical trajectories up to fp32 noise amplified by 1/sqrt(v)
+        print(f"[trajectory] {kind} {nm}: max drift {d / (lr * iters):.3g}, mean {(got - ref).abs().mean().item() / (lr * iters):.3g} (units of lr * iters)")
         assert d < 0.15 * lr * iters, f"{nm} drifted by {d}"
         assert (got - ref).abs().mean().item() < 2e-2 * lr * iters, nm
     # the loss the native loop reports for its last render agrees with the torch loop's trajectory
@@ -220,8 +221,9 @@ def test_native_adan_matches_autograd_loop_with_reference_adan():
         d = (got - ref).abs()
         moved = (ref - init[nm].to(DEV)).abs().max().item()
         assert moved > 2 * lr, nm                      # Adan's first steps are ~lr each: the parameters did move
-        assert d.max().item() < 0.15 * lr * iters, f"{nm} drifted by {d.max().item()}"
-        assert d.mean().item() < 2e-2 * lr * iters, nm
+        print(f"[trajectory] {nm}: max drift {d.max().item() / (lr * iters):.3g}, mean {d.mean().item() / (lr * iters):.3g} (units of lr * iters)")
+        assert d.max().item() < 2e-3 * lr * iters, f"{nm} drifted by {d.max().item()}"  # measured: <= 1.5e-4
+        assert d.mean().item() < 3e-6 * lr * iters, nm                                      # measured: <= 2e-7
     # one call of 12 iterations == 12 calls of one iteration, bit for bit
     one = NativeFitter(gt, n, kind="cholesky", lr=lr, eps=1e-15, init=init, optimizer="adan")
     for _ in range(iters):
@@ -254,8 +256,9 @@ def test_native_scale_rot_model_matches_autograd_loop():
     fit.train(iters - 1)
     for got, ref, nm in ((fit.xyz, want[0], "xyz"), (fit.chol, want[1], "chol"), (fit.feat, want[2], "feat")):
         d = (got - ref).abs()
-        assert d.max().item() < 0.15 * lr * iters, f"{nm} drifted by {d.max().item()}"
-        assert d.mean().item() < 2e-2 * lr * iters, nm
+        print(f"[trajectory] {nm}: max drift {d.max().item() / (lr * iters):.3g}, mean {d.mean().item() / (lr * iters):.3g} (units of lr * iters)")
+        assert d.max().item() < 2e-3 * lr * iters, f"{nm} drifted by {d.max().item()}"  # measured: <= 1.5e-4
+        assert d.mean().item() < 3e-6 * lr * iters, nm                                      # measured: <= 2e-7
 
 
 def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
