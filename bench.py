@@ -63,6 +63,7 @@ def parse(argv=None):
     p.add_argument("--synthetic-images", action="store_true",
                    help="images/sec leg on Kodak-shaped synthetic pictures instead of the Kodak fixture")
     p.add_argument("--no-batched", action="store_true", help="skip the `batched` block")
+    p.add_argument("--no-static", action="store_true", help="skip the `static_scene_step` block")
     p.add_argument("--images-per-gpu-probe", action="store_true",
                    help="also report the aggregate step rate of 2, 3 and 4 independent images stepped concurrently on "
                         "separate HIP streams of this GPU (extra information, not `value`)")
@@ -224,8 +225,9 @@ def run_rank(args):
                 # pair count of the reference's loops (forward.cu:650, backward.cu:1258), not evaluated work
                 "nominal_pairs_per_s": 2 * 256.0 * m / (avg_us * 1e-6),
                 "note": "HIP start/stop events of the tile-pass kernel inside the timed call"},
-            "static_scene_step": static_scene_rate(xyz, L, col, op, gt, n, h, w, dev),
         }
+        if not args.no_static:
+            line["static_scene_step"] = static_scene_rate(xyz, L, col, op, gt, n, h, w, dev)
         if not args.no_batched:
             line["batched"] = batched_rate(n, h, w, dev)
         if images is not None:
@@ -325,7 +327,9 @@ def batched_rate(n, h, w, dev, ks=(4, 8, 24), iters=60):
                     "tile_pass_us_per_image": avg / k, "algorithmic_bytes_per_launch": nbytes,
                     "roofline": {"bound": "hbm", "kernel": "gi2d::fast_fwdbwd_batched_kernel<1>",
                                  "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                                 "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic("gi2d::fast_fwdbwd_batched_kernel<1>", n, h, w, k)[0],
+                                 "traffic_source": pmc_traffic("gi2d::fast_fwdbwd_batched_kernel<1>", n, h, w, k)[1]},
                     "num_intersects_mean": float(np.mean(m))})
         del b, fits
         torch.cuda.empty_cache()
@@ -413,25 +417,29 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
                         f"fitted in lockstep as one batch"}
 
 
-def pmc_traffic(kernel, n, h, w):
+def pmc_traffic(kernel, n, h, w, images_per_launch=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/traffic.json, built by
-    tools/make_profiles.py: 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md) and where the
-    figure comes from.  Hardware counters cannot be read from inside the timed process, so this is a STORED value of
-    the same command under rocprofv3, labelled as such; null when no counters were collected for this workload."""
+    tools/make_profiles3.py: 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md; one section per
+    profiled workload) and where the figure comes from.  Hardware counters cannot be read from inside the timed
+    process, so this is a STORED value of the same command under rocprofv3, labelled as such; null when no counters were
+    collected for this workload."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
-        c = t["config"]
-        if (c["num_points"], c["height"], c["width"]) != (n, h, w):
-            return None, f"none: profiles/traffic.json holds counters for {c['num_points']} gaussians at " \
-                         f"{c['width']}x{c['height']}, not for this workload"
-        for k, v in t["kernels"].items():
-            if k.replace(" ", "").endswith(kernel.replace(" ", "")):
-                return v["hbm_bytes_per_launch"], \
-                    f"stored: profiles/traffic.json ({t.get('source', 'rocprofv3 --pmc passes of bench.py')}), " \
-                    f"not measured in this run"
-        return None, f"none: profiles/traffic.json has no entry for {kernel}"
-    except (OSError, KeyError, ValueError) as e:
+        for wl in t["workloads"]:
+            c = wl.get("config") or {}
+            if (c.get("num_points"), c.get("height"), c.get("width")) != (n, h, w) or \
+                    c.get("images_per_launch") != images_per_launch:
+                continue
+            for v in wl["kernels"].values():
+                if v["kernel"].replace(" ", "").endswith(kernel.replace(" ", "")):
+                    return v["hbm_bytes_per_launch"], \
+                        f"stored: profiles/traffic.json, workload {wl['workload']} ({t.get('source', 'rocprofv3 --pmc')}), " \
+                        f"not measured in this run"
+            return None, f"none: profiles/traffic.json, workload {wl['workload']}, has no entry for {kernel}"
+        return None, f"none: profiles/traffic.json holds no counters for {n} gaussians at {w}x{h}" + \
+                     (f", {images_per_launch} images per launch" if images_per_launch else "")
+    except (OSError, KeyError, ValueError, TypeError) as e:
         return None, f"none: profiles/traffic.json unreadable ({type(e).__name__})"
 
 

@@ -1,0 +1,53 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence kept under profiles/round3_*: for each workload the kernel-trace stats and separate
+# --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ groups; never combined with other trace domains).
+#   gpurun --timeout 1200 -- 'bash tools/profile_round3.sh'      then      python tools/make_profiles3.py
+# workloads: head    bench.py's timed loop (Cholesky, N=50 000, 768x512, training iterations)
+#            c4      the same at 2040x1356 (BASELINE config 4)
+#            batched 24 images per launch (tools/batch_time.py, N=50 000)
+#            c5      rotation-scale model, quantisation-aware iterations, N=30 000 (tools/quant_time.py)
+#            fit     24 Kodak images x 10 000 iterations as one batch (tools/kodak_fit.py): trained scenes, prune / grow
+set -e
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/rp3
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+HEAD="--no-cpu-baseline --images 0 --no-batched --no-static"
+C4="$HEAD --height 1356 --width 2040"
+stats() { # name, program...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/stats -o run -- python3 "$@" > $OUT/$name.out 2> $OUT/$name.log || true
+  rm -f $OUT/$name/stats/*kernel_trace.csv  # the per-dispatch trace is large; the stats are what is kept
+}
+pmc() { # name, pass, counters (quoted), program...
+  local name=$1 pass=$2 ctr=$3; shift 3
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name/$pass -o run -- python3 "$@" > /dev/null 2> $OUT/$name.$pass.log || true
+  rm -f $OUT/$name/$pass/*kernel_trace.csv
+}
+SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS"
+SQ2="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+mkdir -p $OUT/head $OUT/c4 $OUT/batched $OUT/c5 $OUT/fit
+stats head $REPO/bench.py $HEAD
+echo "head stats done"
+for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc head $1 "$2" $REPO/bench.py $HEAD --steps 20 --warmup 5; done
+pmc head sq1 "$SQ1" $REPO/bench.py $HEAD --steps 20 --warmup 5
+pmc head sq2 "$SQ2" $REPO/bench.py $HEAD --steps 20 --warmup 5
+echo "head pmc done"
+stats c4 $REPO/bench.py $C4
+for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc c4 $1 "$2" $REPO/bench.py $C4 --steps 20 --warmup 5; done
+pmc c4 sq1 "$SQ1" $REPO/bench.py $C4 --steps 20 --warmup 5
+echo "c4 done"
+stats batched $REPO/tools/batch_time.py 50000 512 768 cholesky 24
+python3 $REPO/tools/batch_time.py 50000 512 768 cholesky 4 8 24 > $OUT/batched_plain.out 2>&1 || true
+for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc batched $1 "$2" $REPO/tools/batch_time.py 50000 512 768 cholesky 24; done
+pmc batched sq1 "$SQ1" $REPO/tools/batch_time.py 50000 512 768 cholesky 24
+pmc batched sq2 "$SQ2" $REPO/tools/batch_time.py 50000 512 768 cholesky 24
+echo "batched done"
+stats c5 $REPO/tools/quant_time.py 30000 400 scale_rot
+pmc c5 sq1 "$SQ1" $REPO/tools/quant_time.py 30000 100 scale_rot
+echo "c5 done"
+stats fit $REPO/tools/kodak_fit.py 24 10000 1
+pmc fit sq1 "$SQ1" $REPO/tools/kodak_fit.py 24 1000 1
+echo "fit done"
+cd $REPO && python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+tail -n 1 $OUT/bench_plain.json | cut -c1-400
