@@ -236,10 +236,16 @@ __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kerne
         k = batch_find(tile_start, k_images, (int)blockIdx.x);
         local = (int)blockIdx.x - tile_start[k];
     }
+    // image and tile are the same for the whole workgroup: say so (the integer divisions above leave them in vector
+    // registers, and everything derived from them -- the argument block's loads, the tile's row and column -- would
+    // follow: 4 more VGPRs than the single-image kernel, i.e. spills at this kernel's 80-register budget)
+    k = __builtin_amdgcn_readfirstlane(k);
+    local = __builtin_amdgcn_readfirstlane(local);
     const TilePassArgs &a = imgs[k].t;
     const float4 *recs = recs_for_tile_pass(a.rs, local == 0 && threadIdx.x == 0);
-    fused_tile<MODE>(sm, a.tile_order[local], a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins,
-                     a.partial_g, a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse);
+    const int tile = __builtin_amdgcn_readfirstlane(a.tile_order[local]);
+    fused_tile<MODE>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
+                     a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse);
 }
 
 // --------------------------------------------------------------------------------------- reduce

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void train_project_fill_batched_kernel(const B
                                                                          const int *__restrict__ pg_start,
                                                                          int k_images) {
     const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
-    const int local = (int)blockIdx.x - pg_start[k];
+    const int local = __builtin_amdgcn_readfirstlane((int)blockIdx.x - pg_start[k]);
     train_project_fill_body<KIND>(local * blockDim.x + threadIdx.x, imgs[k].u);
 }
 
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_batched_kernel(const 
                                                                           int k_images, AdamStep a_xyz, AdamStep a_chol,
                                                                           AdamStep a_feat, int step) {
     const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
-    const int local = (int)blockIdx.x - pg_start[k];
-    const int last = pg_start[k + 1] - pg_start[k] - 1;
+    const int local = __builtin_amdgcn_readfirstlane((int)blockIdx.x - pg_start[k]);
+    const int last = __builtin_amdgcn_readfirstlane(pg_start[k + 1] - pg_start[k] - 1);
     train_reduce_update_body<KIND, FILL_NEXT, ADAN>(local, local == last, imgs[k].u, a_xyz, a_chol, a_feat, step);
 }
 
