@@ -99,34 +99,64 @@ __device__ __forceinline__ int2 pack_box(int mnx, int mny, int mxx, int mxy) {
 // screen): append it to the rows of the tiles of the new box that were not in the box it was binned with before.
 // `old`: prev_box[g], loaded by the caller together with its other inputs -- read here, after the caller's stores, it
 // would be one more dependent memory round trip at the end of a latency-bound kernel.
-__device__ __forceinline__ void fill_diff(int g, bool member, int mnx, int mny, int mxx, int mxy, int tiles_x,
-                                          int2 old, int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
-    member = member && mxx > mnx && mxy > mny;
-    const int2 nw = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
-    if (old.x == nw.x && old.y == nw.y) return;  // the usual case: same tiles as last time, nothing to do
-    prev_box[g] = nw;
-    if (!member) return;  // its old entries are dropped by the tile pass (they fail the membership test)
-    const int omnx = old.x & 0xffff, omxx = (int)((unsigned)old.x >> 16), omny = old.y & 0xffff,
-              omxy = (int)((unsigned)old.y >> 16);
-    const int w = mxx - mnx, nt = w * (mxy - mny);
+// In two halves: fill_diff_begin stores the new box and issues the FIRST trip's returning atomics, fill_diff_end stores
+// the ids into the slots they returned (and runs any further trips: boxes of more than GI2D_FILL_BATCH tiles).  A caller
+// puts its own stores between the two: they are then issued while the atomics are in flight instead of after their
+// round trip (a returning atomic is waited for in issue order, behind every store issued before it) -- the binning step
+// sits at the very end of the per-gaussian kernels' dependency chain, where this round trip cost the training update
+// kernel 4.8 of its 13.9 us.
+struct FillPending {
+    int c[GI2D_FILL_BATCH], p[GI2D_FILL_BATCH];
+    int nt, w, mnx, mny, omnx, omxx, omny, omxy, di, dj;  // nt == 0: nothing to append
+};
+__device__ __forceinline__ void fill_trip_issue(FillPending &f, int base, int tiles_x, int32_t *__restrict__ lists) {
     // GI2D_FILL_BATCH tiles per trip: the returning atomics of a trip are issued back to back, then the stores, so a
     // lane pays one round trip per trip instead of one per tile
-    int di = 0, dj = 0;
-    for (int base = 0; base < nt; base += GI2D_FILL_BATCH) {
-        int c[GI2D_FILL_BATCH], p[GI2D_FILL_BATCH];
 #pragma unroll
-        for (int q = 0; q < GI2D_FILL_BATCH; ++q) {
-            const int ti = mny + di, tj = mnx + dj;
-            const bool was = tj >= omnx && tj < omxx && ti >= omny && ti < omxy;  // still listed from before
-            c[q] = (base + q < nt && !was) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
-            if (++dj == w) dj = 0, ++di;
-        }
-#pragma unroll
-        for (int q = 0; q < GI2D_FILL_BATCH; ++q) p[q] = c[q] >= 0 ? atomicAdd(&lists[c[q]], 1) : GI2D_FAST_C;
-#pragma unroll
-        for (int q = 0; q < GI2D_FILL_BATCH; ++q)
-            if (p[q] < GI2D_FAST_C) lists[c[q] + GI2D_FAST_HDR + p[q]] = g;  // a fuller row is flagged by the tile pass
+    for (int q = 0; q < GI2D_FILL_BATCH; ++q) {
+        const int ti = f.mny + f.di, tj = f.mnx + f.dj;
+        const bool was = tj >= f.omnx && tj < f.omxx && ti >= f.omny && ti < f.omxy;  // still listed from before
+        f.c[q] = (base + q < f.nt && !was) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
+        if (++f.dj == f.w) f.dj = 0, ++f.di;
     }
+#pragma unroll
+    for (int q = 0; q < GI2D_FILL_BATCH; ++q) f.p[q] = f.c[q] >= 0 ? atomicAdd(&lists[f.c[q]], 1) : GI2D_FAST_C;
+}
+__device__ __forceinline__ void fill_trip_store(const FillPending &f, int g, int32_t *__restrict__ lists) {
+#pragma unroll
+    for (int q = 0; q < GI2D_FILL_BATCH; ++q)
+        if (f.p[q] < GI2D_FAST_C) lists[f.c[q] + GI2D_FAST_HDR + f.p[q]] = g;  // a fuller row is flagged by the tile pass
+}
+__device__ __forceinline__ FillPending fill_diff_begin(int g, bool member, int mnx, int mny, int mxx, int mxy,
+                                                       int tiles_x, int2 old, int2 *__restrict__ prev_box,
+                                                       int32_t *__restrict__ lists) {
+    FillPending f;
+    f.nt = 0;
+    member = member && mxx > mnx && mxy > mny;
+    const int2 nw = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
+    if (old.x == nw.x && old.y == nw.y) return f;  // the usual case: same tiles as last time, nothing to do
+    prev_box[g] = nw;
+    if (!member) return f;  // its old entries are dropped by the tile pass (they fail the membership test)
+    f.omnx = old.x & 0xffff, f.omxx = (int)((unsigned)old.x >> 16), f.omny = old.y & 0xffff,
+    f.omxy = (int)((unsigned)old.y >> 16);
+    f.mnx = mnx, f.mny = mny;
+    f.w = mxx - mnx, f.nt = f.w * (mxy - mny);
+    f.di = f.dj = 0;
+    fill_trip_issue(f, 0, tiles_x, lists);
+    return f;
+}
+__device__ __forceinline__ void fill_diff_end(int g, FillPending &f, int tiles_x, int32_t *__restrict__ lists) {
+    if (f.nt == 0) return;
+    fill_trip_store(f, g, lists);
+    for (int base = GI2D_FILL_BATCH; base < f.nt; base += GI2D_FILL_BATCH) {
+        fill_trip_issue(f, base, tiles_x, lists);
+        fill_trip_store(f, g, lists);
+    }
+}
+__device__ __forceinline__ void fill_diff(int g, bool member, int mnx, int mny, int mxx, int mxy, int tiles_x,
+                                          int2 old, int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
+    FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old, prev_box, lists);
+    fill_diff_end(g, f, tiles_x, lists);
 }
 // The tile box a gaussian with centre xy and INT radius rad is binned with -- the rule of map_gaussian_to_intersects
 // (forward.cu:161-166): radius > 0, not below the clip, box of the int radius.  False: it is in no tile.
@@ -233,22 +263,41 @@ __device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mx
 }
 // Binning step of one gaussian: its tile box (the rasterizer's radius_clip equals the projection's on this path), the
 // appends to the rows of tiles it has entered, and its record.
+// `between`: the caller's own stores, issued after the binning step's atomics and before the stores that wait for them
+// (fill_diff_begin / _end above).
+template <class Between>
+__device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
+                                        float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
+                                        float radius_clip, int2 old_box, int2 *__restrict__ prev_box,
+                                        int32_t *__restrict__ lists, float4 *__restrict__ recs, Between between) {
+    int mnx, mny, mxx, mxy;
+    const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
+    FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
+    write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
+                 radius);
+    between();
+    fill_diff_end(g, f, tiles_x, lists);
+}
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
                                         float radius_clip, int2 old_box, int2 *__restrict__ prev_box,
                                         int32_t *__restrict__ lists, float4 *__restrict__ recs) {
-    int mnx, mny, mxx, mxy;
-    const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
-    fill_diff(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
-    write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
-                 radius);
+    bin_one(g, xy, radius, has_tiles, ka, kb, kc, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists,
+            recs, [] {});
+}
+template <class Between>
+__device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
+                                              int tiles_x, int tiles_y, float radius_clip, int2 old_box,
+                                              int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+                                              float4 *__restrict__ recs, Between between) {
+    bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
+            old_box, prev_box, lists, recs, between);
 }
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
                                               int tiles_x, int tiles_y, float radius_clip, int2 old_box,
                                               int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
                                               float4 *__restrict__ recs) {
-    bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
-            old_box, prev_box, lists, recs);
+    bin_projected(g, o, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists, recs, [] {});
 }
 
 // partial-row code of gaussian g in tile (tx, ty) of its box: >= 0 gaussian-major row, < 0: -(big row) - 1

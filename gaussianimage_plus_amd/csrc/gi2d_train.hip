@@ -139,25 +139,25 @@ __device__ __forceinline__ AdamRows adam_load_rows(const TrainParams &P, int g) 
     r.mc = load_row3(P.m_chol, g), r.vc = load_row3(P.v_chol, g), r.mf = load_row3(P.m_feat, g), r.vf = load_row3(P.v_feat, g);
     return r;
 }
-__device__ __forceinline__ void adam_rows(const TrainParams &P, int g, AdamRows r, float gx, float gy,
-                                          const float (&gp)[3], const float (&gf)[3], const AdamStep &a_xyz,
-                                          const AdamStep &a_chol, const AdamStep &a_feat, float2 &new_xy,
-                                          Row3 &new_chol, Row3 &new_feat) {
-    const float nx = adam(r.x.x, gx, r.mx.x, r.vx.x, a_xyz), ny = adam(r.x.y, gy, r.mx.y, r.vx.y, a_xyz);
-    const float c0 = adam(r.c.a, gp[0], r.mc.a, r.vc.a, a_chol), c1 = adam(r.c.b, gp[1], r.mc.b, r.vc.b, a_chol),
-                c2 = adam(r.c.c, gp[2], r.mc.c, r.vc.c, a_chol);
-    const float f0 = adam(r.f.a, gf[0], r.mf.a, r.vf.a, a_feat), f1 = adam(r.f.b, gf[1], r.mf.b, r.vf.b, a_feat),
-                f2 = adam(r.f.c, gf[2], r.mf.c, r.vf.c, a_feat);
-    new_xy = make_float2(nx, ny);
-    new_chol.a = c0, new_chol.b = c1, new_chol.c = c2;
-    new_feat.a = f0, new_feat.b = f1, new_feat.c = f2;
-    store_row2(P.xyz, g, nx, ny);
+// The update in registers (r: rows in, updated rows out) ...
+__device__ __forceinline__ void adam_update_rows(AdamRows &r, float gx, float gy, const float (&gp)[3],
+                                                 const float (&gf)[3], const AdamStep &a_xyz, const AdamStep &a_chol,
+                                                 const AdamStep &a_feat) {
+    r.x.x = adam(r.x.x, gx, r.mx.x, r.vx.x, a_xyz), r.x.y = adam(r.x.y, gy, r.mx.y, r.vx.y, a_xyz);
+    r.c.a = adam(r.c.a, gp[0], r.mc.a, r.vc.a, a_chol), r.c.b = adam(r.c.b, gp[1], r.mc.b, r.vc.b, a_chol),
+    r.c.c = adam(r.c.c, gp[2], r.mc.c, r.vc.c, a_chol);
+    r.f.a = adam(r.f.a, gf[0], r.mf.a, r.vf.a, a_feat), r.f.b = adam(r.f.b, gf[1], r.mf.b, r.vf.b, a_feat),
+    r.f.c = adam(r.f.c, gf[2], r.mf.c, r.vf.c, a_feat);
+}
+// ... and its nine row stores (issued by the caller where they delay nothing: see fill_diff_begin)
+__device__ __forceinline__ void adam_store_rows(const TrainParams &P, int g, const AdamRows &r) {
+    store_row2(P.xyz, g, r.x.x, r.x.y);
     store_row2(P.m_xyz, g, r.mx.x, r.mx.y);
     store_row2(P.v_xyz, g, r.vx.x, r.vx.y);
-    store_row3(P.chol, g, c0, c1, c2);
+    store_row3(P.chol, g, r.c.a, r.c.b, r.c.c);
     store_row3(P.m_chol, g, r.mc.a, r.mc.b, r.mc.c);
     store_row3(P.v_chol, g, r.vc.a, r.vc.b, r.vc.c);
-    store_row3(P.feat, g, f0, f1, f2);
+    store_row3(P.feat, g, r.f.a, r.f.b, r.f.c);
     store_row3(P.m_feat, g, r.mf.a, r.mf.b, r.mf.c);
     store_row3(P.v_feat, g, r.vf.a, r.vf.b, r.vf.c);
 }
@@ -370,21 +370,35 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     if (ADAN) {
         adan_rows(P, g, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
     } else {
-        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
+        adam_update_rows(rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
+        new_xy = rows.x, new_chol = rows.c, new_feat = rows.f;
     }
+    // Everything this lane still has to store that does not wait for the binning step's atomics: the optimizer's rows
+    // (Adam; Adan stored its own above) and the best-model snapshot -- the state dict after this step's update
+    // (train.py:137 copies it after train_iter returned), from the registers the update left, not read back through
+    // memory, one 8- or 12-byte store per row.
+    const auto store_rest = [&] {
+        if (!ADAN) adam_store_rows(P, g, rows);
+        if (snapshot) {
+            store_row2(best.xyz, g, new_xy.x, new_xy.y);
+            store_row3(best.chol, g, new_chol.a, new_chol.b, new_chol.c);
+            store_row3(best.feat, g, new_feat.a, new_feat.b, new_feat.c);
+            if (best.bound) store_row3(best.bound, g, bound3[0], bound3[1], bound3[2]);
+        }
+    };
 #if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 4) /* development aid (wrong results): the next iteration is not prepared */
     if (FILL_NEXT && new_xy.x == 12345.678f) {
 #else
     if (FILL_NEXT) {
 #endif
-        // same code path as train_project_fill_kernel, on the values just written
+        // same code path as train_project_fill_kernel, on the values just computed
         // (The record-set lookup stays HERE.  Hoisted to the top of the kernel together with begin_binning -- either
         // one alone is fine -- the build keeps one more SGPR alive across the whole kernel, spills SGPRs to VGPR lanes,
         // and a stretch of iterations stops being equal to the same iterations issued one by one: measured,
         // deterministic, and worth nothing in time.)
         begin_binning(g, next.status);
         float4 *recs = recs_for_binning(next.recs, g == 0);
-        // From the rows just written, still in registers (no store -> load round trip).  The empty asm makes them
+        // From the rows just computed, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
         // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
         // would no longer be bitwise equal to the same iterations issued one by one (1-ulp differences, measured).
@@ -395,23 +409,19 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         const ProjOut o =
             project_one<KIND>(0, next.clip_coe, &mean2, par2, rot_of<KIND>(par2), img_w, img_h, tiles_x, tiles_y,
                               radius_clip);
-        xys[g] = o.xy;
-        radii[g] = o.radius;
-        store_row3(conics, g, o.k0, o.k1, o.k2);
-        next.num_tiles_hit[g] = o.tiles_hit;
-        // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box)
+        // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box).
+        // Order of the tail: the binning step's returning atomics (gaussians that entered a tile), then every other
+        // store of the lane, then the list stores that need the atomics' results.
         bin_projected(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, box,
-                      next.prev_box, next.lists, recs);
-    }
-    if (snapshot) {  // the state dict after this step's update (train.py:137 copies it after train_iter returned):
-        // from the registers the update left, not read back through memory (a store -> load round trip at the end of
-        // nearly every iteration while the fit still improves)
-        // whole rows: one 8- or 12-byte store per row instead of one per float (the update kernel ends when its last
-        // store is acknowledged, and three dword stores to one row write its cache lines three times)
-        store_row2(best.xyz, g, new_xy.x, new_xy.y);
-        store_row3(best.chol, g, new_chol.a, new_chol.b, new_chol.c);
-        store_row3(best.feat, g, new_feat.a, new_feat.b, new_feat.c);
-        if (best.bound) store_row3(best.bound, g, bound3[0], bound3[1], bound3[2]);
+                      next.prev_box, next.lists, recs, [&] {
+                          xys[g] = o.xy;
+                          radii[g] = o.radius;
+                          store_row3(conics, g, o.k0, o.k1, o.k2);
+                          next.num_tiles_hit[g] = o.tiles_hit;
+                          store_rest();
+                      });
+    } else {
+        store_rest();
     }
 }
 
@@ -984,7 +994,9 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
         }
         float2 new_xy;
         Row3 new_chol, new_feat;
-        adam_rows(P, g, rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat, new_xy, new_chol, new_feat);
+        adam_update_rows(rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
+        adam_store_rows(P, g, rows);
+        new_xy = rows.x, new_chol = rows.c, new_feat = rows.f;
         if (snapshot) {  // from registers, not read back through memory
             best.xyz[2 * g] = new_xy.x;
             best.xyz[2 * g + 1] = new_xy.y;
