@@ -432,8 +432,10 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         else
             rank = 0, lo = 0, hi = count;
         for (int q = lo; q < hi; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
-        if (!(e < sorted && rank == e)) row[GI2D_FAST_HDR + rank] = g;
-        emit(rank, g, u == 0 ? r0 : load_record(recs, g));
+        const bool in_place = e < sorted && rank == e;  // an entry of the ascending part that nothing in front of it moved
+        if (!in_place) row[GI2D_FAST_HDR + rank] = g;
+        // ... and whose optimistic staging at rank = position (before the barrier) therefore already is the final one
+        if (!(OPTIMISTIC && u == 0 && in_place)) emit(rank, g, u == 0 ? r0 : load_record(recs, g));
     }
     if (OPTIMISTIC) __syncthreads();  // OPTIMISTIC callers need no barrier of their own after the call
     return len;

@@ -45,8 +45,13 @@ UNIFORM = [(96, 160, 1500), (160, 96, 2100), (96, 160, 700)]
 MIXED = [(96, 160, 1500), (50, 70, 400), (128, 128, 2500), (33, 200, 900)]
 
 
+# each image alone runs its per-gaussian kernels in 64-lane workgroups (N <= 32768), the batch of three in 256-lane ones
+BIG = [(256, 384, 15000), (384, 256, 14000), (256, 384, 13000)]
+
+
 @pytest.mark.parametrize("kind,optimizer,sizes", [("cholesky", "adan", UNIFORM), ("covariance", "adam", MIXED),
-                                                  ("scale_rot", "adam", MIXED), ("cholesky", "adam", MIXED[:1])])
+                                                  ("scale_rot", "adam", MIXED), ("cholesky", "adam", MIXED[:1]),
+                                                  ("cholesky", "adam", BIG), ("covariance", "adam", BIG)])
 def test_batched_iterations_equal_single_image_calls(kind, optimizer, sizes):
     """9 iterations as 1 + 3 + 5 (stretches: the update kernel also starts the next iteration) of K images in one
     launch per kernel == the same iterations of every image alone."""
@@ -62,6 +67,24 @@ def test_batched_iterations_equal_single_image_calls(kind, optimizer, sizes):
         a.check_status(), b.check_status()
         _assert_same(a, b, f"{kind}/{optimizer} image {i}")
         assert int(a.best_info[1]) > 0  # a snapshot was taken: the decision logic ran
+
+
+@pytest.mark.parametrize("k", [8, 11])
+def test_xcd_mapped_batch_equals_single_image_calls(k):
+    """Eight or more images with the same tile count: image i's tiles go to the workgroups b with b % 8 == i % 8 (one
+    image per XCD's L2); with 11 images three XCDs carry a second image and five run one idle slot.  Same bits."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    sizes = [((96, 160) if i % 3 else (160, 96)) + (500 + 37 * i,) for i in range(k)]  # landscape and portrait: 60 tiles
+    alone, together = _fitters("covariance", "adam", sizes), _fitters("covariance", "adam", sizes)
+    batch = BatchFitter(together)
+    for count in (2, 4):
+        for f in alone:
+            f.train(count)
+        batch.train(count)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(alone, together)):
+        a.check_status(), b.check_status()
+        _assert_same(a, b, f"xcd-mapped image {i} of {k}")
 
 
 def test_batched_adaptive_schedule_equals_single_image_schedules():
