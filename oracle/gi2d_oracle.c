@@ -5,18 +5,22 @@
  * may import, link or call this file.  It is the checker used by tests/, by
  * __graft_entry__.smoke() and by bench.py's `cpu_baseline` leg.
  *
- * PARITY STATUS: the reference holds no test, fixture or CPU implementation of the 2D
- * projection / sum rasterizer, so no vector of the reference's OWN
- * tests pins this file.  What pins it (tests/test_ref_vectors_cpu.py against
- * tests/golden/ref_vectors.npz, generated by tests/golden/make_ref_vectors.py):
- *   - outputs of the reference itself run in the dev container: the Python helpers of
- *     gsplat/gsplat/_torch_impl.py (compute_cov2d_bounds, get_tile_bbox,
+ * PARITY STATUS: pinned by outputs of the reference itself run in the dev container (the
+ * reference holds no test or fixture of the 2D path and its kernels are CUDA-only, SURVEY.md
+ * section 8c; what it can produce on a CPU is its Python layer gsplat/gsplat/_torch_impl.py):
+ *   - tests/golden/ref_vectors.npz (make_ref_vectors.py): compute_cov2d_bounds, get_tile_bbox,
  *     map_gaussian_to_intersects, get_tile_bin_edges -- the CPU side of the reference's
- *     test_cov2d_bounds / test_map_gaussians / test_get_tile_bin_edges), committed as arrays;
- *   - float64 autograd of the formulas forward.cu / foward2d.cu define, an independent
- *     derivation of both backward kernels.
- * Still unpinned by anything outside this repo: the rounding of CUDA's __expf next to the
- * 1/255 cut-off (masked in the tests).  All citations are relative to
+ *     test_cov2d_bounds / test_map_gaussians / test_get_tile_bin_edges -- and the projection
+ *     forward of the three parameterisations through them, committed as arrays;
+ *   - tests/golden/refras_vectors.npz (make_refras_vectors.py): the rasterizer forward AND backward
+ *     from the reference's own CPU rasterizer, _torch_impl.rasterize_forward (:354-421), called
+ *     once per gaussian (one contributor per list: T = 1, its term of the sum rasterizer), the
+ *     images summed, the gradients by torch autograd through the same calls;
+ *   - float64 autograd of the inverse-covariance map for the projection VJPs, with the
+ *     documented double count of the off-diagonal term.
+ * tests/test_ref_vectors_cpu.py holds this file to those arrays.  Outside any CPU pin: the rounding
+ * of CUDA's __expf next to the 1/255 cut-off (pairs inside a band around it are flagged by
+ * pair_eval and skipped by the comparisons).  All citations are relative to
  * /root/reference/gsplat/gsplat/cuda/csrc/.
  *
  * Plain C11 + OpenMP.  fp32 arithmetic follows the CUDA expressions operand by

@@ -3,9 +3,10 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  The product package never imports this module.
 
-Parity status: pinned by outputs of the reference's own Python helpers and by float64 autograd
-(tests/golden/ref_vectors.npz), not by a fixture of the reference's tests (it has none for this path);
-see the header of gi2d_oracle.c.
+Parity status: pinned by arrays the reference's own Python layer produced in the dev container -- its helpers for
+projection / binning (tests/golden/ref_vectors.npz) and its CPU rasterizer `_torch_impl.rasterize_forward` + autograd for
+the tile rasterizer forward and backward (tests/golden/refras_vectors.npz) -- not by a fixture of the reference's tests
+(it has none for this path); see the header of gi2d_oracle.c.
 """
 from __future__ import annotations
 
