@@ -119,8 +119,16 @@ __device__ __forceinline__ void fill_trip_issue(FillPending &f, int base, int ti
         f.c[q] = (base + q < f.nt && !was) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
         if (++f.dj == f.w) f.dj = 0, ++f.di;
     }
+#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 32) /* development aid (wrong results): appends without a returning atomic */
+#pragma unroll
+    for (int q = 0; q < GI2D_FILL_BATCH; ++q) {
+        if (f.c[q] >= 0) __hip_atomic_fetch_or(&lists[f.c[q] + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f.p[q] = f.c[q] >= 0 ? GI2D_FAST_C - 1 : GI2D_FAST_C;
+    }
+#else
 #pragma unroll
     for (int q = 0; q < GI2D_FILL_BATCH; ++q) f.p[q] = f.c[q] >= 0 ? atomicAdd(&lists[f.c[q]], 1) : GI2D_FAST_C;
+#endif
 }
 __device__ __forceinline__ void fill_trip_store(const FillPending &f, int g, int32_t *__restrict__ lists) {
 #pragma unroll
