@@ -85,7 +85,8 @@ struct FusedLds {
 };
 
 // measured: 26.5 KB still leaves room for six workgroups per CU, 27.1 KB does not
-static_assert(sizeof(FusedLds) <= 26624, "FusedLds: the sixth workgroup per CU needs <= 26 KB (see GI2D_FUSED_OCC)");
+static_assert(GI2D_FUSED_OCC < 6 || sizeof(FusedLds) <= 26624,
+              "FusedLds: the sixth workgroup per CU needs <= 26 KB (see GI2D_FUSED_OCC)");
 
 // MODE 0: `vsrc` is the gradient image v_output[H,W,3].
 // MODE 1: `vsrc` is the target image gt[H,W,3]; the pixel gradient is that of mean((clamp(out,0,1) - gt)^2):
