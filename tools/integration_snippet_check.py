@@ -13,3 +13,15 @@ import gaussianimage_plus_amd.quantize as q
 sys.modules["quantize"] = q
 from quantize import *
 print(UniformQuantizer, HybirdQuant)
+
+# INTEGRATION.md section 4 "Several images per launch"
+from gaussianimage_plus_amd.trainer import BatchFitter
+images_hwc_cuda = [synthetic_image(128, 192, 5).cuda(), synthetic_image(192, 128, 6).cuda(), synthetic_image(96, 96, 7).cuda()]
+fits = [NativeFitter(g, 800, kind="covariance", lr=0.018, eps=1e-15, max_points=2000, track_best=True,
+                     device_resident=True) for g in images_hwc_cuda]
+BatchFitter(fits).fit(500, prune_iter=100, grow_iter=100)
+psnrs = [f.load_best() for f in fits]
+for f in fits:
+    f.check_status()
+print("batched fit: best PSNR per image", [round(p, 2) for p in psnrs], "gaussians", [f.n for f in fits])
+assert all(p > 20 for p in psnrs)
