@@ -607,7 +607,10 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         GI2D_BWD_TRACE(8);  // this lane's item is done (lane 0: not the slowest one)
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 5 /* development aid: budget of the item loop */
         if (n_items >= 0) {
-            if (res[0] + res[PSTR - 1] == 12345.678f) sm.part[0] = res[0];
+            float all = 0.f;  // every component stays live: the cut must not let the compiler drop part of the loop
+#pragma unroll
+            for (int q = 0; q < PSTR; ++q) all += res[q];
+            if (it < round1 && all == 12345.678f) sm.part[0] = all;
             return;
         }
 #endif
