@@ -254,6 +254,10 @@ def synthetic_image(h: int, w: int, seed: int) -> torch.Tensor:
 
 
 def load_images(path: str | None, count: int, h: int, w: int) -> List[torch.Tensor]:
+    if path and path.endswith(".npz"):  # a pixel fixture: one uint8 [H, W, 3] array per image (tests/golden/kodak24.npz)
+        import numpy as np
+        z = np.load(path)
+        return [torch.from_numpy(z[k].astype("float32") / 255.0) for k in sorted(z.files)[:count or None]]
     if path:
         import numpy as np
         from PIL import Image
@@ -265,7 +269,8 @@ def load_images(path: str | None, count: int, h: int, w: int) -> List[torch.Tens
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--dataset", type=str, default=None, help="directory of images (e.g. datasets/kodak)")
+    ap.add_argument("--dataset", type=str, default=None,
+                    help="directory of images (e.g. datasets/kodak) or an .npz of uint8 [H,W,3] arrays (tests/golden/kodak24.npz)")
     ap.add_argument("--synthetic", type=int, default=24, help="number of synthetic 768x512 images if no dataset")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=768)

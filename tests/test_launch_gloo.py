@@ -147,3 +147,15 @@ def test_eight_ranks_rehearsal_even_uneven_and_idle_ranks():
         assert abs(m["sum_train_s"] - sum(0.25 * (i + 1) for i in range(count))) < 1e-9
         assert abs(m["avg_num_gaussians"] - (1000 + (count - 1) / 2)) < 1e-9
         assert abs(m["avg_eval_s"] - 0.002) < 1e-12
+
+
+def test_launcher_reads_the_kodak_pixel_fixture(golden_dir):
+    """`--dataset tests/golden/kodak24.npz`: the Kodak pictures without the reference checkout (18 landscape, 6
+    portrait, float [H, W, 3] in [0, 1] as utils.py:21-26 image_path_to_tensor hands them to the trainer)."""
+    from gaussianimage_plus_amd.launch import load_images
+    imgs = load_images(os.path.join(golden_dir, "kodak24.npz"), 24, 0, 0)
+    assert len(imgs) == 24
+    shapes = [tuple(im.shape) for im in imgs]
+    assert shapes.count((512, 768, 3)) == 18 and shapes.count((768, 512, 3)) == 6
+    assert all(im.dtype == torch.float32 and 0.0 <= float(im.min()) and float(im.max()) <= 1.0 for im in imgs)
+    assert len(load_images(os.path.join(golden_dir, "kodak24.npz"), 3, 0, 0)) == 3
