@@ -206,3 +206,32 @@ def test_batched_entry_rejects_bad_batches():
     assert rc != 0 and b"batch table" in lib.gi2d_last_error_string()
     with pytest.raises(AssertionError):
         BatchFitter([a, b])
+    # a table that is not 16-byte aligned, more than 64 images, no images
+    c = _fitters("cholesky", "adam", [(64, 64, 150)])[0]
+    two = (C.c_void_p * 2)(C.addressof(a.state), C.addressof(c.state))
+    big = torch.empty(int(lib.gi2d_batch_bytes(64)) + 64, dtype=torch.uint8, device=DEV)
+    rc = lib.gi2d_train_steps_batched(2, two, big.data_ptr() + 4, big.numel() - 4, lr3, 0.9, 0.999, 1e-8, 1, 1, None)
+    assert rc != 0 and b"aligned" in lib.gi2d_last_error_string()
+    many = (C.c_void_p * 65)(*([C.addressof(a.state)] * 65))
+    assert lib.gi2d_train_steps_batched(65, many, big.data_ptr(), big.numel(), lr3, 0.9, 0.999, 1e-8, 1, 1, None) != 0
+    assert lib.gi2d_train_steps_batched(0, many, big.data_ptr(), big.numel(), lr3, 0.9, 0.999, 1e-8, 1, 1, None) != 0
+    assert lib.gi2d_train_steps_batched(2, two, big.data_ptr(), big.numel(), lr3, 0.9, 0.999, 1e-8, 0, 1, None) != 0  # step 0
+    # count 0: nothing to do, nothing touched
+    before = a.xyz.clone()
+    assert lib.gi2d_train_steps_batched(2, two, big.data_ptr(), big.numel(), lr3, 0.9, 0.999, 1e-8, 1, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a.xyz, before)
+
+
+def test_sixty_four_images_in_one_launch():
+    """The table's limit (one ballot finds a workgroup's image): 64 small images of three sizes, two iterations."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    sizes = [[(48, 64, 120), (64, 48, 90), (33, 50, 60)][i % 3] for i in range(64)]
+    alone, together = _fitters("covariance", "adam", sizes, track_best=False), _fitters("covariance", "adam", sizes,
+                                                                                      track_best=False)
+    for f in alone:
+        f.train(2)
+    BatchFitter(together).train(2)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(alone, together)):
+        _assert_same(a, b, f"image {i} of 64")
