@@ -26,7 +26,13 @@ namespace gi2d {
 #define GI2D_FAST_HDR 16                             /* header words in front of a row's ids */
 #define GI2D_FAST_LROW (GI2D_FAST_C + GI2D_FAST_HDR) /* words per row */
 #define GI2D_FAST_EPT (GI2D_FAST_C / 256)            /* list entries per lane of the 256-lane tile workgroup */
-#define GI2D_FAST_S 16                               /* gaussian-major partial rows per gaussian */
+#define GI2D_FAST_S 32                               /* gaussian-major partial rows per gaussian: a gaussian on <= 32
+                                                        tiles finds its rows by position in its box.  16 left every
+                                                        gaussian on 17..32 tiles (a few per cent of a TRAINED scene:
+                                                        flat regions end up under gaussians 50..100 px wide) to a binary
+                                                        search per tile in the tile's id list -- 8 dependent loads each,
+                                                        32 searches per lane: the training update kernel of a Kodak fit
+                                                        took 166 us per 24-image launch, 71 us with 32 rows */
 #ifndef GI2D_FILL_BATCH
 #define GI2D_FILL_BATCH 16                           /* row-header atomics a lane keeps in flight */
 #endif

@@ -295,6 +295,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 // because dy is constant along a row.  A gaussian owns at most 8 items; their partials are handed to the
 // lane that owns the gaussian through LDS and added in row order.
 #define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
+static_assert(GI2D_BWD_ITEMS == 256, "round index = item >> 8 below");
 #ifndef GI2D_BWD_PART_ROWS
 #define GI2D_BWD_PART_ROWS 176 /* item rows of the LDS hand-off buffer: most tiles of a 50 000-gaussian 768x512 image
                                   (155 items on average) hand over in one pass; 192 rows (27.1 KB in the single-pass tile
@@ -464,34 +465,80 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         wsum = sm.wsum;
         __syncthreads();
     }
-    if ((tid & ~63) < len || wv == 0) {  // waves without entries have nothing to place (wave 0 also closes off[])
+    // items of the tile per class; more than one round of them?  (tile-uniform: every wave needs it for the barriers)
+    unsigned long long total = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) total += (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
+    const int n_total = bwd_field_sum(total);
+    const bool multi_round = n_total > GI2D_BWD_ITEMS;
+    // per class: the items in front of item 256 r in gaussian order, r = 1 .. 7 (multi-round tiles only; the hand-off
+    // buffer is idle until the first round has run)
+    unsigned long long *round_before = reinterpret_cast<unsigned long long *>(sm.part);
+    static_assert(sizeof(sm.part) >= 8 * sizeof(unsigned long long), "round_before[] lives in the hand-off buffer");
+#ifdef GI2D_BWD_GAUSSIAN_ORDER /* development aid: what the ordering by length buys */
+    const bool by_class = false;
+#else
+    const bool by_class = true;
+#endif
+    const bool placing = (tid & ~63) < len || wv == 0;  // waves without entries have nothing to place (wave 0 closes off[])
+    unsigned long long excl = 0ull;
+    if (placing) {
         // one item per row pair this gaussian reaches; its row / pixel-pair ranges ride along in sm.xr
         const BwdItemsOf mine = bwd_items_of(cull);
         if (tid < len) sm.xr[tid] = (cull >> 8) & 0xffffu;  // r0 | r1 << 4 | q0 << 8 | q1 << 12
-        unsigned long long before = 0ull, total = 0ull;  // items of the waves before this one / of the tile, per class
+        unsigned long long before = 0ull;  // items of the waves before this one, per class
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned long long wk = (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
-            total += wk;
-            if (k < wv) before += wk;
-        }
-        const unsigned long long excl = before + incl - mine.counts;  // per class: items of the gaussians before mine
-        const int orig0 = bwd_field_sum(excl);                        // first item of mine in gaussian order
+        for (int k = 0; k < 4; ++k)
+            if (k < wv) before += (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
+        excl = before + incl - mine.counts;         // per class: items of the gaussians before mine
+        const int orig0 = bwd_field_sum(excl);      // first item of mine in gaussian order
         if (tid < len) sm.off[tid] = (unsigned short)orig0;
-        if (tid == 0) sm.off[len] = (unsigned short)bwd_field_sum(total);
-        // where the items go: class by class when the whole tile fits one round, in gaussian order otherwise
-        // (then an item's round must be the round of its row in the hand-off buffer)
-#ifdef GI2D_BWD_GAUSSIAN_ORDER /* development aid: what the ordering by length buys */
-        const bool by_class = false;
-#else
-        const bool by_class = bwd_field_sum(total) <= GI2D_BWD_ITEMS;
-#endif
-        unsigned long long pos = excl + ((total << 16) + (total << 32) + (total << 48));  // + classes before, per field
-        for (int j = 0; j < mine.n; ++j) {
-            const int c = j == 0 ? mine.c_first : (j == mine.n - 1 ? mine.c_last : mine.c_mid);
-            const int slot = by_class ? (int)((pos >> (16 * c)) & 0xffffu) : orig0 + j;
-            pos += 1ull << (16 * c);
-            sm.item[slot] = (unsigned short)(tid | j << 8);
+        if (tid == 0) sm.off[len] = (unsigned short)n_total;
+        // Where the items go: class by class.  A tile of more than one round (trained scenes: gaussians several tiles
+        // wide, 300 ... 600 items per tile) keeps its ROUNDS in gaussian order -- an item's round must be the round of
+        // its row in the hand-off buffer -- and orders the items of each round by class among themselves, which needs
+        // the per-class counts in front of every round boundary first.
+        if (!multi_round) {
+            unsigned long long pos = excl + ((total << 16) + (total << 32) + (total << 48));  // + classes before, per field
+            for (int j = 0; j < mine.n; ++j) {
+                const int c = j == 0 ? mine.c_first : (j == mine.n - 1 ? mine.c_last : mine.c_mid);
+                const int slot = by_class ? (int)((pos >> (16 * c)) & 0xffffu) : orig0 + j;
+                pos += 1ull << (16 * c);
+                sm.item[slot] = (unsigned short)(tid | j << 8);
+            }
+        } else {
+            // the one gaussian whose items contain item 256 r publishes the counts in front of it
+            const int r_last = (orig0 + mine.n - 1) >> 8, b = r_last << 8;
+            if (mine.n > 0 && r_last > 0 && b >= orig0) {
+                unsigned long long before_b = excl;
+                for (int j = 0; j < b - orig0; ++j)  // j < n - 1: never the gaussian's last item
+                    before_b += 1ull << (16 * (j == 0 ? mine.c_first : mine.c_mid));
+                round_before[r_last] = before_b;
+            }
+        }
+    }
+    if (multi_round) {  // tile-uniform
+        __syncthreads();
+        if (placing && tid < len) {
+            const BwdItemsOf mine = bwd_items_of(cull);
+            const int orig0 = bwd_field_sum(excl), rounds = (n_total + GI2D_BWD_ITEMS - 1) / GI2D_BWD_ITEMS;
+            unsigned long long seen = excl;  // per class: items in front of the next one of mine, whole tile
+            int r_cur = -1;
+            unsigned long long r_before = 0ull, r_classes = 0ull;
+            for (int j = 0; j < mine.n; ++j) {
+                const int c = j == 0 ? mine.c_first : (j == mine.n - 1 ? mine.c_last : mine.c_mid);
+                const int r = (orig0 + j) / GI2D_BWD_ITEMS;
+                if (r != r_cur) {
+                    r_cur = r;
+                    r_before = r == 0 ? 0ull : round_before[r];
+                    const unsigned long long in_round = (r + 1 < rounds ? round_before[r + 1] : total) - r_before;
+                    r_classes = (in_round << 16) + (in_round << 32) + (in_round << 48);  // field c: classes < c
+                }
+                const unsigned long long p = seen - r_before + r_classes;
+                const int slot = by_class ? r * GI2D_BWD_ITEMS + (int)((p >> (16 * c)) & 0xffffu) : orig0 + j;
+                seen += 1ull << (16 * c);
+                sm.item[slot] = (unsigned short)(tid | j << 8);
+            }
         }
     }
     __syncthreads();

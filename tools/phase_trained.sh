@@ -1,0 +1,33 @@
+#!/bin/bash
+# Development aid: phase_budget.sh / phase_lds.sh on a TRAINED scene -- one Kodak picture fitted with the adaptive
+# schedule (tools/trained_scene.py), then the single-pass tile kernel cut off after each phase (GI2D_STOP_AFTER = 1 head,
+# 2 forward loop, 3 pixel out + gradient, 4 backward items built, 5 backward item loop, 0 = whole kernel) on the frozen
+# result: VALU instructions, VALU busy quad-cycles and kernel time per cut.
+#   gpurun -- 'bash tools/phase_trained.sh [image] [iterations]'
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/phase_trained
+rm -rf $OUT && mkdir -p $OUT
+python3 tools/trained_scene.py fit ${1:-0} ${2:-50000} /tmp/trained_scene.pt || exit 1
+for v in ${PHASES:-1 2 3 4 5 0}; do
+  rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o
+  make -s -C gaussianimage_plus_amd/csrc EXTRA="-DGI2D_STOP_AFTER=$v $XFLAGS" 2>&1 | grep -E "error"
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc$v -o run -- python3 $GRAFT_REPO_ROOT/tools/trained_scene.py steps 20 > /dev/null 2> $OUT/pmc$v.log)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st$v -o run -- python3 $GRAFT_REPO_ROOT/tools/trained_scene.py steps 100 > $OUT/st$v.out 2> $OUT/st$v.log)
+  python3 - $v $OUT <<'PY'
+import csv, glob, sys, collections
+v, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for f in glob.glob(f"{out}/pmc{v}/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "fast_fwdbwd" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+t = None
+for f in glob.glob(f"{out}/st{v}/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "fast_fwdbwd" in r["Name"]:
+            t = float(r["AverageNs"]) / 1e3
+print(f"stop_after={v}: {t:.2f} us  " + "  ".join(f"{k}={sum(x)/len(x)/1e6:.3f}M" for k, x in sorted(acc.items())), flush=True)
+PY
+done
+cat $OUT/st0.out
+rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o; make -s -C gaussianimage_plus_amd/csrc
