@@ -41,7 +41,7 @@ struct BestSnap {
 struct NextFill {
     float clip_coe;
     int32_t *num_tiles_hit, *lists, *status, *tile_order;
-    int2 *prev_box;
+    PrevBox *prev_box;
     RecSets recs;
 };
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__r
                                                         const float *__restrict__ conics,
                                                         const float *__restrict__ colors,
                                                         const float *__restrict__ opacities, int tiles_x, int tiles_y,
-                                                        float radius_clip, int2 *__restrict__ prev_box,
+                                                        float radius_clip, PrevBox *__restrict__ prev_box,
                                                         int32_t *__restrict__ lists, RecSets rs,
                                                         int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void project_fill_one(
     float4 *recs = recs_for_binning(bt.recs, g == 0);
     if (g >= n) return;
     // every input is requested before the first store below (the outputs may alias them as far as the compiler knows)
-    const int2 old_box = bt.prev_box[g];
+    const PrevBox old_box = bt.prev_box[g];
     const float opac = bt.opacities[g], cr = bt.colors[3 * g], cg = bt.colors[3 * g + 1], cb = bt.colors[3 * g + 2];
     const ProjOut o = project_one<KIND>(g, clip_coe, means2d, p0, p1, img_w, img_h, tiles_x, tiles_y, radius_clip);
     xys[g] = o.xy;
@@ -111,7 +111,11 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int L = tile_list_head<false>(
         ids, grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
             const GaussRec &r = br.r;
-            const int slot = partial_slot(g, br.box, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
+            // the backward kernel finds the entry's partial row by this code; a pool row past the pool's end (the
+            // overflow status is raised here) becomes "no row"
+            int slot = partial_slot(g, br.box, tx, ty, br.pool);
+            float4 *row = partial_row(slot, partial_g, partial_big, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, status);
+            if (!row) slot = GI2D_NO_ROW;
             if (rank < GI2D_TILE_LIST_CAP) {
                 const unsigned mask = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
                 fwd_stage_entry(sm.f, rank, r, mask);
@@ -119,12 +123,12 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
                 dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
                 dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
                 dst[2] = make_float4(r.cb, __int_as_float(slot), __int_as_float(g), __int_as_float((int)mask));
-            } else if (slot >= 0) {
+            } else if (row) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
-                partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
-                partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
+                row[0] = z;
+                row[1] = z;
+                row[2] = z;
             }
         });
     __syncthreads();
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
         mask = (unsigned)__float_as_int(q2.w);
     }
     float4 *dst = nullptr;
-    if (tid < len)
+    if (tid < len && slot != GI2D_NO_ROW)  // validated by the forward kernel that wrote the code
         dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
     bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
 }
@@ -191,15 +195,16 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
 // Empty state of a workspace: every tile row empty, no gaussian binned, identity tile order.
 __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n, int32_t *__restrict__ lists,
                                                            int32_t *__restrict__ tile_order,
-                                                           int2 *__restrict__ prev_box, int32_t *__restrict__ ver) {
+                                                           PrevBox *__restrict__ prev_box, int32_t *__restrict__ ver) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2) ver[i] = 0;
+    if (i == 0) lists[GI2D_POOL_CURSOR] = 0;  // the row pool is empty
     if (i < num_tiles) {
         lists[(size_t)i * GI2D_FAST_LROW] = 0;
         lists[(size_t)i * GI2D_FAST_LROW + 1] = 0;
         tile_order[i] = i;
     }
-    if (i < n) prev_box[i] = make_int2(0, 0);
+    if (i < n) prev_box[i] = no_box();
 }
 
 // ----------------------------------------------------------------- forward + backward in one pass
@@ -250,14 +255,14 @@ __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kerne
 
 // --------------------------------------------------------------------------------------- reduce
 __global__ __launch_bounds__(256) void fast_reduce_kernel(
-    int n, const int2 *__restrict__ prev_box, int tiles_x, int tiles_y, const int32_t *__restrict__ gids_sorted,
+    int n, const PrevBox *__restrict__ prev_box, int tiles_x, int tiles_y, const int32_t *__restrict__ gids_sorted,
     const int2 *__restrict__ tile_bins, const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big,
     float2 *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_rgb, float *__restrict__ v_opacity,
     float4 *__restrict__ v_abs_xy) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     float acc[11];
-    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
-               partial_big, acc);
+    const PrevBox pb = g < n ? prev_box[g] : no_box();
+    reduce_one(g, make_int2(pb.x, pb.y), pb.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big, acc);
     if (g < n) store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
 }
 
@@ -282,7 +287,7 @@ struct NextProject {
 template <int KIND, bool FILL_NEXT>
 __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     int n, int role_blocks, float2 *xys, int32_t *radii, float *conics, int tiles_x, int tiles_y, float radius_clip,
-    int2 *prev_box, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
+    PrevBox *prev_box, const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, const float *__restrict__ p0,
     const float *__restrict__ p1, float img_w, float img_h, float2 *__restrict__ v_xy, float *__restrict__ v_conic,
     float *__restrict__ v_rgb, float *__restrict__ v_opacity, float4 *__restrict__ v_abs_xy,
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
     }
     const int g = block * blockDim.x + threadIdx.x;
     int2 box = make_int2(0, 0);
+    int pool = -1;
     float conic[3] = {0.f, 0.f, 0.f};
     int radius = 0;
     if (g < n) {
@@ -312,8 +318,10 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
             conic[0] = q0.z, conic[1] = q0.w, conic[2] = q1.x;
             box = make_int2(__float_as_int(q2.w), __float_as_int(q3.x));
             radius = __float_as_int(q3.y);
+            pool = __float_as_int(q3.z);
         } else {
-            box = prev_box[g];
+            const PrevBox pb = prev_box[g];
+            box = make_int2(pb.x, pb.y), pool = pb.z;
             conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
             radius = radii[g];
         }
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256) void fast_reduce_project_kernel(
             par[0] = p0[3 * g], par[1] = p0[3 * g + 1], par[2] = p0[3 * g + 2];
     }
     float acc[11];
-    reduce_one(g, box, tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g, partial_big, acc);
+    reduce_one(g, box, pool, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big, acc);
     if (g >= n) return;
     store_grads(g, acc, v_xy, v_conic, v_rgb, v_opacity, v_abs_xy);
     ProjGrad r;
@@ -685,7 +693,7 @@ int gi2d_fast_rasterize_backward_reduce(int n, int tiles_x, int tiles_y, void *w
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int rbs = per_gaussian_block(n);
     hipLaunchKernelGGL(fast_reduce_kernel, dim3((n + rbs - 1) / rbs), dim3(rbs), 0, (hipStream_t)st, n,
-                       (const int2 *)w.prev_box, tiles_x, tiles_y, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g,
+                       (const PrevBox *)w.prev_box, tiles_x, tiles_y, w.gids_sorted, (const int2 *)w.tile_bins, w.partial_g,
                        w.partial_big, (float2 *)v_xy, v_conic, v_rgb, v_opacity, (float4 *)v_abs_xy);
     return check_launch("fast rasterize backward reduce");
 }

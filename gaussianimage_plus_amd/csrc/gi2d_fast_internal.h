@@ -42,6 +42,20 @@ namespace gi2d {
 #define GI2D_BIG_TILES_F 32
 #define GI2D_FAST_ROW 4 /* float4 per partial row: 48 bytes of data padded to one 64-byte line */
 
+// What the binning step remembers per gaussian: (x, y) the packed tile box it is binned with (pack_box; 0/0 = none),
+// z = first row of its run in the row pool (-1: none), w = rows of that run.  Only a gaussian on more than GI2D_FAST_S
+// tiles owns a run: GI2D_FAST_S rows per gaussian are reserved in the gaussian-major buffer, anything larger (a per
+// cent of a trained scene's gaussians, 50...100 px wide) gets box-many consecutive rows from the pool the first time its
+// box needs more than it holds -- a bump allocator (one returning atomic on the cursor word, in the header of tile
+// row 0; emptied with the workspace).  A run is addressed like the gaussian-major rows, by position in the box, so the
+// per-gaussian sum reads consecutive rows instead of searching every tile's id list for its rank (8 dependent loads per
+// tile: on a trained Kodak scene those searches were 23 of the end-of-step kernel's 38 us).  A pool that runs out hands
+// out rows past its end: the tile pass sees the row index, raises the overflow status and stores nothing; the sum skips
+// such a run; the caller falls back as for an overflowing tile row.
+typedef int4 PrevBox;
+#define GI2D_POOL_CURSOR 8 /* word of tile row 0's header (words 2..15 of a header are padding) */
+#define GI2D_NO_ROW ((int)0x80000000) /* partial-row code of an entry whose pool row lies past the pool's end */
+__host__ __device__ __forceinline__ PrevBox no_box() { return make_int4(0, 0, -1, 0); }
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // Workgroup size of the one-lane-per-gaussian kernels (project+fill, reduce+project backward, optimizer update):
 // single waves spread a small population over many CUs and shorten the dependent load chains
@@ -55,12 +69,14 @@ struct FastWs {
     int32_t *gids_sorted;  // == lists: tile_bins hold absolute word positions into it
     int32_t *tile_bins;    // [T * 2]            [row base + HDR, row base + HDR + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
-    int2 *prev_box;        // [N]                tile box each gaussian was last binned with (packed, 0/0 = none)
+    PrevBox *prev_box;     // [N]                tile box each gaussian was last binned with (packed, 0/0 = none) and
+                           //                    its rows in the pool (gaussians on > GI2D_FAST_S tiles; see PrevBox)
     float4 *recs;          // [2][N * 4]         one 64-byte record per gaussian as of the last binning step: what a tile
                            //                    pass needs of it, in ONE cache line (see write_record); two sets, see RecSets
     int32_t *ver;          // [2]                which record set is current (RecSets)
     float4 *partial_g;     // [N * S * 4]        gaussian-major partial rows (64 B each)
-    float4 *partial_big;   // [T * 256 * 4]      partial rows of gaussians on > S tiles, by (tile, rank)
+    float4 *partial_big;   // [T * 256 * 4]      the row POOL: partial rows of gaussians on > S tiles, one run of rows
+                           //                    per gaussian (its box in row-major order), allocated by the binning step
     int32_t *tile_order;   // [T]                tile handled by workgroup b of the single-pass tile kernel: a
                            //                    permutation that balances tile populations over the CUs
     size_t bytes;
@@ -81,8 +97,8 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     // depends on the gaussian count, so a workspace initialised for a capacity can be used with any smaller population
     w.tile_order = (int32_t *)(b + off);
     off += align_up(t * sizeof(int32_t));
-    w.prev_box = (int2 *)(b + off);
-    off += align_up(nn * sizeof(int2));
+    w.prev_box = (PrevBox *)(b + off);
+    off += align_up(nn * sizeof(PrevBox));
     w.ver = (int32_t *)(b + off);
     off += align_up(64 * sizeof(int32_t));
     w.recs = (float4 *)(b + off);
@@ -114,6 +130,7 @@ __device__ __forceinline__ int2 pack_box(int mnx, int mny, int mxx, int mxy) {
 struct FillPending {
     int c[GI2D_FILL_BATCH], p[GI2D_FILL_BATCH];
     int nt, w, mnx, mny, omnx, omxx, omny, omxy, di, dj;  // nt == 0: nothing to append
+    int pool;                                             // first pool row of the gaussian's run (-1: none)
 };
 __device__ __forceinline__ void fill_trip_issue(FillPending &f, int base, int tiles_x, int32_t *__restrict__ lists) {
     // GI2D_FILL_BATCH tiles per trip: the returning atomics of a trip are issued back to back, then the stores, so a
@@ -142,14 +159,21 @@ __device__ __forceinline__ void fill_trip_store(const FillPending &f, int g, int
         if (f.p[q] < GI2D_FAST_C) lists[f.c[q] + GI2D_FAST_HDR + f.p[q]] = g;  // a fuller row is flagged by the tile pass
 }
 __device__ __forceinline__ FillPending fill_diff_begin(int g, bool member, int mnx, int mny, int mxx, int mxy,
-                                                       int tiles_x, int2 old, int2 *__restrict__ prev_box,
+                                                       int tiles_x, PrevBox old, PrevBox *__restrict__ prev_box,
                                                        int32_t *__restrict__ lists) {
     FillPending f;
     f.nt = 0;
+    f.pool = old.z;
     member = member && mxx > mnx && mxy > mny;
     const int2 nw = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
     if (old.x == nw.x && old.y == nw.y) return f;  // the usual case: same tiles as last time, nothing to do
-    prev_box[g] = nw;
+    const int ntiles = member ? (mxx - mnx) * (mxy - mny) : 0;
+    int cap = old.w;
+    if (ntiles > GI2D_FAST_S && ntiles > cap) {  // its run of pool rows (see PrevBox): rare, and rarer still after the first time
+        f.pool = atomicAdd(&lists[GI2D_POOL_CURSOR], ntiles);
+        cap = ntiles;
+    }
+    prev_box[g] = make_int4(nw.x, nw.y, f.pool, cap);
     if (!member) return f;  // its old entries are dropped by the tile pass (they fail the membership test)
     f.omnx = old.x & 0xffff, f.omxx = (int)((unsigned)old.x >> 16), f.omny = old.y & 0xffff,
     f.omxy = (int)((unsigned)old.y >> 16);
@@ -168,7 +192,7 @@ __device__ __forceinline__ void fill_diff_end(int g, FillPending &f, int tiles_x
     }
 }
 __device__ __forceinline__ void fill_diff(int g, bool member, int mnx, int mny, int mxx, int mxy, int tiles_x,
-                                          int2 old, int2 *__restrict__ prev_box, int32_t *__restrict__ lists) {
+                                          PrevBox old, PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists) {
     FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old, prev_box, lists);
     fill_diff_end(g, f, tiles_x, lists);
 }
@@ -223,7 +247,7 @@ static inline RecSets rec_sets(const FastWs &w, int n) {
 // What a binning step needs besides the projection: colour / opacity for the records, the workspace's state.
 struct BinTarget {
     const float *colors, *opacities;
-    int2 *prev_box;
+    PrevBox *prev_box;
     int32_t *lists;
     RecSets recs;
     int32_t *status;
@@ -241,35 +265,39 @@ __device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ statu
 // The record a binning step leaves per gaussian -- everything a tile pass needs of it, gathered with four 16-byte loads
 // of ONE line instead of nine dwords from five arrays (each of the ~72 entries of a tile used to cost 5-6 line requests,
 // all 1536 tiles asking at once):
-//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, radius, -, -)
+//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, radius, pool, -)
 // a, b, c: conic; (hx, hy): half extents of the alpha >= 1/255 box (gi2d_common.h::cull_extent), computed here once per
 // gaussian instead of once per (tile, gaussian); box: the tile box it is binned with (0/0: in no tile), which is what
-// the tile pass tests membership against and derives the partial-row slot from.
+// the tile pass tests membership against and derives the partial-row slot from; pool: first row of its run in the row
+// pool (PrevBox).
 __device__ __forceinline__ void write_record(float4 *__restrict__ recs, int g, float2 xy, float a, float b, float c,
-                                             float opac, float cr, float cg, float cb, int2 box, int radius) {
+                                             float opac, float cr, float cg, float cb, int2 box, int radius, int pool) {
     float hx, hy;
     cull_extent(xy.x, xy.y, a, b, c, opac, hx, hy);
     float4 *r = recs + 4 * (size_t)g;
     r[0] = make_float4(xy.x, xy.y, a, b);
     r[1] = make_float4(c, opac, cr, cg);
     r[2] = make_float4(cb, hx, hy, __int_as_float(box.x));
-    r[3] = make_float4(__int_as_float(box.y), __int_as_float(radius), 0.f, 0.f);
+    r[3] = make_float4(__int_as_float(box.y), __int_as_float(radius), __int_as_float(pool), 0.f);
 }
 struct BinRec {
     GaussRec r;
     float hx, hy;
     int2 box;
+    int pool;
 };
 __device__ __forceinline__ BinRec load_record(const float4 *__restrict__ recs, int g) {
     const float4 *p = recs + 4 * (size_t)g;
     const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-    const float by = p[3].x;
+    const float4 q3 = p[3];
+    const float by = q3.x;
     BinRec o;
     o.r.gx = q0.x, o.r.gy = q0.y, o.r.a = q0.z, o.r.b = q0.w;
     o.r.c = q1.x, o.r.opac = q1.y, o.r.cr = q1.z, o.r.cg = q1.w;
     o.r.cb = q2.x, o.r.slot = -1, o.r.gid = g, o.r.pad = 0;
     o.hx = q2.y, o.hy = q2.z;
     o.box = make_int2(__float_as_int(q2.w), __float_as_int(by));
+    o.pool = __float_as_int(q3.z);
     return o;
 }
 __device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mxx, int &mxy) {
@@ -282,45 +310,58 @@ __device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mx
 template <class Between>
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
-                                        float radius_clip, int2 old_box, int2 *__restrict__ prev_box,
+                                        float radius_clip, PrevBox old_box, PrevBox *__restrict__ prev_box,
                                         int32_t *__restrict__ lists, float4 *__restrict__ recs, Between between) {
     int mnx, mny, mxx, mxy;
     const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
     FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
     write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
-                 radius);
+                 radius, f.pool);
     between();
     fill_diff_end(g, f, tiles_x, lists);
 }
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
-                                        float radius_clip, int2 old_box, int2 *__restrict__ prev_box,
+                                        float radius_clip, PrevBox old_box, PrevBox *__restrict__ prev_box,
                                         int32_t *__restrict__ lists, float4 *__restrict__ recs) {
     bin_one(g, xy, radius, has_tiles, ka, kb, kc, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists,
             recs, [] {});
 }
 template <class Between>
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
-                                              int tiles_x, int tiles_y, float radius_clip, int2 old_box,
-                                              int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+                                              int tiles_x, int tiles_y, float radius_clip, PrevBox old_box,
+                                              PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists,
                                               float4 *__restrict__ recs, Between between) {
     bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
             old_box, prev_box, lists, recs, between);
 }
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
-                                              int tiles_x, int tiles_y, float radius_clip, int2 old_box,
-                                              int2 *__restrict__ prev_box, int32_t *__restrict__ lists,
+                                              int tiles_x, int tiles_y, float radius_clip, PrevBox old_box,
+                                              PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists,
                                               float4 *__restrict__ recs) {
     bin_projected(g, o, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists, recs, [] {});
 }
 
-// partial-row code of gaussian g in tile (tx, ty) of its box: >= 0 gaussian-major row, < 0: -(big row) - 1
-__device__ __forceinline__ int partial_slot(int g, int2 box, int tx, int ty, int big_row) {
+// partial-row code of gaussian g in tile (tx, ty) of its box: >= 0 gaussian-major row, < 0: -(pool row) - 1
+// (`pool`: first row of its run, from its record)
+__device__ __forceinline__ int partial_slot(int g, int2 box, int tx, int ty, int pool) {
     int mnx, mny, mxx, mxy;
     unpack_box(box, mnx, mny, mxx, mxy);
-    const int w = mxx - mnx, ntiles = w * (mxy - mny);
-    if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + (ty - mny) * w + (tx - mnx);
-    return -big_row - 1;
+    const int w = mxx - mnx, ntiles = w * (mxy - mny), at = (ty - mny) * w + (tx - mnx);
+    if (ntiles <= GI2D_FAST_S) return g * GI2D_FAST_S + at;
+    return -(pool + at) - 1;
+}
+// Where the partial row with that code lives; nullptr (and the overflow status raised) for a pool row past the pool's end.
+__device__ __forceinline__ float4 *partial_row(int slot, float4 *__restrict__ partial_g, float4 *__restrict__ partial_big,
+                                               int pool_rows, int32_t *__restrict__ status) {
+    if (slot >= 0) return partial_g + GI2D_FAST_ROW * (size_t)slot;
+    const int row = -slot - 1;
+    if (row < 0 || row >= pool_rows) {  // the pool ran out (PrevBox): as a tile row that overflowed
+        atomicOr(&status[1], 1);
+        atomicOr(&status[2], 1);
+        return nullptr;
+    }
+    return partial_big + GI2D_FAST_ROW * (size_t)row;
 }
 
 #ifndef GI2D_HEAD_TRACE /* gi2d_fused_core.h defines it for its phase trace (development aid) */
@@ -539,11 +580,12 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
 }
 
 // acc[11] <- ordered sum of gaussian g's partial rows; `box`: the tile box g was binned with for the tile pass that
-// wrote them (prev_box[g] or the box field of its record; 0/0 for lanes without a gaussian).  Must be called by whole
-// waves.
-__device__ __forceinline__ void reduce_one(int g, int2 box, int tiles_x, const int32_t *__restrict__ gids_sorted,
-                                           const int2 *__restrict__ tile_bins, int num_tiles,
-                                           const float4 *__restrict__ partial_g,
+// wrote them and `pool` its run of pool rows (PrevBox / the fields of its record; 0/0 for lanes without a gaussian).
+// Must be called by whole waves.  Order of the sum (the reference-shaped ops use the same, gi2d_raster.hip): ascending
+// tile id up to GI2D_BIG_TILES_F tiles; beyond, lane l of the wave adds the box's tiles l, l + 64, ... and the 64 sums meet
+// in a fixed butterfly.
+static_assert(GI2D_FAST_S == GI2D_BIG_TILES_F, "gaussian-major rows up to the size where the order of the sum changes");
+__device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_rows, const float4 *__restrict__ partial_g,
                                            const float4 *__restrict__ partial_big, float (&acc)[11]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -569,31 +611,20 @@ __device__ __forceinline__ void reduce_one(int g, int2 box, int tiles_x, const i
             for (int q = 0; q < GI2D_REDUCE_BATCH; ++q)
                 if (k0 + q < ntiles) add_partial_row(acc, r[q][0], r[q][1], r[q][2]);
         }
-    } else if (mapped && ntiles <= GI2D_BIG_TILES_F) {
-        for (int i = mny; i < mxy; ++i)
-            for (int j = mnx; j < mxx; ++j) {
-                const int tile = i * tiles_x + j;
-                const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, g);
-                if (pos >= 0)
-                    add_partial<GI2D_FAST_ROW>(acc, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - list_base(tile)));
-            }
     }
-    unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F);
-    while (big) {  // a gaussian on > 32 tiles: the whole wave strides over its tiles
+    // a run that does not lie inside the pool was never written (partial_row): the overflow status is up
+    unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F && pool >= 0 && pool + ntiles <= pool_rows);
+#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 64) /* development aid (wrong results): gaussians on > 32 tiles are not summed */
+    big = 0ull;
+#endif
+    while (big) {  // a gaussian on > 32 tiles: the whole wave strides over its run of rows
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const int bx0 = __shfl(mnx, src, 64), by0 = __shfl(mny, src, 64);
-        const int bw = __shfl(mxx, src, 64) - bx0, bn = __shfl(ntiles, src, 64);
-        const int bg = __shfl(g, src, 64);
+        const int bn = __shfl(ntiles, src, 64), bpool = __shfl(pool, src, 64);
         float part[11];
 #pragma unroll
         for (int q = 0; q < 11; ++q) part[q] = 0.f;
-        for (int t = lane; t < bn; t += 64) {
-            const int tile = (by0 + t / bw) * tiles_x + bx0 + t % bw;
-            const int pos = find_in_tile(gids_sorted, tile_bins, tile, num_tiles, bg);
-            if (pos >= 0)
-                add_partial<GI2D_FAST_ROW>(part, partial_big, (size_t)tile * GI2D_TILE_LIST_CAP + (pos - list_base(tile)));
-        }
+        for (int t = lane; t < bn; t += 64) add_partial<GI2D_FAST_ROW>(part, partial_big, (size_t)bpool + t);
 #pragma unroll
         for (int q = 0; q < 11; ++q) {
             float v = part[q];

@@ -99,6 +99,7 @@ __device__ __forceinline__ void fused_tile(
     float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
     float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
     const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int pool_rows = tiles_x * tiles_y * GI2D_TILE_LIST_CAP;  // rows of `partial_big`, the row pool (PrevBox)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lx = tid & 15, ly = tid >> 4;  // == (lane & 15, wv * 4 + (lane >> 4)): wave wv owns pixel rows 4wv..4wv+3
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
@@ -125,19 +126,19 @@ __device__ __forceinline__ void fused_tile(
     const int L = tile_list_head<true>(
         sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
             const GaussRec &r = br.r;
-            const int slot = partial_slot(g, br.box, tx, ty, tile * GI2D_TILE_LIST_CAP + rank);
+            const int slot = partial_slot(g, br.box, tx, ty, br.pool);
             if (rank < GI2D_TILE_LIST_CAP) {
                 sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
                 sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
                 sm.gCb[rank] = r.cb;
                 sm.cullw[rank] = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
                 sm.slot[rank] = slot;
-            } else if (slot >= 0) {
+            } else if (float4 *row = partial_row(slot, partial_g, partial_big, pool_rows, status)) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                partial_g[GI2D_FAST_ROW * (size_t)slot] = z;
-                partial_g[GI2D_FAST_ROW * (size_t)slot + 1] = z;
-                partial_g[GI2D_FAST_ROW * (size_t)slot + 2] = z;
+                row[0] = z;
+                row[1] = z;
+                row[2] = z;
             }
         });
     GI2D_TRACE(2);
@@ -208,10 +209,7 @@ __device__ __forceinline__ void fused_tile(
     // ---- backward on the same staged records
     bwd_publish_pixel(sm, lx, ly, v0, v1, v2, 0.f);
     float4 *dst = nullptr;
-    if (tid < len) {
-        const int slot = sm.slot[tid];
-        dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
-    }
+    if (tid < len) dst = partial_row(sm.slot[tid], partial_g, partial_big, pool_rows, status);
     bwd_run_tile<false, false, true>(sm, len, cull, 0, tx0, ty0, dst, scan_incl, sm.scan_w);
     GI2D_TRACE(10);
     GI2D_TRACE_VALUE(14, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID

@@ -294,8 +294,10 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 //   S0 = sum w, S1 = sum w dx, S2 = sum w dx^2,  w = opac*vis*v_alpha = -v_sigma  (backward.cu:948)
 // because dy is constant along a row.  A gaussian owns at most 8 items; their partials are handed to the
 // lane that owns the gaussian through LDS and added in row order.
-#define GI2D_BWD_ITEMS 256 /* items per round = one per lane */
-static_assert(GI2D_BWD_ITEMS == 256, "round index = item >> 8 below");
+#ifndef GI2D_BWD_ITEMS
+#define GI2D_BWD_ITEMS 256 /* items per round (<= 256 = one per lane) */
+#endif
+static_assert(GI2D_BWD_ITEMS <= 256 && 8 * GI2D_TILE_LIST_CAP / GI2D_BWD_ITEMS < 16, "rounds per tile: round_before[16]");
 #ifndef GI2D_BWD_PART_ROWS
 #define GI2D_BWD_PART_ROWS 176 /* item rows of the LDS hand-off buffer: most tiles of a 50 000-gaussian 768x512 image
                                   (155 items on average) hand over in one pass; 192 rows (27.1 KB in the single-pass tile
@@ -474,7 +476,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
     // per class: the items in front of item 256 r in gaussian order, r = 1 .. 7 (multi-round tiles only; the hand-off
     // buffer is idle until the first round has run)
     unsigned long long *round_before = reinterpret_cast<unsigned long long *>(sm.part);
-    static_assert(sizeof(sm.part) >= 8 * sizeof(unsigned long long), "round_before[] lives in the hand-off buffer");
+    static_assert(sizeof(sm.part) >= 16 * sizeof(unsigned long long), "round_before[] lives in the hand-off buffer");
 #ifdef GI2D_BWD_GAUSSIAN_ORDER /* development aid: what the ordering by length buys */
     const bool by_class = false;
 #else
@@ -508,7 +510,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             }
         } else {
             // the one gaussian whose items contain item 256 r publishes the counts in front of it
-            const int r_last = (orig0 + mine.n - 1) >> 8, b = r_last << 8;
+            const int r_last = (orig0 + mine.n - 1) / GI2D_BWD_ITEMS, b = r_last * GI2D_BWD_ITEMS;
             if (mine.n > 0 && r_last > 0 && b >= orig0) {
                 unsigned long long before_b = excl;
                 for (int j = 0; j < b - orig0; ++j)  // j < n - 1: never the gaussian's last item

@@ -85,7 +85,7 @@ __device__ __forceinline__ void train_project_fill_body(int g, const UpdateArgs 
     begin_binning(g, u.next.status);
     float4 *recs = recs_for_binning(u.next.recs, g == 0);
     if (g >= n) return;
-    const int2 old_box = u.next.prev_box[g];  // with the other inputs, ahead of the stores
+    const PrevBox old_box = u.next.prev_box[g];  // with the other inputs, ahead of the stores
     const Row3 col = load_row3(P.feat, g);
     const float opac = P.opacity[g];
     float2 mean;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     }
     const TrainParams &P = u.P;
     const NextFill &next = u.next;
-    const int2 *prev_box = u.next.prev_box;
+    const PrevBox *prev_box = u.next.prev_box;
     float2 *xys = u.xys;
     int32_t *radii = u.radii;
     float *conics = u.conics;
@@ -300,7 +300,7 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     const bool in_rows = g < u.n;
     AdamRows rows;
     if (!ADAN && in_rows) rows = adam_load_rows(P, g);
-    const int2 box_ld = in_rows ? prev_box[g] : make_int2(0, 0);
+    const PrevBox box_ld = in_rows ? prev_box[g] : no_box();
     const int radius = in_rows ? radii[g] : 0;
     float conic[3] = {0.f, 0.f, 0.f};
     if (in_rows) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
@@ -309,7 +309,8 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     const Row3 bound_row = in_rows ? load_row3(P.bound, P.bound_stride ? g : 0) : Row3{0.f, 0.f, 0.f};
     const float bound3[3] = {bound_row.a, bound_row.b, bound_row.c};
     const int n = live_n(P, u.n);
-    const int2 box = g < n ? box_ld : make_int2(0, 0);
+    const PrevBox pbox = g < n ? box_ld : no_box();
+    const int2 box = make_int2(pbox.x, pbox.y);
 #if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 1) /* development aid (wrong results): no best-model decision */
     const bool snapshot = false;
 #else
@@ -320,7 +321,7 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
 #if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 2) /* development aid (wrong results): no gradient gather */
     for (int q = 0; q < 11; ++q) acc[q] = 1e-9f * (float)(box.x + q);
 #else
-    reduce_one(g, box, tiles_x, u.gids_sorted, u.tile_bins, tiles_x * tiles_y, u.partial_g, u.partial_big, acc);
+    reduce_one(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big, acc);
 #endif
     if (g >= n) return;
     float2 mean;
@@ -412,7 +413,7 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box).
         // Order of the tail: the binning step's returning atomics (gaussians that entered a tile), then every other
         // store of the lane, then the list stores that need the atomics' results.
-        bin_projected(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, box,
+        bin_projected(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, pbox,
                       next.prev_box, next.lists, recs, [&] {
                           xys[g] = o.xy;
                           radii[g] = o.radius;
@@ -514,14 +515,14 @@ __device__ __forceinline__ void quantise_row(const TrainParams &P, const QuantTr
 __global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
+    int32_t *__restrict__ num_tiles_hit, PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
     int32_t *__restrict__ status) {
     n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
-    const int2 old_box = prev_box[g];  // with the other inputs, ahead of the stores
+    const PrevBox old_box = prev_box[g];  // with the other inputs, ahead of the stores
     const float opac = P.opacity[g];
     const QuantVals v = load_quant(Q);
     QuantRow r;
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainPara
 
 __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const int2 *__restrict__ prev_box,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const PrevBox *__restrict__ prev_box,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best,
@@ -773,8 +774,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
-    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
-               partial_big, acc);
+    const PrevBox pbox = g < n ? prev_box[g] : no_box();
+    reduce_one(g, make_int2(pbox.x, pbox.y), pbox.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big, acc);
     float sums[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) sums[k] = 0.f;
@@ -918,14 +919,14 @@ __device__ __forceinline__ void quantise_row_rs(const QuantTrain &Q, const Quant
 __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
     int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
     float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, int2 *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
+    int32_t *__restrict__ num_tiles_hit, PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
     int32_t *__restrict__ status) {
     n = live_n(P, n);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
-    const int2 old_box = prev_box[g];  // with the other inputs, ahead of the stores
+    const PrevBox old_box = prev_box[g];  // with the other inputs, ahead of the stores
     const float opac = P.opacity[g];
     const QuantValsRS v = load_quant_rs(Q);
     QuantRowRS r;
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
 
 __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const int2 *__restrict__ prev_box,
+    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const PrevBox *__restrict__ prev_box,
     const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
     const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
     AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
@@ -958,8 +959,8 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
     if (g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
-    reduce_one(g, g < n ? prev_box[g] : make_int2(0, 0), tiles_x, gids_sorted, tile_bins, tiles_x * tiles_y, partial_g,
-               partial_big, acc);
+    const PrevBox pbox = g < n ? prev_box[g] : no_box();
+    reduce_one(g, make_int2(pbox.x, pbox.y), pbox.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big, acc);
     float sums[GI2D_QT_RS_SUMS];
 #pragma unroll
     for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = 0.f;
@@ -1412,7 +1413,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
                 best.step = step;
                 hipLaunchKernelGGL(train_reduce_update_quant_rs_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
                                    (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
-                                   s->radius_clip, (const int2 *)w.prev_box, (const int32_t *)w.gids_sorted,
+                                   s->radius_clip, (const PrevBox *)w.prev_box, (const int32_t *)w.gids_sorted,
                                    (const int2 *)w.tile_bins,
                                    (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
                                    (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best);
@@ -1437,7 +1438,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
             best.step = step;
             hipLaunchKernelGGL(train_reduce_update_quant_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
                                (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
-                               s->radius_clip, (const int2 *)w.prev_box, (const int32_t *)w.gids_sorted,
+                               s->radius_clip, (const PrevBox *)w.prev_box, (const int32_t *)w.gids_sorted,
                                (const int2 *)w.tile_bins,
                                (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
                                (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, s->status);

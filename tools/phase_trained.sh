@@ -7,7 +7,9 @@
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/phase_trained
 rm -rf $OUT && mkdir -p $OUT
-python3 tools/trained_scene.py fit ${1:-0} ${2:-50000} /tmp/trained_scene.pt || exit 1
+# FIT_ARGS: everything trained_scene.py takes after the path (grow_iter), e.g. FIT_ARGS=5000 with 4500 iterations = the
+# 5 000 large gaussians of a fit's first stretch
+python3 tools/trained_scene.py fit ${1:-0} ${2:-50000} /tmp/trained_scene.pt $FIT_ARGS || exit 1
 for v in ${PHASES:-1 2 3 4 5 0}; do
   rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o
   make -s -C gaussianimage_plus_amd/csrc EXTRA="-DGI2D_STOP_AFTER=$v $XFLAGS" 2>&1 | grep -E "error"

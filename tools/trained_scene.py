@@ -1,5 +1,5 @@
 """A TRAINED scene as the frozen input of cut-off / knock-out builds (development aid).
-  trained_scene.py fit [image] [iterations] [path]   fit one Kodak picture with the adaptive covariance schedule of
+  trained_scene.py fit [image] [iterations] [path] [grow_iter]   fit one Kodak picture with the adaptive covariance schedule of
                                                     launch.py (5 000 -> 50 000 gaussians) and save the activated
                                                     parameters + the picture
   trained_scene.py steps [steps] [path]             HotPath.step() on that frozen scene (what static_steps.py does on
@@ -22,10 +22,11 @@ if mode == "fit":
     from gaussianimage_plus_amd.trainer import NativeFitter
     image, iters = int(a[1]) if len(a) > 1 else 0, int(a[2]) if len(a) > 2 else 20000
     path = a[3] if len(a) > 3 else "/tmp/trained_scene.pt"
+    grow = int(a[4]) if len(a) > 4 else max(iters // 10, 1)
     gt = bench.load_kodak(image + 1)[1][image].to(dev)
     fit = NativeFitter(gt, 5000, kind="covariance", lr=0.018, eps=1e-15, max_points=50000, track_best=True,
                        device_resident=True)
-    fit.fit(iters, prune_iter=100, grow_iter=max(iters // 10, 1))
+    fit.fit(iters, prune_iter=100, grow_iter=grow)
     fit.sync_population()
     torch.cuda.synchronize()
     torch.save({"means": fit.xyz.cpu(), "params": (fit.chol + fit.bound).cpu(), "colors": fit.feat.cpu(),
