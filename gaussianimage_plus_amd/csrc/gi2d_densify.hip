@@ -23,6 +23,10 @@
 #include "gi2d_common.h"
 
 namespace gi2d {
+int launch_workspace_init(void *ws, int n, int tiles_x, int tiles_y, const int32_t *only_if_moved, gi2d_stream_t st);  // gi2d_fast.hip
+}
+
+namespace gi2d {
 
 #define GI2D_DENSIFY_MAX_ARRAYS 24
 struct RowArrays {  // the per-gaussian arrays of a fit that move together; width = floats per row
@@ -430,7 +434,14 @@ int gi2d_train_prune(const gi2d_train_state *s, void *scratch, size_t scratch_by
                        w.rowbuf);
     hipLaunchKernelGGL(prune_copyback_kernel, grid, block, 0, st, rows, (const int32_t *)w.counts,
                        (const float *)w.rowbuf, s->num_points_dev, pruned_total);
-    return check_launch("train prune");
+    rc = check_launch("train prune");
+    if (rc != GI2D_OK) return rc;
+    // rows that moved were renumbered: the workspace's persistent tile lists (they hold gaussian ids) start over --
+    // decided on the device, like the move itself; a check that drops nothing (nearly all of them) leaves the lists alone
+    if (s->workspace)
+        rc = launch_workspace_init(s->workspace, n, (s->img_width + 15) / 16, (s->img_height + 15) / 16,
+                                   (const int32_t *)w.counts, st_);
+    return rc;
 }
 
 int gi2d_train_grow(const gi2d_train_state *s, int max_points, int budget_cap, const float *rand3, int rand_rows,

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
 // Empty state of a workspace: every tile row empty, no gaussian binned, identity tile order.
 __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n, int32_t *__restrict__ lists,
                                                            int32_t *__restrict__ tile_order,
-                                                           PrevBox *__restrict__ prev_box, int32_t *__restrict__ ver) {
+                                                           PrevBox *__restrict__ prev_box, int32_t *__restrict__ ver,
+                                                           const int32_t *__restrict__ only_if_moved) {
+    // only_if_moved: {population after, population before} of a device-side prune (gi2d_densify.hip): the lists refer to
+    // gaussian ids, which only change when rows were actually dropped -- one check in a few hundred on a Kodak fit
+    if (only_if_moved && (only_if_moved[0] == only_if_moved[1] || only_if_moved[0] == 0)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2) ver[i] = 0;
     if (i == 0) lists[GI2D_POOL_CURSOR] = 0;  // the row pool is empty
@@ -424,6 +428,19 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
 }
 }  // namespace gi2d
 
+namespace gi2d {
+// gi2d_fast_workspace_init without its argument checks; `only_if_moved`: see fast_ws_init_kernel
+int launch_workspace_init(void *ws, int n, int tiles_x, int tiles_y, const int32_t *only_if_moved, gi2d_stream_t st) {
+    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
+    const int t = tiles_x * tiles_y;
+    const int work = t > n ? t : n;
+    if (work == 0) return GI2D_OK;
+    hipLaunchKernelGGL(fast_ws_init_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)st, t, n,
+                       w.lists, w.tile_order, w.prev_box, w.ver, only_if_moved);
+    return check_launch("fast workspace init");
+}
+}  // namespace gi2d
+
 extern "C" {
 
 int gi2d_timer_create(void **timer) {
@@ -485,13 +502,7 @@ int gi2d_fast_tile_capacity(void) { return GI2D_FAST_C; }
 int gi2d_fast_workspace_init(void *ws, size_t ws_bytes, int n, int tiles_x, int tiles_y, gi2d_stream_t st) {
     int rc = check_ws("fast workspace init: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
-    FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
-    const int t = tiles_x * tiles_y;
-    const int work = t > n ? t : n;
-    if (work == 0) return GI2D_OK;
-    hipLaunchKernelGGL(fast_ws_init_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)st, t, n,
-                       w.lists, w.tile_order, w.prev_box, w.ver);
-    return check_launch("fast workspace init");
+    return gi2d::launch_workspace_init(ws, n, tiles_x, tiles_y, nullptr, st);
 }
 
 static BinTarget bin_target(const FastWs &w, int n, const float *colors, const float *opac, int32_t *status) {

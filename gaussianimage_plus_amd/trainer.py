@@ -442,8 +442,7 @@ class NativeFitter:
             with torch.cuda.device(self.dev):
                 _lib.call("gi2d_train_prune", self._state_ref, self.dens_scratch.data_ptr(), self.dens_scratch.numel(),
                           self.dens_counts.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream)
-            self._reset_bins()  # ids may have been renumbered
-            return None
+            return None  # the call itself empties the workspace's tile lists if (and only if) rows were renumbered
         n = self.n
         cov = self._chol[:n] + (self._bound[:n] if self.per_point_bound else self._bound)
         valid = positive_definite_mask(cov)

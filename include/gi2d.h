@@ -498,9 +498,11 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
  *                     rand3 f32[rand_rows,3]: uniform numbers (row r belongs to the r-th selected pixel); budget_cap =
  *                     1000, or max_points at the last growth step of a run (train.py:91-97); *added (device, optional)
  *                     accumulates the number appended.
- * Both need gi2d_densify_scratch_bytes(state, max_points) bytes of scratch and only enqueue kernels; afterwards the
- * caller re-initialises the fast workspace (gi2d_fast_workspace_init: gaussian ids changed) and raises its own upper
- * bound num_points by budget_cap (clamped to max_points) after a growth. */
+ * Both need gi2d_densify_scratch_bytes(state, max_points) bytes of scratch and only enqueue kernels.  gi2d_train_prune
+ * itself empties state->workspace's persistent tile lists when -- and only when -- rows were renumbered (decided on the
+ * device: a check that drops nothing leaves the lists as they are); after a growth the caller raises its own upper
+ * bound num_points by budget_cap (clamped to max_points) and re-initialises the fast workspace
+ * (gi2d_fast_workspace_init: its layout depends on num_points). */
 size_t gi2d_densify_scratch_bytes(const gi2d_train_state *state, int max_points);
 int gi2d_train_prune(const gi2d_train_state *state, void *scratch, size_t scratch_bytes, int32_t *pruned_total,
                      gi2d_stream_t stream);

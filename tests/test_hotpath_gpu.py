@@ -385,3 +385,75 @@ def test_pipelined_step_equals_unpipelined_and_survives_input_changes():
     assert torch.equal(img, b.out_img)
     a.step()                            # and the loop goes on
     assert torch.equal(a.v_params, b.v_params)
+
+
+def _big_and_small(n_big, n_small, h, w, seed, sigma=(18.0, 60.0)):
+    """n_big gaussians tens of pixels wide (tile boxes of far more than 32 tiles) in front of n_small ordinary ones."""
+    rng = np.random.default_rng(seed)
+    xyz_s, L_s, col_s, op_s = synth_cholesky(n_small, h, w, seed)
+    xyz_b = ((rng.random((n_big, 2)) - 0.5) * 1.6).astype(np.float32)
+    s = rng.uniform(sigma[0], sigma[1], (n_big, 2))
+    L_b = np.stack([s[:, 0], rng.uniform(-5, 5, n_big), s[:, 1]], 1).astype(np.float32)
+    col_b = (rng.random((n_big, 3)) * 0.05).astype(np.float32)
+    xyz, L = np.concatenate([xyz_b, xyz_s]), np.concatenate([L_b, L_s])
+    col, op = np.concatenate([col_b, col_s]), np.ones((n_big + n_small, 1), np.float32)
+    return xyz, L, col, op
+
+
+def test_gaussians_on_more_than_32_tiles_use_the_row_pool_and_equal_the_exact_path():
+    """Gaussians on more than GI2D_FAST_S = 32 tiles keep their partial rows in a pooled run (csrc/gi2d_fast_internal.h:
+    PrevBox).  Over steps in which they grow (a larger run is allocated), shrink and move (the run is reused), every
+    step's image and gradients equal the capacity-free ops bit for bit."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n_big, n_small, h, w = 40, 3000, 256, 384
+    xyz, L, col, op = _big_and_small(n_big, n_small, h, w, 21)
+    n = n_big + n_small
+    fused = HotPath(n, h, w, device=DEV, mode="fused")
+    exact = HotPath(n, h, w, device=DEV, mode="exact")
+    v = _v_out(h, w, 3)
+    rng = np.random.default_rng(5)
+    for step in range(6):
+        if step:
+            scale = (1.35, 0.5, 1.0, 1.6, 0.8)[step - 1]   # grow, shrink below 32 tiles for some, move only, grow, shrink
+            L[:n_big] *= np.float32(scale)
+            xyz[:n_big] = np.clip(xyz[:n_big] + rng.normal(size=(n_big, 2)).astype(np.float32) * 0.05, -0.95, 0.95)
+        for hp in (fused, exact):
+            hp.set_inputs(xyz, L, col, op)
+            hp.set_v_out(v)
+            hp.step(pipelined=False)
+            hp.check_status()
+        assert int((fused.nth[:n_big] > 32).sum()) >= (0 if step == 2 else 10), "the scene must exercise the pool"
+        for a, b in ((fused.out_img, exact.out_img), (fused.v_params, exact.v_params), (fused.v_mean2d, exact.v_mean2d),
+                     (fused.v_rgb, exact.v_rgb), (fused.v_opac, exact.v_opac)):
+            assert torch.equal(a, b), step
+
+
+def test_row_pool_overflow_is_flagged_and_step_safe_recovers():
+    """The pool holds tiles x 256 rows; 300 gaussians that each cover all 64 tiles of a 128x128 image ask for 19 200 of
+    its 16 384: the tile pass must raise the overflow status (and write nothing out of bounds), step_safe() redoes the
+    step on the capacity-free ops, and the emptied workspace serves a later problem."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n_big, n_small, h, w = 300, 200, 128, 128
+    xyz, L, col, op = _big_and_small(n_big, n_small, h, w, 8, sigma=(70.0, 90.0))
+    xyz[:n_big] *= 0.1
+    n = n_big + n_small
+    fused = HotPath(n, h, w, device=DEV, mode="fused")
+    exact = HotPath(n, h, w, device=DEV, mode="exact")
+    v = _v_out(h, w, 4)
+    for hp in (fused, exact):
+        hp.set_inputs(xyz, L, col, op)
+        hp.set_v_out(v)
+    fused.step(pipelined=False)
+    assert int(fused.nth[:n_big].min()) == 64
+    with pytest.raises(RuntimeError):
+        fused.check_status()
+    fused.step_safe()
+    exact.step()
+    exact.check_status()
+    assert torch.equal(fused.out_img, exact.out_img) and torch.equal(fused.v_params, exact.v_params)
+    xyz2, L2, col2, op2 = _big_and_small(20, n - 20, h, w, 9)
+    for hp in (fused, exact):
+        hp.set_inputs(xyz2, L2, col2, op2)
+        hp.step(pipelined=False)
+        hp.check_status()
+    assert torch.equal(fused.out_img, exact.out_img) and torch.equal(fused.v_params, exact.v_params)

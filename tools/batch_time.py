@@ -34,6 +34,8 @@ def main():
               f"{dt / iters / k * 1e6:7.2f} us per image-iteration, {k * iters / dt:9.0f} image-iterations/s", flush=True)
         del b, fit
         torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        time.sleep(0.5)  # returning gigabytes to the driver stalls the queue for ~0.1 s: keep it out of the next timing
     fit = NativeFitter(synthetic_image(h, w, 100).to(dev), n, kind=kind, lr=1e-3, seed=3047, track_best=True)
     fit.train(50)
     torch.cuda.synchronize()
