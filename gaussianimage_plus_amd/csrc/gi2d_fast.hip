@@ -229,15 +229,17 @@ __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kerne
     int xcd_map) {
     __shared__ FusedLds sm;
     int k, local;
-    if (xcd_map) {
-        // Images with the same tile count, K >= 8: image k's tiles go to the workgroups b with b % 8 == k % 8.  Workgroups
-        // are dealt to the eight XCDs round-robin, so one image's records, tile rows and gradient rows stay in ONE XCD's
-        // 4 MiB L2 instead of being fetched into all eight (placement is a speed choice only: any mapping is correct).
+    if ((int)blockIdx.x < xcd_map * uniform_tiles) {
+        // Images with the same tile count: the first 8 * floor(K / 8) of them (`xcd_map` images) go to the XCDs whole --
+        // image k's tiles to the workgroups b with b % 8 == k % 8.  Workgroups are dealt to the eight XCDs round-robin, so
+        // one image's records, tile rows and gradient rows stay in ONE XCD's 4 MiB L2 instead of being fetched into all
+        // eight (placement is a speed choice only: any mapping is correct).  The K % 8 images left over follow in plain
+        // order, spread over all XCDs: giving them an XCD each would leave the other XCDs idle for a whole image (12 images
+        // then took the time of 16).
         const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
         const int slot = j / uniform_tiles;
         k = slot * 8 + x;
         local = j - slot * uniform_tiles;
-        if (k >= k_images) return;  // the last slot of an XCD whose share of the images is one short
     } else if (uniform_tiles > 0) {
         k = (int)blockIdx.x / uniform_tiles;
         local = (int)blockIdx.x - k * uniform_tiles;
@@ -411,12 +413,9 @@ namespace gi2d {
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
                              hipStream_t st) {
     if (total_blocks <= 0) return GI2D_OK;
-    int xcd_map = 0;
+    int xcd_map = 0;  // images placed on the XCDs whole (see the kernel): a multiple of 8
 #ifndef GI2D_NO_XCD_MAP /* development aid: what the XCD-aware mapping buys */
-    if (uniform_tiles > 0 && k_images >= 8) {
-        xcd_map = 1;
-        total_blocks = 8 * ((k_images + 7) / 8) * uniform_tiles;
-    }
+    if (uniform_tiles > 0) xcd_map = k_images & ~7;
 #endif
     if (mode == 0)
         GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<0>, dim3((unsigned)total_blocks), dim3(256), st,
