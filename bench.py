@@ -59,7 +59,10 @@ def parse(argv=None):
     p.add_argument("--image-iterations", type=int, default=50000,
                    help="training iterations per image in the images/sec leg (train.py:204: 50000)")
     p.add_argument("--images-per-gpu", type=int, default=24,
-                   help="images of a rank fitted as ONE batch in the images/sec leg (gi2d_train_steps_batched)")
+                   help="images of a rank fitted concurrently in the images/sec leg (gi2d_train_steps_batched)")
+    p.add_argument("--batch-groups", type=int, default=3,
+                   help="... as this many batches (image i of the rank in batch i mod G), each on its own HIP stream and "
+                        "host thread: one batch's update kernel overlaps another's tile pass (1 = one batch)")
     p.add_argument("--synthetic-images", action="store_true",
                    help="images/sec leg on Kodak-shaped synthetic pictures instead of the Kodak fixture")
     p.add_argument("--no-batched", action="store_true", help="skip the `batched` block")
@@ -376,7 +379,7 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
         return rows[i]
 
     def fit_group(idx, imgs):
-        res = launch.fit_images_native([im.to(dev) for im in imgs], num_points, iters, batched=True, **kw)
+        res = launch.fit_images_native([im.to(dev) for im in imgs], num_points, iters, batched=max(int(args.batch_groups), 1), **kw)
         rows.update(zip(idx, res))
         return res
 
@@ -409,12 +412,14 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
                               "best_model_gaussians": int(rows[i]["num_gaussians"]),
                               "final_model_gaussians": int(rows[i].get("final_num_gaussians", rows[i]["num_gaussians"]))}
                              for i in mine],
-            "images_per_batch_per_gpu": min(max(1, args.images_per_gpu), max(1, len(mine))),
+            "images_concurrent_per_gpu": min(max(1, args.images_per_gpu), max(1, len(mine))),
+            "batches_per_gpu": min(max(1, args.batch_groups), max(1, len(mine))),
             "warmup": "two 144x96 images, 300 iterations of the same schedule as one batch, untimed (code objects loaded)",
             "workload": f"{len(pics)} {'synthetic 768x512' if args.synthetic_images else 'Kodak'} images, covariance "
                         f"model {num_points}->{max_points} gaussians, {iters} iterations/image (train.py:204: 50000), "
                         f"prune every {prune_iter}, grow every {grow_iter}; image i -> rank i mod {world}, a rank's images "
-                        f"fitted in lockstep as one batch"}
+                        f"fitted concurrently as {max(1, args.batch_groups)} batches (every kernel of an iteration "
+                        f"launched once per batch) on as many HIP streams"}
 
 
 def pmc_traffic(kernel, n, h, w, images_per_launch=None):

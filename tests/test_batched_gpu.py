@@ -118,6 +118,21 @@ def test_batched_launcher_equals_streams_launcher():
         assert ra["psnr"] > 20
 
 
+@pytest.mark.parametrize("groups", [2, 3, 7])
+def test_batches_on_streams_equal_one_batch(groups):
+    """batched=G: the images of a GPU as G batches (image i in batch i mod G), each on its own HIP stream and host thread --
+    what the launcher and bench.py's images/s leg use; every image's result is that of the single batch (hence of fitting
+    it alone).  Five images: uneven batches, and more batches asked for than there are images."""
+    from gaussianimage_plus_amd.launch import fit_images_native, synthetic_image
+    gts = [synthetic_image(96, 144, 60 + i).to(DEV) for i in range(5)]
+    kw = dict(lr=0.018, kind="covariance", max_points=1800, prune_iter=50, grow_iter=100, eps=1e-15, eval_renders=1)
+    a = fit_images_native(gts, 1200, 350, batched=True, **kw)
+    b = fit_images_native(gts, 1200, 350, batched=groups, **kw)
+    for ra, rb in zip(a, b):
+        assert ra["mse"] == rb["mse"] and ra["num_gaussians"] == rb["num_gaussians"]
+        assert ra["final_num_gaussians"] == rb["final_num_gaussians"]
+
+
 class _FastImage(C.Structure):
     """struct gi2d_fast_image (include/gi2d.h), field for field."""
     _fields_ = [("num_points", C.c_int), ("tiles_x", C.c_int), ("tiles_y", C.c_int), ("img_width", C.c_uint),

@@ -1,5 +1,5 @@
 """The images/s leg of bench.py alone: Kodak images fitted as one batch (development aid; run under rocprofv3 for the
-per-kernel breakdown).  usage: kodak_fit.py [images] [iterations] [batched 0/1]"""
+per-kernel breakdown).  usage: kodak_fit.py [images] [iterations] [0 = one stream per image / 1 = one batch / G = G batches on G streams]"""
 import os
 import sys
 import time
@@ -19,9 +19,9 @@ grow = 5000 if iters >= 20000 else max(iters // 10, 1)
 kw = dict(lr=0.018, seed=3047, kind="covariance", max_points=50000, prune_iter=100, grow_iter=grow, eps=1e-15,
           optimizer="adam", eval_renders=1)
 t0 = time.time()
-rows = launch.fit_images_native([p.to(dev) for p in pics], 5000, iters, batched=bool(batched), threaded=True, **kw)
+rows = launch.fit_images_native([p.to(dev) for p in pics], 5000, iters, batched=(True if batched == 1 else batched), threaded=True, **kw)
 torch.cuda.synchronize()
 dt = time.time() - t0
-print(f"{count} images x {iters} iterations in {dt:.2f} s = {count / dt:.3f} images/s; "
+print(f"[mode {batched}] {count} images x {iters} iterations in {dt:.2f} s = {count / dt:.3f} images/s; "
       f"{dt / iters / count * 1e6:.2f} us per image-iteration; mean PSNR {sum(r['psnr'] for r in rows) / count:.2f}, "
       f"mean gaussians {sum(r['num_gaussians'] for r in rows) / count:.0f}")
