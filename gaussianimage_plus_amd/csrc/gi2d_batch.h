@@ -106,9 +106,26 @@ static inline TilePassArgs tile_pass_args(const FastWs &w, int n, int tiles_x, i
     return a;
 }
 
+// Quantisation-aware iterations (gi2d_train.hip): the quantisers' state of one image.
+struct QuantTrain {
+    float qmax_xy, qmax_cov, qmax_col;  // unsigned quantisers: qmin = 0
+    float qmin_rot, qmax_rot;           // rotation-scale model: the SIGNED rotation quantiser
+    float *qparams;                     // [12] xy scale[2], xy beta[2], cov scale, cov beta, colour scale[3], colour beta[3]
+    float *qm, *qv;                     // [12] Adam moments of qparams
+    float *range;                       // [4] min log, max log, #elements at the min, #at the max (variance channels)
+    float *qfeat;                       // [N,3] dequantised colours
+    float *partial;                     // [blocks][GI2D_QT_ROW]
+    int32_t *defer;                     // [8 + 8*defer_cap]: count, then 32-byte entries (flat index into chol,
+                                        // gradient, parameter, Adam moments, bound)
+    int defer_cap;
+    float *best_q, *dbg_q;              // [12] snapshot of qparams / [16] gradients (tests), or null
+};
+#define GI2D_QT_ROW 24  // 12 LSQ sums, 2 log sums, next range (min, #min, max, #max), padding
+
 struct BatchImage {
     TilePassArgs t;
     UpdateArgs u;
+    QuantTrain q;  // quantisation-aware batches only
 };
 
 #define GI2D_BATCH_MAX 64 /* images per launch: one ballot finds a workgroup's image */

@@ -461,20 +461,6 @@ __global__ __launch_bounds__(256) void train_reduce_update_batched_kernel(const 
 //     elements that attain the extremes receive sum-type gradients.  The update kernel cannot finish those elements
 //     (their gradient needs the global sums) in its main pass: it parks them in a short list for the closing step;
 //   * the log range of the NEXT iteration (min / max / tie counts of the updated variances).
-struct QuantTrain {
-    float qmax_xy, qmax_cov, qmax_col;  // unsigned quantisers: qmin = 0
-    float qmin_rot, qmax_rot;           // rotation-scale model: the SIGNED rotation quantiser
-    float *qparams;                     // [12] xy scale[2], xy beta[2], cov scale, cov beta, colour scale[3], colour beta[3]
-    float *qm, *qv;                     // [12] Adam moments of qparams
-    float *range;                       // [4] min log, max log, #elements at the min, #at the max (variance channels)
-    float *qfeat;                       // [N,3] dequantised colours
-    float *partial;                     // [blocks][GI2D_QT_ROW]
-    int32_t *defer;                     // [8 + 8*defer_cap]: count, then 32-byte entries (flat index into chol,
-                                        // gradient, parameter, Adam moments, bound)
-    int defer_cap;
-    float *best_q, *dbg_q;              // [12] snapshot of qparams / [16] gradients (tests), or null
-};
-#define GI2D_QT_ROW 24  // 12 LSQ sums, 2 log sums, next range (min, #min, max, #max), padding
 
 struct QuantVals {
     float xs[2], xb[2], cs, cb, fs[3], fb[3];
@@ -512,13 +498,20 @@ __device__ __forceinline__ void quantise_row(const TrainParams &P, const QuantTr
     for (int q = 0; q < 3; ++q) r.col[q] = quant_eval<GI2D_QUANT_LSQ>(cin[q], v.fs[q], v.fb[q], 0.f, Q.qmax_col);
 }
 
-__global__ __launch_bounds__(256) void train_project_fill_quant_kernel(
-    int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
-    float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
-    int32_t *__restrict__ status) {
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// The kernels of a quantisation-aware iteration as functions of (workgroup index within the image, the image's argument
+// blocks): the single-image kernels pass blockIdx.x and their kernel arguments, the batched ones their image's entry of
+// the batch table (gi2d_batch.h).
+__device__ __forceinline__ void project_fill_quant_body(int block, const UpdateArgs &u, const QuantTrain &Q) {
+    const TrainParams &P = u.P;
+    const int n = live_n(P, u.n);
+    const float clip_coe = u.next.clip_coe, img_w = u.img_w, img_h = u.img_h, radius_clip = u.radius_clip;
+    const int tiles_x = u.tiles_x, tiles_y = u.tiles_y;
+    float2 *xys = u.xys;
+    int32_t *radii = u.radii, *num_tiles_hit = u.next.num_tiles_hit, *lists = u.next.lists, *status = u.next.status;
+    float *conics = u.conics;
+    PrevBox *prev_box = u.next.prev_box;
+    const RecSets &rs = u.next.recs;
+    const int g = block * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
@@ -570,31 +563,22 @@ __device__ __forceinline__ void wave_range_reduce(float &mn, float &cmn, float &
     }
 }
 
-// Workgroup-level close of one partial row: sums[14] per lane in, row written by the first lanes.
-__device__ __forceinline__ void block_partial_row(float (&sums)[14], float mn, float cmn, float mx, float cmx,
-                                                  float *row) {
-    __shared__ float red[4][18];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = (int)blockDim.x >> 6;
+// One partial row per WAVE (row = the wave's index among the image's waves): fixed-order wave sums, written by the
+// wave's first lane.  Rows per wave, not per workgroup, so that the closing kernel's sums do not depend on the workgroup
+// size a launch happens to use -- single-image launches pick 64 or 256 lanes by population, a batch by its total.
+__device__ __forceinline__ int quant_wave_row(int block) { return block * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6); }
+__device__ __forceinline__ void wave_partial_row(float (&sums)[14], float mn, float cmn, float mx, float cmx,
+                                                 float *row) {
 #pragma unroll
     for (int k = 0; k < 14; ++k) sums[k] = wave_sum(sums[k]);
     wave_range_reduce(mn, cmn, mx, cmx);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 14; ++k) red[wave][k] = sums[k];
-        red[wave][14] = mn, red[wave][15] = cmn, red[wave][16] = mx, red[wave][17] = cmx;
-    }
-    __syncthreads();
-    if (threadIdx.x < 14) {
-        float t = red[0][threadIdx.x];
-        for (int w = 1; w < waves; ++w) t += red[w][threadIdx.x];
-        row[threadIdx.x] = t;
-    } else if (threadIdx.x == 14) {
-        float a = red[0][14], ac = red[0][15], b = red[0][16], bc = red[0][17];
-        for (int w = 1; w < waves; ++w) {
-            range_min_combine(a, ac, red[w][14], red[w][15]);
-            range_max_combine(b, bc, red[w][16], red[w][17]);
-        }
-        row[14] = a, row[15] = ac, row[16] = b, row[17] = bc;
+    if ((threadIdx.x & 63) == 0) {
+        float4 *r4 = reinterpret_cast<float4 *>(row);
+        r4[0] = make_float4(sums[0], sums[1], sums[2], sums[3]);
+        r4[1] = make_float4(sums[4], sums[5], sums[6], sums[7]);
+        r4[2] = make_float4(sums[8], sums[9], sums[10], sums[11]);
+        r4[3] = make_float4(sums[12], sums[13], mn, cmn);
+        r4[4] = make_float4(mx, cmx, 0.f, 0.f);
     }
 }
 
@@ -731,21 +715,11 @@ __device__ __forceinline__ void quant_finish(int blocks, const TrainParams &P, c
     }
 }
 
-// A launch of its own (one workgroup).  Running it in the last workgroup of the producing kernel instead (ticket +
-// device-scope fences) was measured and dropped: on this 8-XCD part every workgroup's release fence writes its L2
-// back, which made the update kernel 17 us slower to save a 4 us launch.
-template <bool RANGE_ONLY>
-__global__ __launch_bounds__(256) void train_quant_finish_kernel(int blocks, TrainParams P, QuantTrain Q,
-                                                                 AdamStep a_chol, AdamStep a_qxy, AdamStep a_qcov,
-                                                                 AdamStep a_qcol, float *__restrict__ dbg_grads,
-                                                                 BestSnap best) {
-    quant_finish<RANGE_ONLY>(blocks, P, Q, a_chol, a_qxy, a_qcov, a_qcol, dbg_grads, best);
-}
-
 // Range of the variance channels of the current parameters (start of a call, after the host touched them)
-__global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainParams P, QuantTrain Q) {
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void quant_range_body(int block, const UpdateArgs &u, const QuantTrain &Q) {
+    const TrainParams &P = u.P;
+    const int n = live_n(P, u.n);
+    const int g = block * blockDim.x + threadIdx.x;
     float sums[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) sums[k] = 0.f;
@@ -759,19 +733,26 @@ __global__ __launch_bounds__(256) void train_quant_range_kernel(int n, TrainPara
             range_max_combine(mx, cmx, t, 1.f);
         }
     }
-    block_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)blockIdx.x * GI2D_QT_ROW);
+    wave_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)quant_wave_row(block) * GI2D_QT_ROW);
 }
 
-__global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
-    int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const PrevBox *__restrict__ prev_box,
-    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
-    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
-    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best,
-    int32_t *__restrict__ status) {
+__device__ __forceinline__ void reduce_update_quant_body(int block, const UpdateArgs &u, const QuantTrain &Q,
+                                                         const AdamStep &a_xyz, const AdamStep &a_chol,
+                                                         const AdamStep &a_feat, int step) {
 #pragma clang fp contract(off)
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const TrainParams &P = u.P;
+    const int n = live_n(P, u.n);
+    const float img_w = u.img_w, img_h = u.img_h;
+    const int tiles_x = u.tiles_x, tiles_y = u.tiles_y;
+    const int32_t *radii = u.radii;
+    const float *conics = u.conics;
+    const PrevBox *prev_box = u.next.prev_box;
+    const float4 *partial_g = u.partial_g, *partial_big = u.partial_big;
+    float *dbg_grads = u.dbg_grads;
+    BestSnap best = u.best;
+    best.step = step;
+    const int g = block * blockDim.x + threadIdx.x;
+    int32_t *status = u.next.status;
     const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
     const PrevBox pbox = g < n ? prev_box[g] : no_box();
@@ -869,7 +850,7 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(
             }
         }
     }
-    block_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)blockIdx.x * GI2D_QT_ROW);
+    wave_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)quant_wave_row(block) * GI2D_QT_ROW);
 }
 
 
@@ -916,13 +897,17 @@ __device__ __forceinline__ void quantise_row_rs(const QuantTrain &Q, const Quant
     for (int q = 0; q < 3; ++q) r.col[q] = quant_eval<GI2D_QUANT_LSQ>(cin[q], v.fs[q], v.fb[q], 0.f, Q.qmax_col);
 }
 
-__global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
-    int n, float clip_coe, TrainParams P, QuantTrain Q, float img_w, float img_h, int tiles_x, int tiles_y,
-    float radius_clip, float2 *__restrict__ xys, int32_t *__restrict__ radii, float *__restrict__ conics,
-    int32_t *__restrict__ num_tiles_hit, PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists, RecSets rs,
-    int32_t *__restrict__ status) {
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void project_fill_quant_rs_body(int block, const UpdateArgs &u, const QuantTrain &Q) {
+    const TrainParams &P = u.P;
+    const int n = live_n(P, u.n);
+    const float clip_coe = u.next.clip_coe, img_w = u.img_w, img_h = u.img_h, radius_clip = u.radius_clip;
+    const int tiles_x = u.tiles_x, tiles_y = u.tiles_y;
+    float2 *xys = u.xys;
+    int32_t *radii = u.radii, *num_tiles_hit = u.next.num_tiles_hit, *lists = u.next.lists, *status = u.next.status;
+    float *conics = u.conics;
+    PrevBox *prev_box = u.next.prev_box;
+    const RecSets &rs = u.next.recs;
+    const int g = block * blockDim.x + threadIdx.x;
     begin_binning(g, status);
     float4 *recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
@@ -946,15 +931,22 @@ __global__ __launch_bounds__(256) void train_project_fill_quant_rs_kernel(
                   old_box, prev_box, lists, recs);
 }
 
-__global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
-    int n, TrainParams P, QuantTrain Q, const float2 *__restrict__ xys, const int32_t *__restrict__ radii,
-    const float *__restrict__ conics, int tiles_x, int tiles_y, float radius_clip, const PrevBox *__restrict__ prev_box,
-    const int32_t *__restrict__ gids_sorted, const int2 *__restrict__ tile_bins,
-    const float4 *__restrict__ partial_g, const float4 *__restrict__ partial_big, float img_w, float img_h,
-    AdamStep a_xyz, AdamStep a_chol, AdamStep a_feat, float *__restrict__ dbg_grads, BestSnap best) {
+__device__ __forceinline__ void reduce_update_quant_rs_body(int block, const UpdateArgs &u, const QuantTrain &Q,
+                                                            const AdamStep &a_xyz, const AdamStep &a_chol,
+                                                            const AdamStep &a_feat, int step) {
 #pragma clang fp contract(off)
-    n = live_n(P, n);
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const TrainParams &P = u.P;
+    const int n = live_n(P, u.n);
+    const float img_w = u.img_w, img_h = u.img_h;
+    const int tiles_x = u.tiles_x, tiles_y = u.tiles_y;
+    const int32_t *radii = u.radii;
+    const float *conics = u.conics;
+    const PrevBox *prev_box = u.next.prev_box;
+    const float4 *partial_g = u.partial_g, *partial_big = u.partial_big;
+    float *dbg_grads = u.dbg_grads;
+    BestSnap best = u.best;
+    best.step = step;
+    const int g = block * blockDim.x + threadIdx.x;
     AdamRows rows;
     if (g < n) rows = adam_load_rows(P, g);
     const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
@@ -1010,26 +1002,20 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_rs_kernel(
             }
         }
     }
-    // this workgroup's partial row (fixed order: wave sums, then waves in order)
-    __shared__ float red[4][GI2D_QT_RS_SUMS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = (int)blockDim.x >> 6;
+    // this wave's partial row (see wave_partial_row)
 #pragma unroll
     for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = wave_sum(sums[k]);
-    if (lane == 0) {
+    if ((threadIdx.x & 63) == 0) {
+        float4 *r4 = reinterpret_cast<float4 *>(Q.partial + (size_t)quant_wave_row(block) * GI2D_QT_ROW);
 #pragma unroll
-        for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) red[wave][k] = sums[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < GI2D_QT_RS_SUMS) {
-        float t = red[0][threadIdx.x];
-        for (int w = 1; w < waves; ++w) t += red[w][threadIdx.x];
-        Q.partial[(size_t)blockIdx.x * GI2D_QT_ROW + threadIdx.x] = t;
+        for (int k = 0; k < GI2D_QT_RS_SUMS / 4; ++k)
+            r4[k] = make_float4(sums[4 * k], sums[4 * k + 1], sums[4 * k + 2], sums[4 * k + 3]);
     }
 }
 
 // One workgroup: sums the partial rows in double (fixed order) and runs Adam on the 16 quantiser values.
-__global__ __launch_bounds__(256) void train_quant_finish_rs_kernel(int blocks, QuantTrain Q, AdamStep a_qxy,
-                                                                    AdamStep a_qcov, AdamStep a_qcol, BestSnap best) {
+__device__ __forceinline__ void quant_finish_rs(int blocks, const QuantTrain &Q, const AdamStep &a_qxy,
+                                                const AdamStep &a_qcov, const AdamStep &a_qcol, const BestSnap &best) {
 #pragma clang fp contract(off)
     __shared__ double lane_acc[256][GI2D_QT_RS_SUMS + 1];  // odd stride in 8-byte words
     __shared__ double dred[16][GI2D_QT_RS_SUMS];
@@ -1079,6 +1065,95 @@ __global__ __launch_bounds__(256) void train_quant_finish_rs_kernel(int blocks, 
         if (Q.dbg_q) Q.dbg_q[q] = grad;
         if (snap && Q.best_q) Q.best_q[q] = nv;
     }
+}
+
+// ------------------------------------------------------------------ kernels of the quantisation-aware iteration
+// MODEL: 1 covariance, 2 rotation-scale.  Single-image forms take the image's argument blocks as kernel arguments; the
+// batched forms find theirs in the batch table by workgroup index (gi2d_batch.h), like the plain fitting kernels.
+// The closing step is a launch of its own (one workgroup per image).  Running it in the last workgroup of the producing
+// kernel instead (ticket + device-scope fences) was measured and dropped: on this 8-XCD part every workgroup's release
+// fence writes its L2 back, which made the update kernel 17 us slower to save a 4 us launch.
+template <int MODEL>
+__global__ __launch_bounds__(256) void train_project_fill_quant_kernel(UpdateArgs u, QuantTrain Q) {
+    if (MODEL == 2)
+        project_fill_quant_rs_body((int)blockIdx.x, u, Q);
+    else
+        project_fill_quant_body((int)blockIdx.x, u, Q);
+}
+template <int MODEL>
+__global__ __launch_bounds__(256) void train_project_fill_quant_batched_kernel(const BatchImage *__restrict__ imgs,
+                                                                               const int *__restrict__ pg_start,
+                                                                               int k_images) {
+    const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
+    const int local = __builtin_amdgcn_readfirstlane((int)blockIdx.x - pg_start[k]);
+    if (MODEL == 2)
+        project_fill_quant_rs_body(local, imgs[k].u, imgs[k].q);
+    else
+        project_fill_quant_body(local, imgs[k].u, imgs[k].q);
+}
+template <int MODEL>
+__global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(UpdateArgs u, QuantTrain Q, AdamStep a_xyz,
+                                                                        AdamStep a_chol, AdamStep a_feat, int step) {
+    if (MODEL == 2)
+        reduce_update_quant_rs_body((int)blockIdx.x, u, Q, a_xyz, a_chol, a_feat, step);
+    else
+        reduce_update_quant_body((int)blockIdx.x, u, Q, a_xyz, a_chol, a_feat, step);
+}
+template <int MODEL>
+__global__ __launch_bounds__(256) void train_reduce_update_quant_batched_kernel(const BatchImage *__restrict__ imgs,
+                                                                                const int *__restrict__ pg_start,
+                                                                                int k_images, AdamStep a_xyz,
+                                                                                AdamStep a_chol, AdamStep a_feat,
+                                                                                int step) {
+    const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
+    const int local = __builtin_amdgcn_readfirstlane((int)blockIdx.x - pg_start[k]);
+    if (MODEL == 2)
+        reduce_update_quant_rs_body(local, imgs[k].u, imgs[k].q, a_xyz, a_chol, a_feat, step);
+    else
+        reduce_update_quant_body(local, imgs[k].u, imgs[k].q, a_xyz, a_chol, a_feat, step);
+}
+__global__ __launch_bounds__(256) void train_quant_range_kernel(UpdateArgs u, QuantTrain Q) {
+    quant_range_body((int)blockIdx.x, u, Q);
+}
+__global__ __launch_bounds__(256) void train_quant_range_batched_kernel(const BatchImage *__restrict__ imgs,
+                                                                        const int *__restrict__ pg_start, int k_images) {
+    const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
+    const int local = __builtin_amdgcn_readfirstlane((int)blockIdx.x - pg_start[k]);
+    quant_range_body(local, imgs[k].u, imgs[k].q);
+}
+// closing step; `rows`: partial rows (= waves) of the image's per-gaussian launch.  MODE 0: range only (covariance model,
+// start of a call), 1: covariance model, 2: rotation-scale model.
+template <int MODE>
+__device__ __forceinline__ void quant_finish_any(int rows, const UpdateArgs &u, const QuantTrain &Q, const AdamStep &a_chol,
+                                                 const AdamStep &a_qxy, const AdamStep &a_qcov, const AdamStep &a_qcol,
+                                                 int step) {
+    BestSnap best = u.best;
+    best.step = step;
+    if (MODE == 0) {
+        best.sse = nullptr;
+        quant_finish<true>(rows, u.P, Q, a_chol, a_qxy, a_qcov, a_qcol, nullptr, best);
+    } else if (MODE == 1) {
+        quant_finish<false>(rows, u.P, Q, a_chol, a_qxy, a_qcov, a_qcol, u.dbg_grads, best);
+    } else {
+        quant_finish_rs(rows, Q, a_qxy, a_qcov, a_qcol, best);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void train_quant_finish_kernel(int rows, UpdateArgs u, QuantTrain Q, AdamStep a_chol,
+                                                                 AdamStep a_qxy, AdamStep a_qcov, AdamStep a_qcol,
+                                                                 int step) {
+    quant_finish_any<MODE>(rows, u, Q, a_chol, a_qxy, a_qcov, a_qcol, step);
+}
+// one workgroup per image; rows of image k = its workgroups in the per-gaussian launches x waves per workgroup
+template <int MODE>
+__global__ __launch_bounds__(256) void train_quant_finish_batched_kernel(const BatchImage *__restrict__ imgs,
+                                                                         const int *__restrict__ pg_start,
+                                                                         int waves_per_block, AdamStep a_chol,
+                                                                         AdamStep a_qxy, AdamStep a_qcov, AdamStep a_qcol,
+                                                                         int step) {
+    const int k = (int)blockIdx.x;
+    quant_finish_any<MODE>((pg_start[k + 1] - pg_start[k]) * waves_per_block, imgs[k].u, imgs[k].q, a_chol, a_qxy, a_qcov,
+                           a_qcol, step);
 }
 
 // The batch table is written by kernels that carry the argument blocks as kernel arguments: stream-ordered, no host
@@ -1290,34 +1365,31 @@ static int quant_of(const gi2d_train_state *s, QuantTrain &Q) {
     return GI2D_OK;
 }
 
-// log range of the current variances, then activations/quantisers + projection + fill
-static void train_launch_quant_range(const gi2d_train_state *s, const TrainParams &P, const QuantTrain &Q,
-                                     hipStream_t st) {
-    const int n = s->num_points, bs = per_gaussian_block(n), blocks = (n + bs - 1) / bs;
+// launch shape of the per-gaussian kernels of a quantisation-aware iteration; rows = partial rows (waves) they leave
+struct QuantLaunch {
+    int bs, blocks, rows;
+};
+static QuantLaunch quant_launch_of(int n) {
+    QuantLaunch l;
+    l.bs = per_gaussian_block(n);
+    l.blocks = (n + l.bs - 1) / l.bs;
+    l.rows = l.blocks * (l.bs / 64);
+    return l;
+}
+// log range of the current variances (covariance model, start of a call)
+static void train_launch_quant_range(const UpdateArgs &u, const QuantTrain &Q, hipStream_t st) {
+    const QuantLaunch l = quant_launch_of(u.n);
     const AdamStep z = make_adam_step(0.0, 0.9, 0.999, 0.0, 1.f, 1, false);
-    BestSnap nb;
-    nb.xyz = nb.chol = nb.feat = nb.bound = nb.sse = nullptr;
-    nb.info = nullptr;
-    nb.tile_sse = nullptr;
-    nb.num_tiles = nb.step = 0;
-    hipLaunchKernelGGL(train_quant_range_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q);
-    hipLaunchKernelGGL(train_quant_finish_kernel<true>, dim3(1), dim3(256), 0, st, blocks, P, Q, z, z, z, z,
-                       (float *)nullptr, nb);
+    hipLaunchKernelGGL(train_quant_range_kernel, dim3(l.blocks), dim3(l.bs), 0, st, u, Q);
+    hipLaunchKernelGGL(train_quant_finish_kernel<0>, dim3(1), dim3(256), 0, st, l.rows, u, Q, z, z, z, z, 0);
 }
-static void train_launch_project_fill_quant(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
-                                            const QuantTrain &Q, int tx, int ty, hipStream_t st) {
-    const int n = s->num_points, bs = per_gaussian_block(n);
-    hipLaunchKernelGGL(train_project_fill_quant_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P, Q,
-                       (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
-}
-
-static void train_launch_project_fill_quant_rs(const gi2d_train_state *s, const FastWs &w, const TrainParams &P,
-                                               const QuantTrain &Q, int tx, int ty, hipStream_t st) {
-    const int n = s->num_points, bs = per_gaussian_block(n);
-    hipLaunchKernelGGL(train_project_fill_quant_rs_kernel, dim3((n + bs - 1) / bs), dim3(bs), 0, st, n, s->clip_coe, P,
-                       Q, (float)s->img_width, (float)s->img_height, tx, ty, s->radius_clip, (float2 *)s->xys, s->radii,
-                       s->conics, s->num_tiles_hit, w.prev_box, w.lists, rec_sets(w, n), s->status);
+// activations / quantisers + projection + fill
+static void train_launch_project_fill_quant(int model, const UpdateArgs &u, const QuantTrain &Q, hipStream_t st) {
+    const QuantLaunch l = quant_launch_of(u.n);
+    if (model == 2)
+        hipLaunchKernelGGL(train_project_fill_quant_kernel<2>, dim3(l.blocks), dim3(l.bs), 0, st, u, Q);
+    else
+        hipLaunchKernelGGL(train_project_fill_quant_kernel<1>, dim3(l.blocks), dim3(l.bs), 0, st, u, Q);
 }
 
 // Forward only (render): activations + projection + fill + rasterize into state->out_img.
@@ -1334,12 +1406,9 @@ int gi2d_train_render(const gi2d_train_state *s, gi2d_stream_t st_) {
         QuantTrain Q;
         rc = quant_of(s, Q);
         if (rc != GI2D_OK) return rc;
-        if (s->kind == 2) {  // GaussianImage_RS.forward_quantize (models/gaussianimage_rs.py:443-471)
-            train_launch_project_fill_quant_rs(s, w, P, Q, tx, ty, st);
-        } else {
-            train_launch_quant_range(s, P, Q, st);
-            train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
-        }
+        const UpdateArgs uq = update_args_of(s, w, tx, ty);
+        if (s->kind != 2) train_launch_quant_range(uq, Q, st);  // (the RS model's ranges are learned values)
+        train_launch_project_fill_quant(s->kind, uq, Q, st);  // GaussianImage_RS.forward_quantize: models/gaussianimage_rs.py:443-471
         return gi2d_fast_rasterize_forward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr,
                                            s->workspace, s->workspace_bytes, s->status, nullptr, nullptr, s->out_img,
                                            st_);
@@ -1396,36 +1465,13 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
             set_error("train steps: quantiser optimizer step must be >= 1");
             return GI2D_ERR_INVALID_ARGUMENT;
         }
-        const int bs = per_gaussian_block(n), blocks = (n + bs - 1) / bs;
-        if (s->kind == 2) {
-            for (int it = 0; it < count; ++it) {
-                const int step = first_step + it, qstep = q->first_step + it;
-                train_launch_project_fill_quant_rs(s, w, P, Q, tx, ty, st);
-                rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
-                                                          nullptr, nullptr, s->gt, grad_scale, s->tile_sse,
-                                                          s->workspace, s->workspace_bytes, s->status, s->out_img, st_);
-                if (rc != GI2D_OK) return rc;
-                AdamStep a[3], aq[3];
-                for (int k = 0; k < 3; ++k) {
-                    a[k] = make_adam_step(lr[k], beta1, beta2, 0.0, eps, step, false);
-                    aq[k] = make_adam_step(q->lr[k], q->beta1, q->beta2, 0.0, q->eps[k], qstep, false);
-                }
-                best.step = step;
-                hipLaunchKernelGGL(train_reduce_update_quant_rs_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
-                                   (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
-                                   s->radius_clip, (const PrevBox *)w.prev_box, (const int32_t *)w.gids_sorted,
-                                   (const int2 *)w.tile_bins,
-                                   (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
-                                   (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best);
-                hipLaunchKernelGGL(train_quant_finish_rs_kernel, dim3(1), dim3(256), 0, st, blocks, Q, aq[0], aq[1],
-                                   aq[2], best);
-            }
-            return check_launch("train steps (quantised, rotation-scale)");
-        }
-        train_launch_quant_range(s, P, Q, st);
+        const UpdateArgs uq = update_args_of(s, w, tx, ty);
+        const QuantLaunch l = quant_launch_of(n);
+        const int model = s->kind == 2 ? 2 : 1;
+        if (model == 1) train_launch_quant_range(uq, Q, st);
         for (int it = 0; it < count; ++it) {
             const int step = first_step + it, qstep = q->first_step + it;
-            train_launch_project_fill_quant(s, w, P, Q, tx, ty, st);
+            train_launch_project_fill_quant(model, uq, Q, st);
             rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
                                                       nullptr, nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
                                                       s->workspace_bytes, s->status, s->out_img, st_);
@@ -1435,15 +1481,17 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
                 a[k] = make_adam_step(lr[k], beta1, beta2, 0.0, eps, step, false);
                 aq[k] = make_adam_step(q->lr[k], q->beta1, q->beta2, 0.0, q->eps[k], qstep, false);
             }
-            best.step = step;
-            hipLaunchKernelGGL(train_reduce_update_quant_kernel, dim3(blocks), dim3(bs), 0, st, n, P, Q,
-                               (const float2 *)s->xys, (const int32_t *)s->radii, (const float *)s->conics, tx, ty,
-                               s->radius_clip, (const PrevBox *)w.prev_box, (const int32_t *)w.gids_sorted,
-                               (const int2 *)w.tile_bins,
-                               (const float4 *)w.partial_g, (const float4 *)w.partial_big, (float)s->img_width,
-                               (float)s->img_height, a[0], a[1], a[2], s->dbg_grads, best, s->status);
-            hipLaunchKernelGGL(train_quant_finish_kernel<false>, dim3(1), dim3(256), 0, st, blocks, P, Q, a[1], aq[0],
-                               aq[1], aq[2], s->dbg_grads, best);
+            if (model == 2) {
+                hipLaunchKernelGGL(train_reduce_update_quant_kernel<2>, dim3(l.blocks), dim3(l.bs), 0, st, uq, Q, a[0],
+                                   a[1], a[2], step);
+                hipLaunchKernelGGL(train_quant_finish_kernel<2>, dim3(1), dim3(256), 0, st, l.rows, uq, Q, a[1], aq[0],
+                                   aq[1], aq[2], step);
+            } else {
+                hipLaunchKernelGGL(train_reduce_update_quant_kernel<1>, dim3(l.blocks), dim3(l.bs), 0, st, uq, Q, a[0],
+                                   a[1], a[2], step);
+                hipLaunchKernelGGL(train_quant_finish_kernel<1>, dim3(1), dim3(256), 0, st, l.rows, uq, Q, a[1], aq[0],
+                                   aq[1], aq[2], step);
+            }
         }
         return check_launch("train steps (quantised)");
     }
