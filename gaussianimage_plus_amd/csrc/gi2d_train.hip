@@ -1552,11 +1552,31 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
         int tx, ty;
         int rc = train_check(s, tx, ty);
         if (rc != GI2D_OK) return rc;
-        if (s->kind != s0->kind || s->optimizer != s0->optimizer || s->beta3 != s0->beta3 || s->quant ||
-            s->optimizer < 0 || s->optimizer > 1) {
-            set_error("train steps (batched): the images of a batch share model kind and optimizer; quantisation-aware "
-                      "iterations are single-image calls");
+        if (s->kind != s0->kind || s->optimizer != s0->optimizer || s->beta3 != s0->beta3 || s->optimizer < 0 ||
+            s->optimizer > 1 || (s->quant != nullptr) != (s0->quant != nullptr)) {
+            set_error("train steps (batched): the images of a batch share model kind and optimizer, and are all "
+                      "quantisation-aware or none");
             return GI2D_ERR_UNSUPPORTED;
+        }
+        if (s->quant) {
+            const gi2d_train_quant *q = s->quant, *q0 = s0->quant;
+            bool same = q->xy_bits == q0->xy_bits && q->cov_bits == q0->cov_bits && q->color_bits == q0->color_bits &&
+                        q->rot_bits == q0->rot_bits && q->beta1 == q0->beta1 && q->beta2 == q0->beta2 &&
+                        q->first_step == q0->first_step;
+            for (int c = 0; c < 3; ++c) same = same && q->lr[c] == q0->lr[c] && q->eps[c] == q0->eps[c];
+            if (!same) {
+                set_error("train steps (batched): the quantisers of a batch share bit depths, learning rates, eps, betas "
+                          "and step count");
+                return GI2D_ERR_UNSUPPORTED;
+            }
+            if (q->first_step < 1) {
+                set_error("train steps (batched): quantiser optimizer step must be >= 1");
+                return GI2D_ERR_INVALID_ARGUMENT;
+            }
+            if (s->optimizer != 0) {
+                set_error("train steps (batched): quantisation-aware iterations use Adam");
+                return GI2D_ERR_UNSUPPORTED;
+            }
         }
         if (s->optimizer == 1 && (!s->d_xyz || !s->d_chol || !s->d_feat || !s->pg_xyz || !s->pg_chol || !s->pg_feat)) {
             set_error("train steps (batched): Adan without its extra state (d_*, pg_*)");
@@ -1571,7 +1591,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
         if (k == 0) tiles0 = tx * ty;
         uniform = uniform && tx * ty == tiles0;
     }
-    const bool adan_opt = s0->optimizer == 1;
+    const bool adan_opt = s0->optimizer == 1, quantised = s0->quant != nullptr;
     const int bs = per_gaussian_block((int)(total_n > 0x7fffffff ? 0x7fffffff : total_n));
     BatchTable b = carve_batch(batch, num_images);
     // the table: tile-pass and per-gaussian workgroup ranges, one argument block per image
@@ -1586,10 +1606,16 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
         host_imgs[k].t = tile_pass_args(w, n, tx, ty, s->img_width, s->img_height, s->status, s->out_img, s->gt,
                                         grad_scale, s->tile_sse);
         host_imgs[k].u = update_args_of(s, w, tx, ty);
+        std::memset(&host_imgs[k].q, 0, sizeof(QuantTrain));
+        if (quantised) {
+            int rc = quant_of(s, host_imgs[k].q);
+            if (rc != GI2D_OK) return rc;
+        }
         head.tile_start[k] = tile_blocks;
         head.pg_start[k] = pg_blocks;
         tile_blocks += tx * ty;
-        pg_blocks += (n + bs - 1) / bs + 1;  // + 1: the workgroup that orders the tiles
+        // plain fitting: + 1, the workgroup that orders the tiles (the quantised update kernels have none)
+        pg_blocks += (n + bs - 1) / bs + (quantised ? 0 : 1);
     }
     head.tile_start[num_images] = tile_blocks;
     head.pg_start[num_images] = pg_blocks;
@@ -1597,6 +1623,43 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
     const BatchImage *imgs = b.img;
     const int *pg_start = b.head->pg_start;
     const dim3 gg((unsigned)pg_blocks), bb(bs);
+    if (quantised) {
+        // train_iter_quantize for every image of the batch: four launches per iteration, whatever the number of images
+        const gi2d_train_quant *q = s0->quant;
+        const int model = s0->kind == 2 ? 2 : 1, wpb = bs / 64;
+        const dim3 gi((unsigned)num_images), b256(256);
+        if (model == 1) {
+            const AdamStep z = make_adam_step(0.0, 0.9, 0.999, 0.0, 1.f, 1, false);
+            hipLaunchKernelGGL(train_quant_range_batched_kernel, gg, bb, 0, st, imgs, pg_start, num_images);
+            hipLaunchKernelGGL(train_quant_finish_batched_kernel<0>, gi, b256, 0, st, imgs, pg_start, wpb, z, z, z, z, 0);
+        }
+        for (int it = 0; it < count; ++it) {
+            const int step = first_step + it, qstep = q->first_step + it;
+            if (model == 2)
+                hipLaunchKernelGGL(train_project_fill_quant_batched_kernel<2>, gg, bb, 0, st, imgs, pg_start, num_images);
+            else
+                hipLaunchKernelGGL(train_project_fill_quant_batched_kernel<1>, gg, bb, 0, st, imgs, pg_start, num_images);
+            int rc = launch_tile_pass_batched(1, b, num_images, tile_blocks, uniform ? tiles0 : 0, st);
+            if (rc != GI2D_OK) return rc;
+            AdamStep a[3], aq[3];
+            for (int k = 0; k < 3; ++k) {
+                a[k] = make_adam_step(lr[k], beta1, beta2, 0.0, eps, step, false);
+                aq[k] = make_adam_step(q->lr[k], q->beta1, q->beta2, 0.0, q->eps[k], qstep, false);
+            }
+            if (model == 2) {
+                hipLaunchKernelGGL(train_reduce_update_quant_batched_kernel<2>, gg, bb, 0, st, imgs, pg_start, num_images,
+                                   a[0], a[1], a[2], step);
+                hipLaunchKernelGGL(train_quant_finish_batched_kernel<2>, gi, b256, 0, st, imgs, pg_start, wpb, a[1], aq[0],
+                                   aq[1], aq[2], step);
+            } else {
+                hipLaunchKernelGGL(train_reduce_update_quant_batched_kernel<1>, gg, bb, 0, st, imgs, pg_start, num_images,
+                                   a[0], a[1], a[2], step);
+                hipLaunchKernelGGL(train_quant_finish_batched_kernel<1>, gi, b256, 0, st, imgs, pg_start, wpb, a[1], aq[0],
+                                   aq[1], aq[2], step);
+            }
+        }
+        return check_launch("train steps (batched, quantised)");
+    }
     if (s0->kind == 2)
         hipLaunchKernelGGL(train_project_fill_batched_kernel<kScaleRot>, gg, bb, 0, st, imgs, pg_start, num_images);
     else if (s0->kind == 0)

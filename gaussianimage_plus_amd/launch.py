@@ -82,7 +82,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
                       bits=(12, 10, 6), threaded: bool = False, batched=False) -> List[Dict[str, float]]:
     """Fit the images of `gts` CONCURRENTLY on one GPU on the fused training iteration (trainer.NativeFitter ->
     gi2d_train_step: one C-ABI call, three kernel launches, no host synchronisation per iteration).  With `batched`
-    (plain fitting, not the quantised loop) the images run in lockstep and every kernel of an iteration is launched ONCE
+    the images run in lockstep and every kernel of an iteration is launched ONCE
     for all of them (trainer.BatchFitter -> gi2d_train_steps_batched); `batched` = G > 1 makes G such batches (image i in
     batch i mod G), each on its own HIP stream and host thread: a batch runs its two kernels strictly one after the
     other, and the second, one lane per gaussian, is dependent-load latency -- another batch's tile pass fills that time.
@@ -108,7 +108,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
                for gt in gts]
     # batched: True = one batch, an int G > 1 = G batches of every G-th image, each on its own HIP stream and host thread
     groups = (1 if batched else 0) if isinstance(batched, bool) else max(int(batched), 0)
-    if len(fitters) < 2 or quantize:
+    if len(fitters) < 2:
         groups = 0
     groups = min(groups, len(fitters))
     batched = groups >= 1
@@ -126,9 +126,16 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
     if batched:
         sched_kw["chunk"] = None
         runs = []
+        def fit_batch(part):
+            if quantize:  # train_quantize.py's loop for the whole batch
+                for _ in BatchFitter(part).fit_quantize_schedule(iterations, warmup_iter, bits=bits, **sched_kw):
+                    pass
+            else:
+                BatchFitter(part).fit(iterations, **sched_kw)
+
         if groups == 1:
             with torch.cuda.device(dev):
-                BatchFitter(fitters).fit(iterations, **sched_kw)
+                fit_batch(fitters)
         else:
             # one batch alone runs its two kernels strictly one after the other, and the per-gaussian update kernel is
             # dependent-load latency (on trained scenes with a tail: the waves that hold the large gaussians); a second
@@ -140,7 +147,7 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
             def drive_group(g):
                 try:
                     with torch.cuda.device(dev), torch.cuda.stream(group_streams[g]):
-                        BatchFitter(fitters[g::groups]).fit(iterations, **sched_kw)
+                        fit_batch(fitters[g::groups])
                 except BaseException as e:  # surfaced on the main thread below
                     batch_errors.append(e)
 

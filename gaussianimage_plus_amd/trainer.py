@@ -550,7 +550,7 @@ class NativeFitter:
                              "quantisers are initialised from the data, so fit for a while first")
         self.qm, self.qv, self.qrange = f32(nq), f32(nq), f32(4)
         self.qfeat = f32(self.cap, 3)
-        self.qpartial = f32(((self.cap + 63) // 64 + 1) * 24)
+        self.qpartial = f32(((self.cap + 63) // 64 + 4) * 24)  # one row per wave of the per-gaussian launches
         self.qdefer = torch.zeros(8 + 8 * defer_capacity, dtype=torch.int32, device=dev)
         self.best_qparams = self.qparams.clone()
         self.dbg_qgrads = f32(16) if debug_grads else None
@@ -803,7 +803,10 @@ class BatchFitter:
         for f in fitters:
             assert (f.kind, f.optimizer, f.lr, f.betas, f.eps, f.lr_step, f.lr_gamma, f.iteration, f.opt_start) == \
                    (f0.kind, f0.optimizer, f0.lr, f0.betas, f0.eps, f0.lr_step, f0.lr_gamma, f0.iteration, f0.opt_start)
-            assert f.quant is None and f.dev == f0.dev
+            assert f.dev == f0.dev and (f.quant is None) == (f0.quant is None)
+            if f.quant is not None:  # quantisation-aware batch: one quantiser configuration, one schedule
+                assert (f.q_bits, f.q_rot_bit, f.q_lr, f.q_lr_step, f.q_lr_gamma, f.quant_start) == \
+                       (f0.q_bits, f0.q_rot_bit, f0.q_lr, f0.q_lr_step, f0.q_lr_gamma, f0.quant_start)
         self.fitters = list(fitters)
         self.lib, self.dev = f0.lib, f0.dev
         k = len(self.fitters)
@@ -827,6 +830,13 @@ class BatchFitter:
                 self._lr3[0] = self._lr3[1] = self._lr3[2] = lr
                 done = f0.iteration - f0.opt_start
                 count = min(left, f0.lr_step - done % f0.lr_step, self.max_call)
+                if f0.quant is not None:  # the quantiser optimizers' own StepLR (NativeFitter.train)
+                    qdone = f0.iteration - f0.quant_start
+                    count = min(count, f0.q_lr_step - qdone % f0.q_lr_step)
+                    qlr = f0.q_lr * f0.q_lr_gamma ** (qdone // f0.q_lr_step)
+                    for f in self.fitters:
+                        f.quant.lr[0] = f.quant.lr[1] = f.quant.lr[2] = qlr
+                        f.quant.first_step = qdone + 1
                 rc = self._fn(len(self.fitters), self._states, self.table.data_ptr(), self.table.numel(), self._lr3,
                               b1, b2, f0.eps, done + 1, count, st)
                 if rc != 0:
@@ -858,3 +868,32 @@ class BatchFitter:
     def fit(self, iterations: int, **kw) -> None:
         for _ in self.fit_schedule(iterations, **kw):
             pass
+
+    def fit_quantize_schedule(self, iterations: int, warmup_iter: int, bits=(12, 10, 6), chunk: Optional[int] = None,
+                              log=None, **kw):
+        """NativeFitter.fit_quantize_schedule for the whole batch: the plain warm-up in lockstep (fit_schedule), the
+        switch per image (best warm-up model, prune, quantisers initialised from its own data), then quantisation-aware
+        iterations in lockstep -- four launches per iteration for all images (gi2d_train_steps_batched)."""
+        f0 = self.fitters[0]
+        assert all(f.track_best for f in self.fitters)
+        warm = max(0, min(int(warmup_iter), int(iterations)) - 1)
+        start = f0.iteration
+        for local in self.fit_schedule(warm, chunk=chunk, log=log, total_iterations=int(iterations), **kw):
+            yield local
+        for i, f in enumerate(self.fitters):
+            f.load_best()
+            f.prune_non_definite()
+            f.sync_population()  # the quantisers are initialised from the live rows
+            f.enable_quantize(*bits)
+            if log:
+                log(f"[image {i}] iter {f.iteration - start + 1}: warm-up finished, quantisation-aware from here "
+                    f"({f.n} gaussians)")
+        left = max(0, int(iterations) - 1 - warm)
+        while left > 0:
+            step = min(left, int(chunk)) if chunk else left
+            self.train(step)
+            left -= step
+            yield f0.iteration - start
+        for f in self.fitters:
+            f.prune_non_definite()
+            f.sync_population()

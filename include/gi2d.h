@@ -440,7 +440,7 @@ typedef struct gi2d_train_state {
  *   qm, qv  f32[12]  their Adam moments
  *   range   f32[4]   scratch: log range of the variances (maintained by the calls)
  *   qfeat   f32[N,3] dequantised colours of the last render
- *   partial f32[(ceil(N/64) + 1) * 24] scratch;  defer i32[8 + 8*defer_capacity] scratch (32-byte aligned), zero-initialised by the
+ *   partial f32[(ceil(N/64) + 4) * 24] scratch (one 96-byte row per wave of the per-gaussian launches, 16-byte aligned);  defer i32[8 + 8*defer_capacity] scratch (32-byte aligned), zero-initialised by the
  *           caller: variances that tie with an extreme of the log range wait here for the global sums (more than
  *           defer_capacity of them in one step sets bit 1 of status[2])
  *   best_qparams f32[12] or NULL: snapshot of qparams taken with the best-model snapshot
@@ -479,7 +479,8 @@ int gi2d_train_steps(const gi2d_train_state *state, const double *lr_host, doubl
  * (2*count + 1 launches plus the table writes, whatever num_images is): states[k] is image k's state (its own
  * parameters, optimizer moments, target, workspace, best-model snapshot, device-resident population); all images share
  * kind, optimizer, learning rates and step count; image sizes and populations may differ.  Results per image are those
- * of gi2d_train_steps on that image alone, bit for bit.  Quantisation-aware iterations are single-image calls.
+ * of gi2d_train_steps on that image alone, bit for bit.  Quantisation-aware batches (every state with a `quant`, same bit
+ * depths, learning rates, eps, betas and first_step) run train_iter_quantize for all images: four launches per iteration.
  * batch: device scratch of gi2d_batch_bytes(num_images) bytes, rewritten by every call; num_images <= 64. */
 int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *states, void *batch, size_t batch_bytes,
                              const double *lr_host, double beta1, double beta2, float eps, int first_step, int count,

@@ -250,3 +250,53 @@ def test_sixty_four_images_in_one_launch():
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(alone, together)):
         _assert_same(a, b, f"image {i} of 64")
+
+
+QROWS = ("qparams", "qm", "qv", "best_qparams", "qfeat")
+
+
+@pytest.mark.parametrize("kind,sizes", [("covariance", MIXED), ("scale_rot", UNIFORM), ("covariance", BIG),
+                                        ("scale_rot", BIG)])
+def test_batched_quantised_iterations_equal_single_image_calls(kind, sizes):
+    """Quantisation-aware iterations (train_iter_quantize) of K images with four launches per iteration for all of them
+    == the same iterations image by image: parameters, Adam moments, the quantisers' learned values and their moments,
+    the dequantised colours, render, snapshots -- bit for bit.  BIG: each image alone runs its per-gaussian kernels in
+    64-lane workgroups, the batch in 256-lane ones (the quantisers' whole-array sums are formed from per-WAVE rows, so
+    they do not notice).  A warm-up first: the quantisers are initialised from the data."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    alone, together = _fitters(kind, "adam", sizes), _fitters(kind, "adam", sizes)
+    for fs in (alone, together):
+        for f in fs:
+            f.train(40)
+            f.enable_quantize(12, None, 6, debug_grads=False)
+    for f in alone:
+        for c in (1, 3, 5):
+            f.train(c)
+    b = BatchFitter(together)
+    for c in (1, 3, 5):
+        b.train(c)
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(alone, together)):
+        _assert_same(x, y, f"{kind} image {i}")
+        for nm in QROWS:
+            ta, tb = getattr(x, nm), getattr(y, nm)
+            assert torch.equal(ta, tb), f"{kind} image {i}: {nm} differs in {int((ta != tb).sum())} elements"
+        if kind == "covariance":
+            assert torch.equal(x.qrange, y.qrange), f"image {i}: log range"
+        y.check_status()
+        # and the quantised render (forward_quantize) of the batch-trained model is the single-image one
+        assert torch.equal(x.render(), y.render())
+
+
+def test_batched_quantised_launcher_equals_streams_launcher():
+    """launch.fit_images_native(quantize=True): train_quantize.py's loop in batches == on one stream per image."""
+    from gaussianimage_plus_amd.launch import fit_images_native, synthetic_image
+    gts = [synthetic_image(96, 144, 70 + i).to(DEV) for i in range(4)]
+    kw = dict(lr=0.018, kind="covariance", max_points=1800, prune_iter=50, grow_iter=100, eps=1e-15, eval_renders=1,
+              quantize=True, warmup_iter=200)
+    a = fit_images_native(gts, 1200, 350, batched=False, threaded=True, **kw)
+    for groups in (True, 2):
+        b = fit_images_native(gts, 1200, 350, batched=groups, **kw)
+        for ra, rb in zip(a, b):
+            assert ra["mse"] == rb["mse"] and ra["num_gaussians"] == rb["num_gaussians"]
+            assert ra["psnr_decoded"] == rb["psnr_decoded"] and ra["bpp"] == rb["bpp"]
