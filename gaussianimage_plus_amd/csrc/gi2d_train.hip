@@ -217,21 +217,49 @@ __device__ __forceinline__ float adan(float p, float g, float &m, float &n, floa
 // DPP wave sum -- so all waves of all workgroups take the same decision without a barrier, an LDS round or a host round
 // trip, whatever the workgroup size (64 or 256 lanes, single-image or batched launch).  (The workgroup-wide tree this
 // replaces -- one LDS array, nine barriers -- cost the update kernel 3 of its 14 us.)
+// Images of more than 2048 tiles would need several dependent rounds of loads per wave that way (six at 2040x1356: the
+// update kernel of an adaptive fit at that size took 23 us instead of 12).  Their sum is DEFINED in four chunks -- chunk
+// c = float4s [c L, (c + 1) L), L = ceil(T / 16), each summed by one wave as above; total = (s0 + s1) + (s2 + s3) -- which a
+// 256-lane workgroup forms with its four waves side by side (one LDS exchange, one barrier) and a 64-lane workgroup one
+// chunk after the other: the same bits either way.
 // best_sse_loads: the loads, issued with the kernel's other first-round loads; best_decision: the sum and the verdict.
 #define GI2D_SSE_ROUND 8 /* float4 loads a lane keeps in flight: 8 x 64 x 4 = 2048 tiles per round */
 struct SseLoads {
     float4 v[GI2D_SSE_ROUND];
 };
+struct SseChunks {  // how the image's float4s are split (chunked: more than one round of loads per wave)
+    int n4, len;
+    bool chunked, parallel;
+};
+__device__ __forceinline__ SseChunks sse_chunks(const BestSnap &best) {
+    SseChunks c;
+    c.n4 = best.num_tiles >> 2;
+    c.chunked = c.n4 > 64 * GI2D_SSE_ROUND;
+    c.len = c.chunked ? (c.n4 + 3) >> 2 : c.n4;
+    c.parallel = c.chunked && blockDim.x == 256;
+    return c;
+}
+// one round of loads of chunk [lo, hi) starting at float4 t0
+__device__ __forceinline__ void sse_round(const float4 *__restrict__ sse4, int t0, int hi, float4 (&v)[GI2D_SSE_ROUND]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < GI2D_SSE_ROUND; ++q) {
+        const int t = t0 + lane + 64 * q;
+        v[q] = t < hi ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ float sse_round_sum(const float4 (&v)[GI2D_SSE_ROUND]) {
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < GI2D_SSE_ROUND; ++q) part += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    return part;
+}
 __device__ __forceinline__ SseLoads best_sse_loads(const BestSnap &best) {
     SseLoads s;
     if (best.sse != nullptr) {
-        const float4 *sse4 = reinterpret_cast<const float4 *>(best.tile_sse);
-        const int n4 = best.num_tiles >> 2, lane = threadIdx.x & 63;
-#pragma unroll
-        for (int q = 0; q < GI2D_SSE_ROUND; ++q) {
-            const int t = lane + 64 * q;
-            s.v[q] = t < n4 ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const SseChunks c = sse_chunks(best);
+        const int mine = c.parallel ? (int)(threadIdx.x >> 6) : 0;  // the chunk this wave starts with
+        sse_round(reinterpret_cast<const float4 *>(best.tile_sse), mine * c.len, min(c.n4, (mine + 1) * c.len), s.v);
     }
     return s;
 }
@@ -239,22 +267,43 @@ __device__ __forceinline__ bool best_decision(const BestSnap &best, const SseLoa
     bool snapshot = false;
     if (best.sse != nullptr) {
         const float4 *sse4 = reinterpret_cast<const float4 *>(best.tile_sse);
-        const int n4 = best.num_tiles >> 2, lane = threadIdx.x & 63;
-        float part = 0.f;
-#pragma unroll
-        for (int q = 0; q < GI2D_SSE_ROUND; ++q) part += (first.v[q].x + first.v[q].y) + (first.v[q].z + first.v[q].w);
-        for (int t0 = 64 * GI2D_SSE_ROUND; t0 < n4; t0 += 64 * GI2D_SSE_ROUND) {  // images beyond 2048 tiles
-            float4 v[GI2D_SSE_ROUND];
-#pragma unroll
-            for (int q = 0; q < GI2D_SSE_ROUND; ++q) {
-                const int t = t0 + lane + 64 * q;
-                v[q] = t < n4 ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const SseChunks c = sse_chunks(best);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        // chunk `k`, its first round of loads given or not; the (< 4) tiles behind the last float4 ride on the last chunk
+        const auto chunk_sum = [&](int k, bool have_first) {
+            const int lo = k * c.len, hi = min(c.n4, lo + c.len);
+            float part = 0.f;
+            int t0 = lo;
+            if (have_first) {
+                part = sse_round_sum(first.v);
+                t0 += 64 * GI2D_SSE_ROUND;
             }
-#pragma unroll
-            for (int q = 0; q < GI2D_SSE_ROUND; ++q) part += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+            for (; t0 < hi; t0 += 64 * GI2D_SSE_ROUND) {
+                float4 v[GI2D_SSE_ROUND];
+                sse_round(sse4, t0, hi, v);
+                part += sse_round_sum(v);
+            }
+            if (!c.chunked || k == 3)
+                for (int t = (c.n4 << 2) + lane; t < best.num_tiles; t += 64) part += best.tile_sse[t];
+            return wave_sum_dpp(part);
+        };
+        float total;
+        if (!c.chunked) {
+            total = chunk_sum(0, true);
+        } else {
+            float s0, s1, s2, s3;
+            if (c.parallel) {
+                __shared__ float chunk_s[4];
+                const float mine = chunk_sum(wv, true);
+                if (lane == 0) chunk_s[wv] = mine;
+                __syncthreads();
+                s0 = chunk_s[0], s1 = chunk_s[1], s2 = chunk_s[2], s3 = chunk_s[3];
+            } else {
+                s0 = chunk_sum(0, true), s1 = chunk_sum(1, false), s2 = chunk_sum(2, false), s3 = chunk_sum(3, false);
+            }
+            total = (s0 + s1) + (s2 + s3);
         }
-        for (int t = (n4 << 2) + lane; t < best.num_tiles; t += 64) part += best.tile_sse[t];
-        const float total = wave_sum_dpp(part), prev = best.sse[best.step & 1];
+        const float prev = best.sse[best.step & 1];
         snapshot = total < prev;  // train.py:134 `best_psnr < psnr`
         if (g == 0) {
             best.sse[(best.step + 1) & 1] = snapshot ? total : prev;

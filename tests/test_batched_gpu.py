@@ -47,11 +47,15 @@ MIXED = [(96, 160, 1500), (50, 70, 400), (128, 128, 2500), (33, 200, 900)]
 
 # each image alone runs its per-gaussian kernels in 64-lane workgroups (N <= 32768), the batch of three in 256-lane ones
 BIG = [(256, 384, 15000), (384, 256, 14000), (256, 384, 13000)]
+# more than 2048 tiles per image: the best-model decision sums the per-tile errors in four chunks, one after the other in a
+# 64-lane workgroup (each image alone), side by side in a 256-lane one (the batch)
+LARGE = [(800, 1104, 15000), (1104, 800, 14000), (800, 1104, 13000)]
 
 
 @pytest.mark.parametrize("kind,optimizer,sizes", [("cholesky", "adan", UNIFORM), ("covariance", "adam", MIXED),
                                                   ("scale_rot", "adam", MIXED), ("cholesky", "adam", MIXED[:1]),
-                                                  ("cholesky", "adam", BIG), ("covariance", "adam", BIG)])
+                                                  ("cholesky", "adam", BIG), ("covariance", "adam", BIG),
+                                                  ("cholesky", "adam", LARGE)])
 def test_batched_iterations_equal_single_image_calls(kind, optimizer, sizes):
     """9 iterations as 1 + 3 + 5 (stretches: the update kernel also starts the next iteration) of K images in one
     launch per kernel == the same iterations of every image alone."""
@@ -300,3 +304,13 @@ def test_batched_quantised_launcher_equals_streams_launcher():
         for ra, rb in zip(a, b):
             assert ra["mse"] == rb["mse"] and ra["num_gaussians"] == rb["num_gaussians"]
             assert ra["psnr_decoded"] == rb["psnr_decoded"] and ra["bpp"] == rb["bpp"]
+
+
+def test_best_model_error_of_a_large_image_is_the_sum_of_its_tile_errors():
+    """3 450 tiles: the chunked sum behind the best-model decision (csrc/gi2d_train.hip::best_decision) against torch's."""
+    f = _fitters("cholesky", "adam", LARGE[:1])[0]
+    f.train(1)
+    torch.cuda.synchronize()
+    want = float(f.tile_sse.double().sum())
+    got = float(f.best_sse[1 if f.best_sse[1] < float("inf") else 0])
+    assert abs(got - want) <= 1e-5 * want, (got, want)
