@@ -29,5 +29,8 @@ else:
     fit.train(iters)
 torch.cuda.synchronize()
 dt = time.time() - t0
+cursor = int(fit.ws[:64].view(torch.int32)[8].item())
+fit.check_status()
+print(f"row pool: cursor {cursor} of {fit.tx * fit.ty * 256} rows")
 print(f"2040x1356 {kind}: {iters} iterations in {dt:.2f} s = {dt / iters * 1e6:.1f} us per iteration; {fit.n} gaussians, "
       f"PSNR {fit.psnr():.2f}")
