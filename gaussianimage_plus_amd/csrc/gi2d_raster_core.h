@@ -413,7 +413,12 @@ __device__ __forceinline__ bool fidx_admits(int, const float2 &, int) {
 // Measured: -0.6 us at 10 000 gaussians, -1.5 us at 2040x1356, +-0 at 50 000 / 768x512 (there the phase is not
 // bound by instruction issue).  Splitting row pairs into single rows where a tile has lanes to spare was measured too:
 // it halves the longest item but adds a prologue and a hand-off row per item, +6 % kernel time at every size.
-__device__ __forceinline__ int bwd_len_class(int trips) { return trips >= 9 ? 0 : trips >= 5 ? 1 : trips >= 3 ? 2 : 3; }
+#ifndef GI2D_BWD_ITEM_SHIFT
+#define GI2D_BWD_ITEM_SHIFT 1 /* log2 of the rows one item spans (1 = row pairs); development aid: 2 = groups of four rows */
+#endif
+__device__ __forceinline__ int bwd_len_class(int trips) {
+    return trips >= (9 << (GI2D_BWD_ITEM_SHIFT - 1)) ? 0 : trips >= (5 << (GI2D_BWD_ITEM_SHIFT - 1)) ? 1 : trips >= (3 << (GI2D_BWD_ITEM_SHIFT - 1)) ? 2 : 3;
+}
 struct BwdItemsOf {  // the items of one gaussian
     int n;                  // row pairs
     int c_first, c_mid, c_last;  // length class of the first / the middle / the last one (n == 1: c_first)
@@ -423,12 +428,13 @@ __device__ __forceinline__ BwdItemsOf bwd_items_of(unsigned cull) {
     BwdItemsOf it;
     it.n = 0, it.c_first = it.c_mid = it.c_last = 0, it.counts = 0ull;
     if (!(cull & 15u)) return it;
+    constexpr int SH = GI2D_BWD_ITEM_SHIFT, PER = 1 << SH;
     const int r0 = (int)((cull >> 8) & 15u), r1 = (int)((cull >> 12) & 15u);
     const int np = (int)((cull >> 20) & 15u) - (int)((cull >> 16) & 15u) + 1;
-    it.n = (r1 >> 1) - (r0 >> 1) + 1;
-    const int rows_first = it.n == 1 ? r1 - r0 + 1 : 2 - (r0 & 1), rows_last = 1 + (r1 & 1);
+    it.n = (r1 >> SH) - (r0 >> SH) + 1;
+    const int rows_first = it.n == 1 ? r1 - r0 + 1 : PER - (r0 & (PER - 1)), rows_last = 1 + (r1 & (PER - 1));
     it.c_first = bwd_len_class(rows_first * np);
-    it.c_mid = bwd_len_class(2 * np);
+    it.c_mid = bwd_len_class(PER * np);
     it.c_last = bwd_len_class(rows_last * np);
     it.counts = 1ull << (16 * it.c_first);
     if (it.n > 1) it.counts += (1ull << (16 * it.c_last)) + ((unsigned long long)(it.n - 2) << (16 * it.c_mid));
@@ -567,9 +573,10 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
 #endif
             const int code = sm.item[it], k = code & 255;
             const unsigned xr = sm.xr[k];
-            const int rp = (int)((xr & 15u) >> 1) + (code >> 8);  // items of k: its row pairs in order
-            orig = (int)sm.off[k] + (code >> 8) - round0;         // this item's row in the hand-off order
-            const int row_lo = max(2 * rp, (int)(xr & 15u)), row_hi = min(2 * rp + 1, (int)((xr >> 4) & 15u));
+            constexpr int SH = GI2D_BWD_ITEM_SHIFT;
+            const int rp = (int)((xr & 15u) >> SH) + (code >> 8);  // items of k: its row pairs in order
+            orig = (int)sm.off[k] + (code >> 8) - round0;          // this item's row in the hand-off order
+            const int row_lo = max(rp << SH, (int)(xr & 15u)), row_hi = min((rp << SH) + (1 << SH) - 1, (int)((xr >> 4) & 15u));
 #if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 1 /* development aid (wrong results): one trip per row */
             const int q_lo = (int)((xr >> 8) & 15u), q_hi = q_lo;
 #else
