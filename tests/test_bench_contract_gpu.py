@@ -43,6 +43,7 @@ def test_bench_line_has_the_contract_fields():
     assert im["data"] == "kodak" and im["images_landscape_768x512"] == 2 and im["images_portrait_512x768"] == 0
     assert [row["image"] for row in im["rank0_images"]] == ["kodim01", "kodim02"]
     assert all(10 < row["psnr"] < 60 and row["best_model_gaussians"] > 0 for row in im["rank0_images"])
+    assert im["images_concurrent_per_gpu"] == 2 and im["batches_per_gpu"] == 2  # three asked for, two images to share
     st = d["static_scene_step"]
     assert st["steps_per_s"] > 0 and st["num_intersects"] > 0
     ks = d["batched"]["per_k"]
