@@ -392,10 +392,56 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
                                               int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Emit emit) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
-    const int hdr_count = row[0], hdr_sorted = row[1];
+    const int hdr_count_v = row[0], hdr_sorted_v = row[1];
     int my_id[GI2D_FAST_EPT];
     my_id[0] = row[GI2D_FAST_HDR + tid];
+    // the header is the same for the whole workgroup: say so (vector loads leave it, and everything derived from it --
+    // count, sorted length, rounds -- in vector registers; the single-pass tile kernel sits at its 80-register budget)
+    const int hdr_count = __builtin_amdgcn_readfirstlane(hdr_count_v);
+    const int hdr_sorted = __builtin_amdgcn_readfirstlane(hdr_sorted_v);
     const int count = min(max(hdr_count, 0), GI2D_FAST_C), sorted = min(max(hdr_sorted, 0), count);
+#ifndef GI2D_NO_SHORT_HEAD /* development aid: what the one-wave head of short rows buys */
+    if (count <= 64) {
+        // A row of at most 64 candidates -- every tile of a 2040x1356 image at 50 000 gaussians, every tile of a fit's
+        // first 45 000 iterations (5 000 ... 14 000 large gaussians: ~24 per tile) -- is ONE wave's work: membership,
+        // ranks (ballot / compare loop over the wave's own LDS copy), row write-back and staging need nothing from the
+        // other three waves, which used to run the general path's loads, ballots, group counts and wave scan for
+        // nothing (~80 instructions each, ~250 of a sparse tile's ~3 200).  They wait at the barrier and read the length.
+        if (wv == 0) {
+            const int g = lane < count ? my_id[0] : -1;
+            BinRec r0;
+            bool keep = false;
+            if (g >= 0) {
+                r0 = load_record(recs, g);
+                int mnx, mny, mxx, mxy;
+                unpack_box(r0.box, mnx, mny, mxx, mxy);
+                keep = tx >= mnx && tx < mxx && ty >= mny && ty < mxy;  // the empty box 0/0 contains no tile
+            }
+            const unsigned long long km = __ballot(keep);
+            const int len = __popcll(km);
+            int rank = lane;
+            if (!(len == count && sorted == count)) {  // something was dropped or appended: rank = smaller survivors
+                ids[lane] = keep ? g : -1;             // (ids are unique; dropped entries read as 0xffffffff)
+                __builtin_amdgcn_wave_barrier();
+                rank = 0;
+                for (int q = 0; q < count; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
+                const bool in_place = lane < sorted && rank == lane;
+                if (keep && !in_place) row[GI2D_FAST_HDR + rank] = g;
+            }
+            if (keep) emit(rank, g, r0);
+            if (lane == 0) {
+                if (hdr_count != len || hdr_sorted != len) {
+                    row[0] = len;
+                    row[1] = len;
+                }
+                tile_bins[tile] = make_int2(list_base(tile), list_base(tile) + len);
+                grp[0] = len;
+            }
+        }
+        __syncthreads();  // staging complete and visible (OPTIMISTIC or not: a caller's own barrier after this is harmless)
+        return grp[0];
+    }
+#endif
     if (tid == 0 && hdr_count > GI2D_FAST_C) {  // more candidates than a row holds: the caller must fall back
         atomicOr(&status[1], 1);
         atomicOr(&status[2], 1);

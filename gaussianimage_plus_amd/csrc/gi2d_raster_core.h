@@ -473,12 +473,17 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         wsum = sm.wsum;
         __syncthreads();
     }
-    // items of the tile per class; more than one round of them?  (tile-uniform: every wave needs it for the barriers)
+    // items of the tile per class; more than one round of them?  (tile-uniform: every wave needs it for the barriers --
+    // but a list of at most 32 entries, <= 8 items each, cannot hold more than one round: waves without entries of a
+    // sparse tile skip the sums)
+    const bool placing = (tid & ~63) < len || wv == 0;  // waves without entries have nothing to place (wave 0 closes off[])
     unsigned long long total = 0ull;
+    if (placing || 8 * len > GI2D_BWD_ITEMS) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) total += (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
+        for (int k = 0; k < 4; ++k) total += (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
+    }
     const int n_total = bwd_field_sum(total);
-    const bool multi_round = n_total > GI2D_BWD_ITEMS;
+    const bool multi_round = 8 * len > GI2D_BWD_ITEMS && n_total > GI2D_BWD_ITEMS;
     // per class: the items in front of item 256 r in gaussian order, r = 1 .. 7 (multi-round tiles only; the hand-off
     // buffer is idle until the first round has run)
     unsigned long long *round_before = reinterpret_cast<unsigned long long *>(sm.part);
@@ -488,7 +493,6 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
 #else
     const bool by_class = true;
 #endif
-    const bool placing = (tid & ~63) < len || wv == 0;  // waves without entries have nothing to place (wave 0 closes off[])
     unsigned long long excl = 0ull;
     if (placing) {
         // one item per row pair this gaussian reaches; its row / pixel-pair ranges ride along in sm.xr
