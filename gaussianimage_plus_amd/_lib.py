@@ -13,7 +13,9 @@ import os
 import torch  # noqa: F401  (device memory + streams; see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgi2d_hip.so")
+# GI2D_LIB: a development variant built by `make VARIANT=...` (csrc/Makefile) instead of the product library -- for the
+# measurement scripts under tools/ only; such a library is refused unless GI2D_ALLOW_DEV_BUILD=1 (see load()).
+LIB_PATH = os.environ.get("GI2D_LIB") or os.path.join(_HERE, "libgi2d_hip.so")
 
 _i, _u, _f, _p, _sz = C.c_int, C.c_uint, C.c_float, C.c_void_p, C.c_size_t
 
@@ -109,6 +111,12 @@ def load() -> C.CDLL:
         fn.restype = C.c_size_t
     for name in STRING_FUNCS:
         getattr(lib, name).restype = C.c_char_p
+    ver = lib.gi2d_version().decode()
+    if "dev[" in ver and os.environ.get("GI2D_ALLOW_DEV_BUILD") != "1":
+        raise RuntimeError(
+            f"{LIB_PATH} is a development build ({ver}): cut-off / knock-out switches give wrong results on purpose. "
+            "Rebuild with `make -C gaussianimage_plus_amd/csrc` (no EXTRA), or set GI2D_ALLOW_DEV_BUILD=1 for a "
+            "measurement script that knows what it loads.")
     _lib = lib
     return lib
 

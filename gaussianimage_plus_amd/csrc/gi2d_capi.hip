@@ -16,9 +16,64 @@ int check_launch(const char *what) {
     return (int)e;
 }
 
+#define GI2D_STR2(x) #x
+#define GI2D_STR(x) GI2D_STR2(x)
+// Every development switch of the kernels (cut-off, knock-out, trace and tuning macros: csrc/Makefile passes them to all
+// translation units alike).  A library built with any of them says so in its version string -- " dev[...]" -- and
+// gaussianimage_plus_amd/_lib.py refuses to load it unless GI2D_ALLOW_DEV_BUILD=1: several of them give wrong results
+// on purpose (timing aids).
+static std::string dev_switches() {
+    std::string s;
+    const auto add = [&](const char *name, const char *value) {
+        if (!s.empty()) s += ' ';
+        s += name;
+        if (value && *value) s += std::string("=") + value;
+    };
+    (void)add;
+#ifdef GI2D_STOP_AFTER
+    add("GI2D_STOP_AFTER", GI2D_STR(GI2D_STOP_AFTER));
+#endif
+#ifdef GI2D_FWD_KNOCK
+    add("GI2D_FWD_KNOCK", GI2D_STR(GI2D_FWD_KNOCK));
+#endif
+#ifdef GI2D_BWD_KNOCK
+    add("GI2D_BWD_KNOCK", GI2D_STR(GI2D_BWD_KNOCK));
+#endif
+#ifdef GI2D_RU_KNOCK
+    add("GI2D_RU_KNOCK", GI2D_STR(GI2D_RU_KNOCK));
+#endif
+#ifdef GI2D_BWD_GAUSSIAN_ORDER
+    add("GI2D_BWD_GAUSSIAN_ORDER", "");
+#endif
+#ifdef GI2D_NO_TILE_ORDER
+    add("GI2D_NO_TILE_ORDER", "");
+#endif
+#ifdef GI2D_NO_XCD_MAP
+    add("GI2D_NO_XCD_MAP", "");
+#endif
+#ifdef GI2D_NO_SHORT_HEAD
+    add("GI2D_NO_SHORT_HEAD", "");
+#endif
+#ifdef GI2D_FUSED_TRACE
+    add("GI2D_FUSED_TRACE", "");
+#endif
+#ifdef GI2D_DEV_VARIANT /* any other experiment: -DGI2D_DEV_VARIANT=name next to its own macros */
+    add("GI2D_DEV_VARIANT", GI2D_STR(GI2D_DEV_VARIANT));
+#endif
+    return s;
+}
+
 }  // namespace gi2d
 
 extern "C" {
-const char *gi2d_version(void) { return "gi2d 0.1.0 (gfx950)"; }
+const char *gi2d_version(void) {
+    static const std::string v = [] {
+        std::string s = "gi2d 0.2.0 (gfx950)";
+        const std::string d = gi2d::dev_switches();
+        if (!d.empty()) s += " dev[" + d + "]";
+        return s;
+    }();
+    return v.c_str();
+}
 const char *gi2d_last_error_string(void) { return gi2d::g_last_error.c_str(); }
 }

@@ -63,3 +63,25 @@ def test_quant_argument_checks_need_no_gpu():
     ok = make_spec([0, 1], [0, 0], [63, 1023])
     assert lib.gi2d_quant_forward(C.byref(ok), 10, C.c_void_p(8), C.c_void_p(8), None, None, None, 0, None) == -2
     assert lib.gi2d_quant_forward(C.byref(ok), 0, None, None, None, None, None, 0, None) == 0  # empty input: nothing to do
+
+
+def test_product_library_carries_no_development_switch():
+    """Cut-off / knock-out / trace builds (`make VARIANT=... EXTRA=-DGI2D_...`) live under build/variants/ and say so
+    in gi2d_version(); the in-tree library must be a plain build, and the loader refuses anything else."""
+    import subprocess
+    import sys
+    from gaussianimage_plus_amd import _lib
+    assert "dev[" not in _lib.version(), _lib.version()
+    variant = os.path.join(ROOT, "build", "variants")
+    libs = [os.path.join(d, "libgi2d_hip.so") for d, _, f in os.walk(variant) if "libgi2d_hip.so" in f] \
+        if os.path.isdir(variant) else []
+    for path in libs[:1]:  # any development library in the tree: loading it without the override must fail
+        ver = ctypes.CDLL(path).gi2d_version
+        ver.restype = ctypes.c_char_p
+        if b"dev[" not in ver():
+            continue
+        env = dict(os.environ, GI2D_LIB=path)
+        env.pop("GI2D_ALLOW_DEV_BUILD", None)
+        r = subprocess.run([sys.executable, "-c", "from gaussianimage_plus_amd import _lib; _lib.load()"], cwd=ROOT,
+                           env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and "development build" in r.stderr

@@ -2,9 +2,9 @@
 # Development aid: residency of the single-pass tile kernel (workgroups per CU) against register spills, at 2040x1356
 # (10880 tiles: several rounds of resident workgroups) and at 768x512 (1536 tiles: one round).
 cd $GRAFT_REPO_ROOT
+source tools/variant.sh
 for v in "-DGI2D_FUSED_OCC=6" "-DGI2D_FUSED_OCC=7 -DGI2D_FWD_CHUNK=16" "-DGI2D_FUSED_OCC=8 -DGI2D_FWD_CHUNK=16 -DGI2D_BWD_PART_ROWS=64"; do
-  rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o gaussianimage_plus_amd/csrc/gi2d_train.o
-  make -s -C gaussianimage_plus_amd/csrc EXTRA="$v" 2>&1 | grep -E "error"
+  use_variant "$v"
   echo "variant: $v"
   for CFG in "50000 1356 2040" "50000 512 768" "10000 512 768"; do
     set -- $CFG
@@ -13,4 +13,4 @@ import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']; print('   N=$1 $3x$2: %.1f us/step, tile pass %.1f us' % (d['ms_per_step']*1e3, r['avg_kernel_us']))"
   done
 done
-rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o gaussianimage_plus_amd/csrc/gi2d_train.o; make -s -C gaussianimage_plus_amd/csrc
+use_product

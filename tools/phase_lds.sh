@@ -4,12 +4,12 @@
 # items built, 5 backward item loop, 0 = whole kernel), on the frozen bench scene.  Differences between consecutive
 # cut-offs attribute the counters to the phases.   gpurun -- 'bash tools/phase_lds.sh [N H W]'
 cd $GRAFT_REPO_ROOT
+source tools/variant.sh
 OUT=$GRAFT_REPO_ROOT/gpurun_out/phase_lds
 rm -rf $OUT && mkdir -p $OUT
 ARGS="$*"
 for v in ${PHASES:-1 2 3 4 5 0}; do
-  rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o
-  make -s -C gaussianimage_plus_amd/csrc EXTRA="-DGI2D_STOP_AFTER=$v $XFLAGS" 2>&1 | grep -E "error"
+  use_variant "-DGI2D_STOP_AFTER=$v $XFLAGS"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc$v -o run -- python3 $GRAFT_REPO_ROOT/tools/static_steps.py 20 $ARGS > /dev/null 2> $OUT/pmc$v.log)
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st$v -o run -- python3 $GRAFT_REPO_ROOT/tools/static_steps.py 100 $ARGS > /dev/null 2> $OUT/st$v.log)
   python3 - $v $OUT <<'PY'
@@ -28,4 +28,4 @@ for f in glob.glob(f"{out}/st{v}/**/*kernel_stats.csv", recursive=True):
 print(f"stop_after={v}: {t:.2f} us  " + "  ".join(f"{k}={sum(x)/len(x)/1e6:.3f}M" for k, x in sorted(acc.items())), flush=True)
 PY
 done
-rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o; make -s -C gaussianimage_plus_amd/csrc
+use_product

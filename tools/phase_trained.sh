@@ -5,14 +5,14 @@
 # result: VALU instructions, VALU busy quad-cycles and kernel time per cut.
 #   gpurun -- 'bash tools/phase_trained.sh [image] [iterations]'
 cd $GRAFT_REPO_ROOT
+source tools/variant.sh
 OUT=$GRAFT_REPO_ROOT/gpurun_out/phase_trained
 rm -rf $OUT && mkdir -p $OUT
 # FIT_ARGS: everything trained_scene.py takes after the path (grow_iter), e.g. FIT_ARGS=5000 with 4500 iterations = the
 # 5 000 large gaussians of a fit's first stretch
 python3 tools/trained_scene.py fit ${1:-0} ${2:-50000} /tmp/trained_scene.pt $FIT_ARGS || exit 1
 for v in ${PHASES:-1 2 3 4 5 0}; do
-  rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o
-  make -s -C gaussianimage_plus_amd/csrc EXTRA="-DGI2D_STOP_AFTER=$v $XFLAGS" 2>&1 | grep -E "error"
+  use_variant "-DGI2D_STOP_AFTER=$v $XFLAGS"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc$v -o run -- python3 $GRAFT_REPO_ROOT/tools/trained_scene.py steps 20 > /dev/null 2> $OUT/pmc$v.log)
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st$v -o run -- python3 $GRAFT_REPO_ROOT/tools/trained_scene.py steps 100 > $OUT/st$v.out 2> $OUT/st$v.log)
   python3 - $v $OUT <<'PY'
@@ -32,4 +32,4 @@ print(f"stop_after={v}: {t:.2f} us  " + "  ".join(f"{k}={sum(x)/len(x)/1e6:.3f}M
 PY
 done
 cat $OUT/st0.out
-rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o; make -s -C gaussianimage_plus_amd/csrc
+use_product

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development aid: phase timeline of the tile pass at 2040x1356 (BASELINE config 4).
 cd $GRAFT_REPO_ROOT
-rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o gaussianimage_plus_amd/csrc/gi2d_train.o
-make -s -C gaussianimage_plus_amd/csrc EXTRA="-DGI2D_FUSED_TRACE $1" 2>&1 | grep -E "error"
+source tools/variant.sh
+use_variant "-DGI2D_FUSED_TRACE $1"
 python tools/trace_fused.py 50000 1356 2040 | head -16
-rm -f gaussianimage_plus_amd/csrc/gi2d_fast.o gaussianimage_plus_amd/csrc/gi2d_train.o; make -s -C gaussianimage_plus_amd/csrc
+use_product
