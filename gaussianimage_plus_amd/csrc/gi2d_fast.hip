@@ -180,9 +180,11 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     if (tid < len) {
         const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + tid);
         const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-        sm.gA[tid] = q0;
-        sm.gB[tid] = q1;
+        const ConicS cs = scale_conic(q0.z, q0.w, q1.x);
+        sm.gA[tid] = make_float4(q0.x, q0.y, cs.ha, cs.hb);
+        sm.gB[tid] = make_float4(cs.hc, q1.y, q1.z, q1.w);
         sm.gCb[tid] = q2.x;
+        if constexpr (WITH_ABS) sm.gRaw[tid] = make_float4(q0.z, q0.w, q1.x, 0.f);
         slot = __float_as_int(q2.y);
         mask = (unsigned)__float_as_int(q2.w);
     }

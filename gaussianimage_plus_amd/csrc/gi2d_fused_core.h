@@ -54,10 +54,10 @@ namespace gi2d {
 struct FusedLds {
     static constexpr int PSTR = 9;
     static constexpr bool HAS_FIDX = false;
+    static constexpr bool HAS_RAW = false;
     static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
-    typedef float2 PixB;
-    float4 gA[GI2D_TILE_LIST_CAP + 1];  // gx, gy, a, b        (entry CAP: the forward's never-contributing padding)
-    float4 gB[GI2D_TILE_LIST_CAP + 1];  // c, opac, cr, cg
+    float4 gA[GI2D_TILE_LIST_CAP + 1];  // gx, gy, ha, hb      (entry CAP: the forward's never-contributing padding;
+    float4 gB[GI2D_TILE_LIST_CAP + 1];  // hc, opac, cr, cg     conic pre-scaled: gi2d_common.h::scale_conic)
     float gCb[GI2D_TILE_LIST_CAP + 4];  // cb
     unsigned cullw[GI2D_TILE_LIST_CAP]; // cull_word() of the entry
     int slot[GI2D_TILE_LIST_CAP];       // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big)
@@ -73,15 +73,17 @@ struct FusedLds {
             float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats; afterwards the RGB transpose stage
         };
         struct {  // backward phase (member names as BwdLds: bwd_run_tile is shared)
-            float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];
-            float2 pixB[GI2D_TILE * GI2D_BWD_PIXROW];
-            unsigned short off[GI2D_TILE_LIST_CAP + 4];
+            float4 pix[2 * GI2D_BWD_PIXRECS];
+            unsigned short span[GI2D_TILE_LIST_CAP];
             unsigned short item[8 * GI2D_TILE_LIST_CAP];
             float part[GI2D_BWD_PART_ROWS * PSTR];
-            unsigned short xr[GI2D_TILE_LIST_CAP];
             int wsum[8];
+            int n_items;
         };
     };
+    // rows / columns of entry k's box: its cull word stays staged through both phases
+    __device__ __forceinline__ void set_box(int, unsigned) {}
+    __device__ __forceinline__ unsigned box_of(int k) const { return cullw[k] >> 8; }
 };
 
 // measured: 26.5 KB still leaves room for six workgroups per CU, 27.1 KB does not
@@ -128,8 +130,9 @@ __device__ __forceinline__ void fused_tile(
             const GaussRec &r = br.r;
             const int slot = partial_slot(g, br.box, tx, ty, br.pool);
             if (rank < GI2D_TILE_LIST_CAP) {
-                sm.gA[rank] = make_float4(r.gx, r.gy, r.a, r.b);
-                sm.gB[rank] = make_float4(r.c, r.opac, r.cr, r.cg);
+                const ConicS cs = scale_conic(r.a, r.b, r.c);
+                sm.gA[rank] = make_float4(r.gx, r.gy, cs.ha, cs.hb);
+                sm.gB[rank] = make_float4(cs.hc, r.opac, r.cr, r.cg);
                 sm.gCb[rank] = r.cb;
                 sm.cullw[rank] = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
                 sm.slot[rank] = slot;
@@ -159,9 +162,8 @@ __device__ __forceinline__ void fused_tile(
         sm.lists[wv], mybuf, len, [&](int k) { return sm.cullw[k]; },
         [&](int k) {
             const float4 A = sm.gA[k], B = sm.gB[k];
-            const ConicS cs = scale_conic(A.z, A.w, B.x);
             FwdRec r;
-            r.gx = A.x, r.gy = A.y, r.ha = cs.ha, r.hb = cs.hb, r.hc = cs.hc, r.op = B.y, r.cr = B.z, r.cg = B.w;
+            r.gx = A.x, r.gy = A.y, r.ha = A.z, r.hb = A.w, r.hc = B.x, r.op = B.y, r.cr = B.z, r.cg = B.w;
             r.cb = sm.gCb[k];
             return r;
         },

@@ -42,8 +42,8 @@ __device__ __forceinline__ GaussRec load_gaussian(int g, const float2 *__restric
 
 // Where inside a tile can the gaussian reach alpha >= 1/255?  Packed "cull word":
 //   bits 0-3   the 4-row strips it reaches (forward: one wave per strip)
-//   bits 8-11  first row r0, bits 12-15 last row r1, bits 16-19 first pixel pair q0, bits 20-23 last pair q1
-//   (rows / pairs of the 16x16 tile, from the conservative box of gi2d_common.h::cull_box, clipped to the
+//   bits 8-11  first row r0, bits 12-15 last row r1, bits 16-19 first column c0, bits 20-23 last column c1
+//   (rows / columns of the 16x16 tile, from the conservative box of gi2d_common.h::cull_box, clipped to the
 //   image height); 0 when it reaches nothing.  Evaluating more pixels than necessary never changes a
 //   result (they fail the alpha test); the box guarantees none that passes is left out.
 __device__ __forceinline__ unsigned cull_word_of(const CullBox &box, float tx0, float ty0, int img_h) {
@@ -51,10 +51,10 @@ __device__ __forceinline__ unsigned cull_word_of(const CullBox &box, float tx0, 
     const float r0f = fmaxf(ceilf(box.y0 - ty0), 0.f), r1f = fminf(floorf(box.y1 - ty0), last_row);
     const float c0f = fmaxf(ceilf(box.x0 - tx0), 0.f), c1f = fminf(floorf(box.x1 - tx0), 15.f);
     if (!(r1f >= r0f) || !(c1f >= c0f)) return 0u;
-    const unsigned r0 = (unsigned)r0f, r1 = (unsigned)r1f, q0 = (unsigned)c0f >> 1, q1 = (unsigned)c1f >> 1;
+    const unsigned r0 = (unsigned)r0f, r1 = (unsigned)r1f, c0 = (unsigned)c0f, c1 = (unsigned)c1f;
     const unsigned s0 = r0 >> 2, s1 = r1 >> 2;
     const unsigned strips = ((2u << s1) - 1u) & ~((1u << s0) - 1u);  // bits s0 .. s1
-    return strips | (r0 << 8) | (r1 << 12) | (q0 << 16) | (q1 << 20);
+    return strips | (r0 << 8) | (r1 << 12) | (c0 << 16) | (c1 << 20);
 }
 __device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, float ty0, int img_h) {
     CullBox box;
@@ -108,8 +108,8 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
         const int k = base + lane;
         const unsigned w = k < len ? cull_of(k) : 0u;
         const bool reach = (w >> wv) & 1u;
-        const bool tl = reach && ((w >> 16) & 15u) <= 3u;  // first pixel pair q0 <= 3: touches columns 0..7
-        const bool tr = reach && ((w >> 20) & 15u) >= 4u;  // last pixel pair q1 >= 4: touches columns 8..15
+        const bool tl = reach && ((w >> 16) & 15u) <= 7u;  // first column c0 <= 7: touches columns 0..7
+        const bool tr = reach && ((w >> 20) & 15u) >= 8u;  // last column c1 >= 8: touches columns 8..15
         const unsigned long long ml = __ballot(tl), mr = __ballot(tr);
         if (tl) left[n_left + __popcll(ml & lanemask_lt())] = (unsigned char)k;
         if (tr) right[n_right + __popcll(mr & lanemask_lt())] = (unsigned char)k;
@@ -287,17 +287,25 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
 }
 
 // ========================================================================================== backward
-// Work item = (gaussian k, row pair p) for the pixel rows 2p, 2p+1 the gaussian's alpha>=1/255 box reaches:
-// one lane walks those rows over the box's pixel-pair range only (small gaussians touch ~8 of a row's 16
-// pixels) two pixels at a time with packed fp32 (v_pk_fma_f32 & co), keeping every running sum in
-// registers.  Per row the conic/xy gradients follow from three sums
+// Work item = (gaussian k, ALIGNED row pair p) for the pixel rows 2p, 2p+1 the gaussian's alpha >= 1/255 box reaches:
+// one lane walks the box's COLUMNS c0..c1, one column per trip, the two rows of the pair side by side in packed fp32
+// (v_pk_fma_f32 & co: dx is common to the two rows, the row terms b*dy, c*dy^2 are the packed pair), keeping every
+// running sum in registers.  There is no row loop and no cross-lane reduction: per row the sums
 //   S0 = sum w, S1 = sum w dx, S2 = sum w dx^2,  w = opac*vis*v_alpha = -v_sigma  (backward.cu:948)
-// because dy is constant along a row.  A gaussian owns at most 8 items; their partials are handed to the
-// lane that owns the gaussian through LDS and added in row order.
+// sit in the two halves of three packed registers, and an item hands on six MOMENTS of w over its pixels
+//   T0 = sum w, T1 = sum w dx, T2 = sum w dx^2, U0 = sum w dy, U1 = sum w dx dy, V0 = sum w dy^2
+// (dx, dy relative to the gaussian's centre, so moments of different items simply add) next to the three colour sums.
+// The lane that owns the gaussian adds the moments of its (<= 8) items in row order and turns them into the
+// gradients ONCE per (tile, gaussian) -- v_xy = -(a T1 + b U0, b T1 + c U0), v_conic = -1/2 (T2, U1, V0),
+// v_opacity = T0 / opacity -- instead of once per row as the first design did (its per-row epilogue and per-item
+// division were 40 % of the item loop's instructions).  All items of a gaussian cost the same number of trips (its
+// columns), so the length classes that balance a wave are per GAUSSIAN and an item's slot is slot0(gaussian) + j.
+// A row of the pair outside the box (first / last pair of a box that starts on an odd / ends on an even row) rides
+// along masked.
 #ifndef GI2D_BWD_ITEMS
 #define GI2D_BWD_ITEMS 256 /* items per round (<= 256 = one per lane) */
 #endif
-static_assert(GI2D_BWD_ITEMS <= 256 && 8 * GI2D_TILE_LIST_CAP / GI2D_BWD_ITEMS < 16, "rounds per tile: round_before[16]");
+static_assert(GI2D_BWD_ITEMS == 256, "an item's row in the hand-off buffer is its lane");
 #ifndef GI2D_BWD_PART_ROWS
 #define GI2D_BWD_PART_ROWS 176 /* item rows of the LDS hand-off buffer: most tiles of a 50 000-gaussian 768x512 image
                                   (155 items on average) hand over in one pass; 192 rows (27.1 KB in the single-pass tile
@@ -307,52 +315,45 @@ static_assert(GI2D_BWD_ITEMS <= 256 && 8 * GI2D_TILE_LIST_CAP / GI2D_BWD_ITEMS <
 #ifndef GI2D_BWD_OCC
 #define GI2D_BWD_OCC 5 /* waves per SIMD the register allocator must leave room for; measured: 5 (96 VGPRs) beats 6 (80) */
 #endif
-#ifndef GI2D_BWD_UNROLL
-#define GI2D_BWD_UNROLL 1 /* pixel pairs per trip; 2 needs > 80 VGPRs and costs the sixth workgroup */
-#endif
 
 template <int PSTR>
 __device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR]);
 
-template <bool FIDX>
-struct BwdPixB;  // second word of a pixel pair: (voz0, voz1) and, where final_idx is consulted, (fidx0, fidx1)
-template <>
-struct BwdPixB<true> {
-    typedef float4 type;
-};
-template <>
-struct BwdPixB<false> {
-    typedef float2 type;
-};
-#define GI2D_BWD_PIXROW 9 /* 8 pixel pairs + one element of padding per row (rows of different items: no conflicts) */
+// Pixel gradients in LDS: one 32-byte record per (row pair p, column c) at pix[2 * (16 p + c)]:
+//   (vox_A, vox_B, voy_A, voy_B) (voz_A, voz_B, fidx_A, fidx_B)        A = row 2p, B = row 2p + 1
+// -- exactly the packed operands of an item's trip, two LDS reads (the second one b64 where final_idx is not consulted).
+#define GI2D_BWD_PIXRECS (GI2D_TILE / 2 * GI2D_TILE)
 
 template <bool WITH_ABS, bool FIDX = true>
 struct BwdLds {
     static constexpr int PSTR = WITH_ABS ? 11 : 9;  // odd: conflict-free hand-off rows
     static constexpr bool HAS_FIDX = FIDX;
-    typedef typename BwdPixB<FIDX>::type PixB;
-    float4 pixA[GI2D_TILE * GI2D_BWD_PIXROW];  // per pixel row: 8 pairs of (vox0, vox1, voy0, voy1)
-    PixB pixB[GI2D_TILE * GI2D_BWD_PIXROW];    //                8 pairs of (voz0, voz1 [, fidx0, fidx1])
-    float4 gA[GI2D_TILE_LIST_CAP];  // gx, gy, a, b
-    float4 gB[GI2D_TILE_LIST_CAP];  // c, opac, cr, cg
+    static constexpr bool HAS_RAW = WITH_ABS;
+    float4 pix[2 * GI2D_BWD_PIXRECS];
+    float4 gA[GI2D_TILE_LIST_CAP];  // gx, gy, ha, hb          (conic pre-scaled: scale_conic)
+    float4 gB[GI2D_TILE_LIST_CAP];  // hc, opac, cr, cg
     float gCb[GI2D_TILE_LIST_CAP];  // cb
-    unsigned short off[GI2D_TILE_LIST_CAP + 2];     // exclusive prefix of items per gaussian
+    float4 gRaw[WITH_ABS ? GI2D_TILE_LIST_CAP : 1];  // a, b, c as given (the |v_xy| sums are per pixel: backward.cu:959)
+    unsigned short span[GI2D_TILE_LIST_CAP];        // slot0 | n << 11: the gaussian's items are [slot0, slot0 + n)
     unsigned short item[8 * GI2D_TILE_LIST_CAP];    // k | j << 8: the item's gaussian and which of its row pairs
     static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
     float part[PART_ROWS * PSTR];
-    unsigned short xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | q0 << 8 | q1 << 12 per gaussian
+    unsigned short xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | c0 << 8 | c1 << 12 per gaussian
     int wsum[8];
+    int n_items;
+    // rows / columns of gaussian k's box: bits 8..23 of its cull word
+    __device__ __forceinline__ void set_box(int k, unsigned cull) { xr[k] = (unsigned short)((cull >> 8) & 0xffffu); }
+    __device__ __forceinline__ unsigned box_of(int k) const { return xr[k]; }
 };
 
-// lane (lx, ly) publishes pixel (v_out, final_idx) in pair-major order; -1 outside the image
+// lane (lx, ly) publishes pixel (v_out, final_idx); pixels outside the image carry v_out = 0 and final_idx = -1
 template <class Lds>
 __device__ __forceinline__ void bwd_publish_pixel(Lds &sm, int lx, int ly, float vx, float vy, float vz, float fi) {
-    float *ra = reinterpret_cast<float *>(&sm.pixA[ly * GI2D_BWD_PIXROW]) + (lx >> 1) * 4 + (lx & 1);
-    ra[0] = vx;
-    ra[2] = vy;
-    float *rb = reinterpret_cast<float *>(&sm.pixB[ly * GI2D_BWD_PIXROW]) + (lx >> 1) * (Lds::HAS_FIDX ? 4 : 2) + (lx & 1);
-    rb[0] = vz;
-    if (Lds::HAS_FIDX) rb[2] = fi;
+    float *r = reinterpret_cast<float *>(&sm.pix[2 * ((ly >> 1) * GI2D_TILE + lx)]) + (ly & 1);
+    r[0] = vx;
+    r[2] = vy;
+    r[4] = vz;
+    if (Lds::HAS_FIDX) r[6] = fi;
 }
 template <class Lds>
 __device__ __forceinline__ void bwd_stage_pixels(Lds &sm, int tx, int ty, int img_w, int img_h,
@@ -374,9 +375,11 @@ __device__ __forceinline__ void bwd_stage_pixels(Lds &sm, int tx, int ty, int im
 
 template <class Lds>
 __device__ __forceinline__ void bwd_stage_entry(Lds &sm, int k, const GaussRec &r) {
-    sm.gA[k] = make_float4(r.gx, r.gy, r.a, r.b);
-    sm.gB[k] = make_float4(r.c, r.opac, r.cr, r.cg);
+    const ConicS s = scale_conic(r.a, r.b, r.c);
+    sm.gA[k] = make_float4(r.gx, r.gy, s.ha, s.hb);
+    sm.gB[k] = make_float4(s.hc, r.opac, r.cr, r.cg);
     sm.gCb[k] = r.cb;
+    if constexpr (Lds::HAS_RAW) sm.gRaw[k] = make_float4(r.a, r.b, r.c, 0.f);
 }
 
 // After pixels and the first `len` gaussians are staged (no barrier needed before the call): builds the
@@ -396,48 +399,25 @@ __device__ __forceinline__ void bwd_stage_entry(Lds &sm, int k, const GaussRec &
     } while (0)
 #endif
 
-template <bool USE_FIDX>
-__device__ __forceinline__ bool fidx_admits(int idx, const float4 &p1, int half) {
-    return !USE_FIDX || idx <= __float_as_int(half ? p1.w : p1.z);
-}
-template <bool USE_FIDX>
-__device__ __forceinline__ bool fidx_admits(int, const float2 &, int) {
-    static_assert(!USE_FIDX, "final_idx is not staged in this LDS layout");
-    return true;
-}
-
-// An item is one row pair of one gaussian; it costs (rows of the pair inside the box) x (pixel pairs of the box) trips
-// of the pixel loop, 1 .. 16.  A wave runs as long as its longest item, so a tile's items are handed to the lanes by
-// length class -- 9..16, 5..8, 3..4, 1..2 trips, longest first -- instead of in gaussian order: at 50 000 gaussians per
-// 768x512 image 64 % of the issued lane-trips are then useful (41 % in gaussian order; a full sort by length: 66 %).
-// Measured: -0.6 us at 10 000 gaussians, -1.5 us at 2040x1356, +-0 at 50 000 / 768x512 (there the phase is not
-// bound by instruction issue).  Splitting row pairs into single rows where a tile has lanes to spare was measured too:
-// it halves the longest item but adds a prologue and a hand-off row per item, +6 % kernel time at every size.
-#ifndef GI2D_BWD_ITEM_SHIFT
-#define GI2D_BWD_ITEM_SHIFT 1 /* log2 of the rows one item spans (1 = row pairs); development aid: 2 = groups of four rows */
-#endif
-__device__ __forceinline__ int bwd_len_class(int trips) {
-    return trips >= (9 << (GI2D_BWD_ITEM_SHIFT - 1)) ? 0 : trips >= (5 << (GI2D_BWD_ITEM_SHIFT - 1)) ? 1 : trips >= (3 << (GI2D_BWD_ITEM_SHIFT - 1)) ? 2 : 3;
-}
+// An item costs (columns of the box) trips of the pixel loop, 1 .. 16, the same for every item of a gaussian.  A wave
+// runs as long as its longest item, so a tile's items are handed to the lanes by length class -- 9..16, 5..8, 3..4,
+// 1..2 trips, longest first -- instead of in gaussian order (41 % of the issued lane-trips useful in gaussian order,
+// 64 % by class; a full sort by length: 66 %).
+__device__ __forceinline__ int bwd_len_class(int trips) { return trips >= 9 ? 0 : trips >= 5 ? 1 : trips >= 3 ? 2 : 3; }
 struct BwdItemsOf {  // the items of one gaussian
-    int n;                  // row pairs
-    int c_first, c_mid, c_last;  // length class of the first / the middle / the last one (n == 1: c_first)
-    unsigned long long counts;   // items per class, 16 bits each (class c in bits 16c .. 16c+15)
+    int n;                      // row pairs, 0 .. 8
+    int cls;                    // length class of all of them
+    unsigned long long counts;  // n in the 16-bit field of its class (class c in bits 16c .. 16c+15)
 };
 __device__ __forceinline__ BwdItemsOf bwd_items_of(unsigned cull) {
     BwdItemsOf it;
-    it.n = 0, it.c_first = it.c_mid = it.c_last = 0, it.counts = 0ull;
+    it.n = 0, it.cls = 0, it.counts = 0ull;
     if (!(cull & 15u)) return it;
-    constexpr int SH = GI2D_BWD_ITEM_SHIFT, PER = 1 << SH;
     const int r0 = (int)((cull >> 8) & 15u), r1 = (int)((cull >> 12) & 15u);
-    const int np = (int)((cull >> 20) & 15u) - (int)((cull >> 16) & 15u) + 1;
-    it.n = (r1 >> SH) - (r0 >> SH) + 1;
-    const int rows_first = it.n == 1 ? r1 - r0 + 1 : PER - (r0 & (PER - 1)), rows_last = 1 + (r1 & (PER - 1));
-    it.c_first = bwd_len_class(rows_first * np);
-    it.c_mid = bwd_len_class(PER * np);
-    it.c_last = bwd_len_class(rows_last * np);
-    it.counts = 1ull << (16 * it.c_first);
-    if (it.n > 1) it.counts += (1ull << (16 * it.c_last)) + ((unsigned long long)(it.n - 2) << (16 * it.c_mid));
+    const int nc = (int)((cull >> 20) & 15u) - (int)((cull >> 16) & 15u) + 1;
+    it.n = (r1 >> 1) - (r0 >> 1) + 1;
+    it.cls = bwd_len_class(nc);
+    it.counts = (unsigned long long)(unsigned)it.n << (16 * it.cls);
     return it;
 }
 // First half of the item scan: this wave's inclusive scan of the per-class counts, its totals published in
@@ -460,11 +440,18 @@ __device__ __forceinline__ int bwd_field_sum(unsigned long long packed) {
     return (int)((packed & 0xffffu) + ((packed >> 16) & 0xffffu) + ((packed >> 32) & 0xffffu) + (packed >> 48));
 }
 
+template <bool USE_FIDX>
+__device__ __forceinline__ bool fidx_admits(int idx, float fidx_bits) {
+    return !USE_FIDX || idx <= __float_as_int(fidx_bits);
+}
+
 template <bool WITH_ABS, bool USE_FIDX = true, bool PRESCANNED = false, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
 __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, int list_base, float tx0, float ty0,
                                              float4 *__restrict__ dst, unsigned long long prescan_incl = 0ull,
                                              const int *prescan_wsum = nullptr) {
     constexpr int PSTR = Lds::PSTR;
+    static_assert(!USE_FIDX || Lds::HAS_FIDX, "final_idx is not staged in this LDS layout");
+    static_assert(!WITH_ABS || Lds::HAS_RAW, "the |v_xy| sums need the conic as given");
     const int tid = threadIdx.x, wv = tid >> 6;
     unsigned long long incl = prescan_incl;
     const int *wsum = prescan_wsum;
@@ -473,192 +460,140 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         wsum = sm.wsum;
         __syncthreads();
     }
-    // items of the tile per class; more than one round of them?  (tile-uniform: every wave needs it for the barriers --
-    // but a list of at most 32 entries, <= 8 items each, cannot hold more than one round: waves without entries of a
-    // sparse tile skip the sums)
-    const bool placing = (tid & ~63) < len || wv == 0;  // waves without entries have nothing to place (wave 0 closes off[])
-    unsigned long long total = 0ull;
-    if (placing || 8 * len > GI2D_BWD_ITEMS) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) total += (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
-    }
-    const int n_total = bwd_field_sum(total);
-    const bool multi_round = 8 * len > GI2D_BWD_ITEMS && n_total > GI2D_BWD_ITEMS;
-    // per class: the items in front of item 256 r in gaussian order, r = 1 .. 7 (multi-round tiles only; the hand-off
-    // buffer is idle until the first round has run)
-    unsigned long long *round_before = reinterpret_cast<unsigned long long *>(sm.part);
-    static_assert(sizeof(sm.part) >= 16 * sizeof(unsigned long long), "round_before[] lives in the hand-off buffer");
-#ifdef GI2D_BWD_GAUSSIAN_ORDER /* development aid: what the ordering by length buys */
-    const bool by_class = false;
-#else
-    const bool by_class = true;
-#endif
-    unsigned long long excl = 0ull;
+    // waves without entries have nothing to place (wave 0 publishes the item count)
+    const bool placing = (tid & ~63) < len || wv == 0;
     if (placing) {
-        // one item per row pair this gaussian reaches; its row / pixel-pair ranges ride along in sm.xr
-        const BwdItemsOf mine = bwd_items_of(cull);
-        if (tid < len) sm.xr[tid] = (cull >> 8) & 0xffffu;  // r0 | r1 << 4 | q0 << 8 | q1 << 12
-        unsigned long long before = 0ull;  // items of the waves before this one, per class
+        // the per-wave totals are the same for every lane: keep them, and everything derived from them, in scalar
+        // registers (class c's first slot = items of the classes before it)
+        unsigned long long before = 0ull, total = 0ull;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < wv) before += (unsigned long long)(unsigned)wsum[2 * k + 1] << 32 | (unsigned)wsum[2 * k];
-        excl = before + incl - mine.counts;         // per class: items of the gaussians before mine
-        const int orig0 = bwd_field_sum(excl);      // first item of mine in gaussian order
-        if (tid < len) sm.off[tid] = (unsigned short)orig0;
-        if (tid == 0) sm.off[len] = (unsigned short)n_total;
-        // Where the items go: class by class.  A tile of more than one round (trained scenes: gaussians several tiles
-        // wide, 300 ... 600 items per tile) keeps its ROUNDS in gaussian order -- an item's round must be the round of
-        // its row in the hand-off buffer -- and orders the items of each round by class among themselves, which needs
-        // the per-class counts in front of every round boundary first.
-        if (!multi_round) {
-            unsigned long long pos = excl + ((total << 16) + (total << 32) + (total << 48));  // + classes before, per field
-            for (int j = 0; j < mine.n; ++j) {
-                const int c = j == 0 ? mine.c_first : (j == mine.n - 1 ? mine.c_last : mine.c_mid);
-                const int slot = by_class ? (int)((pos >> (16 * c)) & 0xffffu) : orig0 + j;
-                pos += 1ull << (16 * c);
-                sm.item[slot] = (unsigned short)(tid | j << 8);
-            }
-        } else {
-            // the one gaussian whose items contain item 256 r publishes the counts in front of it
-            const int r_last = (orig0 + mine.n - 1) / GI2D_BWD_ITEMS, b = r_last * GI2D_BWD_ITEMS;
-            if (mine.n > 0 && r_last > 0 && b >= orig0) {
-                unsigned long long before_b = excl;
-                for (int j = 0; j < b - orig0; ++j)  // j < n - 1: never the gaussian's last item
-                    before_b += 1ull << (16 * (j == 0 ? mine.c_first : mine.c_mid));
-                round_before[r_last] = before_b;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(wsum[2 * k]);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(wsum[2 * k + 1]);
+            const unsigned long long w = (unsigned long long)hi << 32 | lo;
+            total += w;
+            if (k < __builtin_amdgcn_readfirstlane(wv)) before += w;
         }
-    }
-    if (multi_round) {  // tile-uniform
-        __syncthreads();
-        if (placing && tid < len) {
-            const BwdItemsOf mine = bwd_items_of(cull);
-            const int orig0 = bwd_field_sum(excl), rounds = (n_total + GI2D_BWD_ITEMS - 1) / GI2D_BWD_ITEMS;
-            unsigned long long seen = excl;  // per class: items in front of the next one of mine, whole tile
-            int r_cur = -1;
-            unsigned long long r_before = 0ull, r_classes = 0ull;
-            for (int j = 0; j < mine.n; ++j) {
-                const int c = j == 0 ? mine.c_first : (j == mine.n - 1 ? mine.c_last : mine.c_mid);
-                const int r = (orig0 + j) / GI2D_BWD_ITEMS;
-                if (r != r_cur) {
-                    r_cur = r;
-                    r_before = r == 0 ? 0ull : round_before[r];
-                    const unsigned long long in_round = (r + 1 < rounds ? round_before[r + 1] : total) - r_before;
-                    r_classes = (in_round << 16) + (in_round << 32) + (in_round << 48);  // field c: classes < c
-                }
-                const unsigned long long p = seen - r_before + r_classes;
-                const int slot = by_class ? r * GI2D_BWD_ITEMS + (int)((p >> (16 * c)) & 0xffffu) : orig0 + j;
-                seen += 1ull << (16 * c);
-                sm.item[slot] = (unsigned short)(tid | j << 8);
-            }
+        const unsigned long long class_base = (total << 16) + (total << 32) + (total << 48);  // field c: classes < c
+        const BwdItemsOf mine = bwd_items_of(cull);
+        const unsigned long long pos = before + class_base + (incl - mine.counts);
+        const int slot0 = (int)((pos >> (16 * mine.cls)) & 0xffffu);
+        if (tid < len) {
+            sm.set_box(tid, cull);
+            sm.span[tid] = (unsigned short)(slot0 | mine.n << 11);
+            for (int j = 0; j < mine.n; ++j) sm.item[slot0 + j] = (unsigned short)(tid | j << 8);
         }
+        if (tid == 0) sm.n_items = bwd_field_sum(total);
     }
     __syncthreads();
     GI2D_BWD_TRACE(7);
-    const int n_items = sm.off[len];
+    const int n_items = sm.n_items;
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 4 /* development aid: budget of the item build */
     if (n_items >= 0) return;
 #endif
-
-    // pixel x coordinates of a row's first pair, exactly as the forward forms them: (float)j
-    // (small integers: stepping by 2.0 stays exact)
-    const v2f px_first = {tx0, tx0 + 1.f};
+    // this lane's gaussian: its items are the slots [my_lo, my_hi)
+    int my_lo = 0, my_hi = 0;
+    if (dst != nullptr) {
+        const int sp = sm.span[tid];
+        my_lo = sp & 0x7ff, my_hi = my_lo + (sp >> 11);
+    }
 
     int round0 = 0;
     do {
         const int round1 = min(n_items, round0 + GI2D_BWD_ITEMS);
         const int it = round0 + tid;
         float res[PSTR];
-        int orig = -1;
 #if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 3 /* development aid (wrong results): no item is run */
         if (it < 0) {
 #else
         if (it < round1) {
 #endif
             const int code = sm.item[it], k = code & 255;
-            const unsigned xr = sm.xr[k];
-            constexpr int SH = GI2D_BWD_ITEM_SHIFT;
-            const int rp = (int)((xr & 15u) >> SH) + (code >> 8);  // items of k: its row pairs in order
-            orig = (int)sm.off[k] + (code >> 8) - round0;          // this item's row in the hand-off order
-            const int row_lo = max(rp << SH, (int)(xr & 15u)), row_hi = min((rp << SH) + (1 << SH) - 1, (int)((xr >> 4) & 15u));
-#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 1 /* development aid (wrong results): one trip per row */
-            const int q_lo = (int)((xr >> 8) & 15u), q_hi = q_lo;
+            const unsigned xr = sm.box_of(k);  // r0 | r1 << 4 | c0 << 8 | c1 << 12
+            const int r0 = (int)(xr & 15u), r1 = (int)((xr >> 4) & 15u);
+            const int p = (r0 >> 1) + (code >> 8);               // items of k: its row pairs in order
+            const bool in_a = 2 * p >= r0, in_b = 2 * p + 1 <= r1;  // a box may start on row B / end on row A of a pair
+            const int c_lo = (int)((xr >> 8) & 15u);
+#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 1 /* development aid (wrong results): one trip per item */
+            const int c_hi = c_lo;
 #else
-            const int q_lo = (int)((xr >> 8) & 15u), q_hi = (int)((xr >> 12) & 15u);
+            const int c_hi = (int)((xr >> 12) & 15u);
 #endif
             const float4 A = sm.gA[k], B = sm.gB[k];
             const float cb = sm.gCb[k];
-            const float gx = A.x, gy = A.y, a = A.z, b = A.w, c = B.x, opac = B.y;
-            const ConicS s = scale_conic(a, b, c);
-            const v2f ha2 = {s.ha, s.ha}, gx2 = {gx, gx}, opac2 = {opac, opac};
+            const float gx = A.x, gy = A.y, opac = B.y;
+            ConicS s;
+            s.ha = A.z, s.hb = A.w, s.hc = B.x;
+            // row terms exactly as the forward forms them: dy = gy - (float)i, b*dy, c*dy*dy
+            const float py_a = ty0 + (float)(2 * p);
+            const v2f dy = {gy - py_a, gy - (py_a + 1.f)};
+            const v2f bdy = {row_term_b(s, dy.x), row_term_b(s, dy.y)};
+            const v2f cdy2 = {row_term_c(s, dy.x), row_term_c(s, dy.y)};
+            const v2f ha2 = {s.ha, s.ha}, opac2 = {opac, opac};
             const v2f cr2 = {B.z, B.z}, cg2 = {B.w, B.w}, cb2 = {cb, cb};
             const int idx = list_base + k;
-            float vx = 0.f, vy = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, gop = 0.f;
+            v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
             v2f gr = {0.f, 0.f}, gg = {0.f, 0.f}, gb = {0.f, 0.f}, ax = {0.f, 0.f}, ay = {0.f, 0.f};
-            const int row_end = row_hi;
+            float4 raw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (WITH_ABS) raw = sm.gRaw[k];
+            const float4 *rec = &sm.pix[2 * (p * GI2D_TILE + c_lo)];
+            const float4 *rec_end = rec + 2 * (c_hi - c_lo);
+            // pixel x coordinates exactly as the forward forms them: (float)j (small integers: stepping by 1.0 stays exact)
+            float px = tx0 + (float)c_lo;
 #pragma unroll 1
-            for (int row = row_lo; row <= row_end; ++row) {
-                const float dy = gy - (ty0 + (float)row);
-                const float bdy = row_term_b(s, dy), cdy2 = row_term_c(s, dy);
-                const v2f bdy2 = {bdy, bdy}, cdy22 = {cdy2, cdy2};
-                const float bdy_u = b * dy, cdy_u = c * dy;
-                v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
-                const float4 *pa = &sm.pixA[row * GI2D_BWD_PIXROW];
-                const typename Lds::PixB *pb = &sm.pixB[row * GI2D_BWD_PIXROW];
-                v2f px = px_first + (v2f){(float)(2 * q_lo), (float)(2 * q_lo)};
-#pragma unroll 1
-                for (int q = q_lo; q <= q_hi; ++q) {
-                    const float4 P0 = pa[q];
-                    const typename Lds::PixB P1 = pb[q];
-                    const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
-                    const v2f dx = gx2 - px;
-                    px += (v2f){2.f, 2.f};
-                    // == pair_sigma() of the forward, two pixels per instruction
-                    const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha2, dx, bdy2), cdy22);
-                    const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
-                    const v2f t = opac2 * vis;
-                    // backward.cu:903 (idx <= final_idx) and :925 (alpha = min(1,t) < 1/255 <=> t < 1/255)
-                    const bool ok0 = fidx_admits<USE_FIDX>(idx, P1, 0) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
-                    const bool ok1 = fidx_admits<USE_FIDX>(idx, P1, 1) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
-                    const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
-                    const v2f am = {fminf(1.f, tz.x), fminf(1.f, tz.y)};
-                    // backward.cu:940-946
-                    const v2f v_alpha =
-                        __builtin_elementwise_fma(cb2, voz, __builtin_elementwise_fma(cg2, voy, cr2 * vox));
-                    gr = __builtin_elementwise_fma(am, vox, gr);
-                    gg = __builtin_elementwise_fma(am, voy, gg);
-                    gb = __builtin_elementwise_fma(am, voz, gb);
-                    const v2f w = tz * v_alpha;  // = -v_sigma (backward.cu:948), 0 when the pair is invalid
-                    S0 += w;
-                    const v2f wdx = w * dx;
-                    S1 += wdx;
-                    S2 = __builtin_elementwise_fma(wdx, dx, S2);
-                    if (WITH_ABS) {  // backward.cu:959-960 (commented in the shipped kernel): sum |v_xy|
-                        const v2f a2 = {a, a}, b2 = {b, b};
-                        const v2f ux = w * __builtin_elementwise_fma(a2, dx, (v2f){bdy_u, bdy_u});
-                        const v2f uy = w * __builtin_elementwise_fma(b2, dx, (v2f){cdy_u, cdy_u});
-                        ax += __builtin_elementwise_abs(ux);
-                        ay += __builtin_elementwise_abs(uy);
-                    }
+            for (;; rec += 2) {
+                const float4 P0 = rec[0];
+                float4 P1;
+                if (USE_FIDX) {
+                    P1 = rec[1];
+                } else {
+                    const float2 h = *reinterpret_cast<const float2 *>(rec + 1);
+                    P1 = make_float4(h.x, h.y, 0.f, 0.f);
                 }
-                const float s0 = S0.x + S0.y, s1 = S1.x + S1.y, s2 = S2.x + S2.y;
-                const float dys0 = dy * s0;
-                vx -= __builtin_fmaf(a, s1, b * dys0);   // sum v_sigma*(a dx + b dy)
-                vy -= __builtin_fmaf(b, s1, c * dys0);   // sum v_sigma*(b dx + c dy)
-                c0 -= 0.5f * s2;                         // sum 0.5 v_sigma dx dx
-                c1 -= 0.5f * dy * s1;                    // sum 0.5 v_sigma dx dy
-                c2 -= 0.5f * dy * dys0;                  // sum 0.5 v_sigma dy dy
-                gop += s0;                               // sum opac*vis*v_alpha
+                const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
+                const float dx1 = gx - px;
+                px += 1.f;
+                const v2f dx = {dx1, dx1};
+                // == pair_sigma() of the forward, the two rows of the pair per instruction
+                const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha2, dx, bdy), cdy2);
+                const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+                const v2f t = opac2 * vis;
+                // backward.cu:903 (idx <= final_idx) and :925 (alpha = min(1,t) < 1/255 <=> t < 1/255)
+                const bool ok0 = in_a && fidx_admits<USE_FIDX>(idx, P1.z) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
+                const bool ok1 = in_b && fidx_admits<USE_FIDX>(idx, P1.w) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
+                const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
+                const v2f am = {fminf(1.f, tz.x), fminf(1.f, tz.y)};
+                // backward.cu:940-946
+                const v2f v_alpha =
+                    __builtin_elementwise_fma(cb2, voz, __builtin_elementwise_fma(cg2, voy, cr2 * vox));
+                gr = __builtin_elementwise_fma(am, vox, gr);
+                gg = __builtin_elementwise_fma(am, voy, gg);
+                gb = __builtin_elementwise_fma(am, voz, gb);
+                const v2f w = tz * v_alpha;  // = -v_sigma (backward.cu:948), 0 when the pair is invalid
+                S0 += w;
+                const v2f wdx = w * dx;
+                S1 += wdx;
+                S2 = __builtin_elementwise_fma(wdx, dx, S2);
+                if (WITH_ABS) {  // backward.cu:959-960 (commented in the shipped kernel): sum |v_xy|
+                    const v2f a2 = {raw.x, raw.x}, b2 = {raw.y, raw.y}, c2 = {raw.z, raw.z};
+                    const v2f ux = w * __builtin_elementwise_fma(a2, dx, b2 * dy);
+                    const v2f uy = w * __builtin_elementwise_fma(b2, dx, c2 * dy);
+                    ax += __builtin_elementwise_abs(ux);
+                    ay += __builtin_elementwise_abs(uy);
+                }
+                if (rec >= rec_end) break;
             }
-            res[0] = vx;
-            res[1] = vy;
-            res[2] = c0;
-            res[3] = c1;
-            res[4] = c2;
+            // the item's moments (see the head of this section)
+            const float u0a = dy.x * S0.x, u0b = dy.y * S0.y;
+            res[0] = S1.x + S1.y;                              // T1 = sum w dx
+            res[1] = u0a + u0b;                                // U0 = sum w dy
+            res[2] = S2.x + S2.y;                              // T2 = sum w dx^2
+            res[3] = __builtin_fmaf(dy.x, S1.x, dy.y * S1.y);  // U1 = sum w dx dy
+            res[4] = __builtin_fmaf(dy.x, u0a, dy.y * u0b);    // V0 = sum w dy^2
             res[5] = gr.x + gr.y;
             res[6] = gg.x + gg.y;
             res[7] = gb.x + gb.y;
-            res[8] = (gop != 0.f) ? gop / opac : 0.f;  // v_opacity = sum vis*v_alpha (backward.cu:961)
+            res[8] = S0.x + S0.y;                              // T0 = sum w = sum opac*vis*v_alpha
             if (WITH_ABS) {
                 res[PSTR - 2] = ax.x + ax.y;
                 res[PSTR - 1] = ay.x + ay.y;
@@ -674,30 +609,21 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             return;
         }
 #endif
-        // hand-off: the lane that owns gaussian `tid` adds its (<= 8) row-pair partials of this round, in row
+        // hand-off: the lane that owns gaussian `tid` adds the moments of its (<= 8) items of this round, in row
         // order.  The LDS exchange buffer holds PART_ROWS item rows, so a round is handed over in
         // GI2D_BWD_ITEMS / PART_ROWS passes (half the buffer = two more barriers, 4.5 KB less LDS per workgroup).
         constexpr int PROWS = Lds::PART_ROWS;
-        int my_lo = 0, my_hi = 0;
-        if (dst != nullptr) my_lo = sm.off[tid], my_hi = sm.off[tid + 1];
         const int lo = max(my_lo, round0), hi = min(my_hi, round1);
         // a gaussian without items still owes a zero row
         const bool owner = dst != nullptr && (hi > lo || (round0 == 0 && my_hi == my_lo));
         float acc[PSTR];
 #pragma unroll
         for (int q = 0; q < PSTR; ++q) acc[q] = 0.f;
-        if (owner && my_lo < round0) {  // earlier round(s) already stored part of this row
-            const float4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
-            acc[0] = d0.x, acc[1] = d0.y, acc[2] = d0.z, acc[3] = d0.w;
-            acc[4] = d1.x, acc[5] = d1.y, acc[6] = d1.z, acc[7] = d1.w;
-            acc[8] = d2.x;
-            if (PSTR > 9) acc[PSTR - 2] = d2.y, acc[PSTR - 1] = d2.z;
-        }
 #pragma unroll
         for (int h0 = 0; h0 < GI2D_BWD_ITEMS; h0 += PROWS) {
             if (h0 > 0 && round0 + h0 >= round1) break;  // nothing left in this round (tile-uniform)
-            if (orig >= h0 && orig < h0 + PROWS) {
-                float *out = &sm.part[(orig - h0) * PSTR];
+            if (tid >= h0 && tid < h0 + PROWS && it < round1) {
+                float *out = &sm.part[(tid - h0) * PSTR];
 #pragma unroll
                 for (int q = 0; q < PSTR; ++q) out[q] = res[q];
             }
@@ -719,11 +645,33 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             if (!last) __syncthreads();
         }
         GI2D_BWD_TRACE(9);
+        if (owner) {
+            if (hi > lo) {
+                // moments -> gradients, once per (tile, gaussian) and round: the map is linear, so the rounds' rows add.
+                // The conic staged in LDS is the pre-scaled one (a log2e / 2, b log2e, c log2e / 2).
+                const float4 A = sm.gA[tid], B = sm.gB[tid];
+                const float ln2 = 0.6931471805599453f;
+                const float T1 = acc[0], U0 = acc[1], opac = B.y;
+                acc[0] = -ln2 * __builtin_fmaf(2.f * A.z, T1, A.w * U0);  // -(a T1 + b U0) = sum v_sigma (a dx + b dy)
+                acc[1] = -ln2 * __builtin_fmaf(A.w, T1, 2.f * B.x * U0);  // -(b T1 + c U0) = sum v_sigma (b dx + c dy)
+                acc[2] *= -0.5f;                                          // sum 0.5 v_sigma dx dx
+                acc[3] *= -0.5f;                                          // sum 0.5 v_sigma dx dy
+                acc[4] *= -0.5f;                                          // sum 0.5 v_sigma dy dy
+                acc[8] = (acc[8] != 0.f) ? acc[8] / opac : 0.f;           // v_opacity = sum vis*v_alpha (backward.cu:961)
+            }
+            if (my_lo < round0) {  // an earlier round already stored part of this row
+                const float4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
+                acc[0] += d0.x, acc[1] += d0.y, acc[2] += d0.z, acc[3] += d0.w;
+                acc[4] += d1.x, acc[5] += d1.y, acc[6] += d1.z, acc[7] += d1.w;
+                acc[8] += d2.x;
+                if (PSTR > 9) acc[PSTR - 2] += d2.y, acc[PSTR - 1] += d2.z;
+            }
 #if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 4 /* development aid (wrong results): gradient rows are not stored */
-        if (owner && acc[0] == 12345.678f) store_partial_row<PSTR>(dst, acc);
+            if (acc[0] == 12345.678f) store_partial_row<PSTR>(dst, acc);
 #else
-        if (owner) store_partial_row<PSTR>(dst, acc);
+            store_partial_row<PSTR>(dst, acc);
 #endif
+        }
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);
 }

@@ -159,13 +159,19 @@ def test_quantised_fit_end_to_end_codec():
         fit.train(300)
         fit.check_status()
         p_q = fit.load_best()
+        p_live = fit.psnr()  # the snapshot's own (quantised) render
         enc = fit.compress_wo_ec()
         out = fit.decompress_wo_ec(enc)
         p_dec = 10 * math.log10(1.0 / torch.nn.functional.mse_loss(out, gt).item())
-        runs.append((p_warm, p_q, p_dec, fit.qparams.clone(), fit.xyz.clone(), enc, fit.n))
-    p_warm, p_q, p_dec, qp, xyz, enc, n_left = runs[0]
+        runs.append((p_warm, p_q, p_dec, fit.qparams.clone(), fit.xyz.clone(), enc, fit.n, p_live))
+    p_warm, p_q, p_dec, qp, xyz, enc, n_left, p_live = runs[0]
+    print(f"codec: warm {p_warm:.3f} dB, best step {p_q:.3f} dB, snapshot render {p_live:.3f} dB, decoded {p_dec:.3f} dB")
     assert p_warm > 22 and p_q > p_warm - 3.0, (p_warm, p_q)      # 12/10/6-bit attributes cost little
-    assert abs(p_dec - p_q) < 0.5, (p_dec, p_q)                    # the decoder reproduces the trained render
+    assert abs(p_dec - p_live) < 0.02, (p_dec, p_live)             # the decoder reproduces the snapshot's render
+    # The snapshot follows train.py:133-139: the PSNR is that of the render made INSIDE the best step, the parameters
+    # are the ones that step's update left behind -- one optimizer step apart (at lr 0.018 on a 144x96 image that is
+    # up to a dB either way, and which way depends on the last bit of the trajectory).
+    assert abs(p_dec - p_q) < 2.0, (p_dec, p_q)
     assert torch.equal(qp, runs[1][3]) and torch.equal(xyz, runs[1][4])  # ordered sums, no float atomics: bitwise
     for key, hi in (("quant_means", 4095), ("quant_cholesky_elements", 1023), ("feature_dc_index", 63)):
         c = enc[key]

@@ -10,6 +10,10 @@ variant_name() {  # a file-system-safe name for a flag string
 use_variant() {
   local flags="$1" name; name=$(variant_name "$1")
   if [ -z "$(echo $flags)" ]; then use_product; return; fi
+  # PREBUILT=1: variants were built before the snapshot was sent (file times do not survive the copy: make would rebuild)
+  if [ "$PREBUILT" = 1 ] && [ -f $GRAFT_REPO_ROOT/build/variants/$name/libgi2d_hip.so ]; then
+    export GI2D_LIB=$GRAFT_REPO_ROOT/build/variants/$name/libgi2d_hip.so GI2D_ALLOW_DEV_BUILD=1; return
+  fi
   if make -s -j8 -C $GRAFT_REPO_ROOT/gaussianimage_plus_amd/csrc VARIANT="$name" EXTRA="$flags" 2>&1 | grep -E "error|Error"; then return 1; fi
   export GI2D_LIB=$GRAFT_REPO_ROOT/build/variants/$name/libgi2d_hip.so GI2D_ALLOW_DEV_BUILD=1
 }
