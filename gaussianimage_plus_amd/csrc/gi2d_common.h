@@ -112,6 +112,31 @@ __device__ __forceinline__ float pair_sigma(const ConicS &s, float dx, float bdy
 }
 __device__ __forceinline__ float pair_vis(float sigma_l2) { return __builtin_amdgcn_exp2f(-sigma_l2); }
 
+// Which pairs of a gaussian land (forward.cu:539-541: `sigma < 0 || alpha < 1/255` are skipped, alpha = min(1, opac *
+// vis)).  With sigma' = log2e * sigma the two tests are ONE range test, 0 <= sigma' <= log2(255 * opac), and for
+// non-negative floats "<=" is the order of their bit patterns while every negative float (sign bit set) compares
+// above all of them as an unsigned integer:
+//     lands  <=>  (unsigned)bits(sigma') < lim,      lim = bits(log2(255 * opac)) + 1      (one v_cmp instead of two)
+// lim = 0: never (255 * opac < 1, opac <= 0).  A gaussian with a NaN among its parameters keeps the reference's
+// behaviour -- every comparison with NaN is false, so nothing is skipped and alpha = fminf(1, NaN) = 1 -- with
+// lim = 0xffffffff.  `clamp`: min(1, .) can bind (opac > 1, or NaN): with 0 <= opac <= 1 a landing pair has
+// vis <= 1 (v_exp_f32 of a non-positive argument never exceeds 1: tools/ubench/exp_le_one.hip sweeps it), so
+// opac * vis <= 1 and the min is the identity -- loops over entries none of which needs it run without the two v_min.
+struct AlphaRule {
+    unsigned lim;
+    bool clamp;
+};
+__device__ __forceinline__ AlphaRule alpha_rule(float gx, float gy, float a, float b, float c, float opac) {
+    AlphaRule r;
+    const float s = gx + gy + a + b + c + opac;
+    const bool has_nan = s != s;  // (also inf - inf: such a gaussian is evaluated everywhere, as one with a NaN is)
+    r.clamp = has_nan || !(opac <= 1.f);
+    const float smax = __builtin_amdgcn_logf(opac * 255.f);  // v_log_f32 = log2
+    r.lim = has_nan ? 0xffffffffu : (smax >= 0.f ? (unsigned)__float_as_int(smax) + 1u : 0u);
+    return r;
+}
+__device__ __forceinline__ bool pair_lands(float sigma_l2, unsigned lim) { return (unsigned)__float_as_int(sigma_l2) < lim; }
+
 // Conservative pixel-space bounding box of {sigma <= ln(255*opac)} (the only place where a
 // pair can pass `alpha >= 1/255`, forward.cu:541), widened by a safety margin.  Returns false
 // when the gaussian can never contribute; full=true when no finite box exists (non positive

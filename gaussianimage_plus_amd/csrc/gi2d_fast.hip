@@ -117,8 +117,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
             float4 *row = partial_row(slot, partial_g, partial_big, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, status);
             if (!row) slot = GI2D_NO_ROW;
             if (rank < GI2D_TILE_LIST_CAP) {
-                const unsigned mask = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
-                fwd_stage_entry(sm.f, rank, r, mask);
+                const AlphaRule ar = alpha_rule(r.gx, r.gy, r.a, r.b, r.c, r.opac);
+                const unsigned mask = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h, ar.clamp);
+                fwd_stage_entry(sm.f, rank, r, mask, ar.lim);
                 float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
                 dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
                 dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
         const ConicS cs = scale_conic(q0.z, q0.w, q1.x);
         sm.gA[tid] = make_float4(q0.x, q0.y, cs.ha, cs.hb);
         sm.gB[tid] = make_float4(cs.hc, q1.y, q1.z, q1.w);
-        sm.gCb[tid] = q2.x;
+        sm.gC[tid] = make_float2(q2.x, __int_as_float((int)alpha_rule(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y).lim));
         if constexpr (WITH_ABS) sm.gRaw[tid] = make_float4(q0.z, q0.w, q1.x, 0.f);
         slot = __float_as_int(q2.y);
         mask = (unsigned)__float_as_int(q2.w);

@@ -58,9 +58,8 @@ struct FusedLds {
     static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
     float4 gA[GI2D_TILE_LIST_CAP + 1];  // gx, gy, ha, hb      (entry CAP: the forward's never-contributing padding;
     float4 gB[GI2D_TILE_LIST_CAP + 1];  // hc, opac, cr, cg     conic pre-scaled: gi2d_common.h::scale_conic)
-    float gCb[GI2D_TILE_LIST_CAP + 4];  // cb
+    float2 gC[GI2D_TILE_LIST_CAP + 2];  // cb, lim (gi2d_common.h::AlphaRule)
     unsigned cullw[GI2D_TILE_LIST_CAP]; // cull_word() of the entry
-    int slot[GI2D_TILE_LIST_CAP];       // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big)
     float sse_w[4];
     int scan_w[8];  // per-wave totals of the backward's item scan (outside the overlay: written during the forward phase)
     int grp[32];    // tile_list_head: survivors per 64 entries (ascending part, appended part)
@@ -79,6 +78,12 @@ struct FusedLds {
             float part[GI2D_BWD_PART_ROWS * PSTR];
             int wsum[8];
             int n_items;
+        };
+        struct {  // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big): written by the head,
+                  // read when the backward starts -- in bytes the forward's buffers do not reach and the backward only
+                  // writes in its hand-off (`part`), behind the barrier that follows the reads
+            char fwd_reach[sizeof(unsigned char) * 4 * 2 * GI2D_FWD_LISTLEN + sizeof(float4) * GI2D_FWD_PAIRBUF];
+            int slot[GI2D_TILE_LIST_CAP];
         };
     };
     // rows / columns of entry k's box: its cull word stays staged through both phases
@@ -121,7 +126,7 @@ __device__ __forceinline__ void fused_tile(
     if (tid == 0) {
         sm.gA[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
         sm.gB[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
-        sm.gCb[GI2D_TILE_LIST_CAP] = 0.f;
+        sm.gC[GI2D_TILE_LIST_CAP] = make_float2(0.f, 0.f);            // lim 0: never lands
     }
     GI2D_TRACE(1);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
@@ -133,8 +138,9 @@ __device__ __forceinline__ void fused_tile(
                 const ConicS cs = scale_conic(r.a, r.b, r.c);
                 sm.gA[rank] = make_float4(r.gx, r.gy, cs.ha, cs.hb);
                 sm.gB[rank] = make_float4(cs.hc, r.opac, r.cr, r.cg);
-                sm.gCb[rank] = r.cb;
-                sm.cullw[rank] = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h);
+                const AlphaRule ar = alpha_rule(r.gx, r.gy, r.a, r.b, r.c, r.opac);
+                sm.gC[rank] = make_float2(r.cb, __int_as_float((int)ar.lim));
+                sm.cullw[rank] = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h, ar.clamp);
                 sm.slot[rank] = slot;
             } else if (float4 *row = partial_row(slot, partial_g, partial_big, pool_rows, status)) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
@@ -164,7 +170,8 @@ __device__ __forceinline__ void fused_tile(
             const float4 A = sm.gA[k], B = sm.gB[k];
             FwdRec r;
             r.gx = A.x, r.gy = A.y, r.ha = A.z, r.hb = A.w, r.hc = B.x, r.op = B.y, r.cr = B.z, r.cg = B.w;
-            r.cb = sm.gCb[k];
+            const float2 c = sm.gC[k];
+            r.cb = c.x, r.lim = (unsigned)__float_as_int(c.y);
             return r;
         },
         (float)j, (float)i, o0, o1, o2, last_unused);

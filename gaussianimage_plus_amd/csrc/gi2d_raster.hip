@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(
     // dependent global loads), and records which 4-row strips each gaussian can reach
     if (tid < len) {
         const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
-        fwd_stage_entry(sm, tid, r, cull_word(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h));
+        const AlphaRule ar = alpha_rule(r.gx, r.gy, r.a, r.b, r.c, r.opac);
+        fwd_stage_entry(sm, tid, r, cull_word(r, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), img_h, ar.clamp), ar.lim);
     }
     if (tid == 0) fwd_stage_dummy(sm);
     __syncthreads();
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void raster_bwd_k
     unsigned mask = 0;
     if (tid < len) {
         const GaussRec r = load_gaussian(gids_sorted[range.x + tid], xys, conics, colors, opacities);
-        bwd_stage_entry(sm, tid, r);
-        mask = cull_word(r, tx0, ty0, img_h);
+        const AlphaRule ar = alpha_rule(r.gx, r.gy, r.a, r.b, r.c, r.opac);
+        bwd_stage_entry(sm, tid, r, ar.lim);
+        mask = cull_word(r, tx0, ty0, img_h, ar.clamp);
     }
     bwd_run_tile<WITH_ABS>(sm, len, mask, range.x, tx0, ty0,
                            tid < len ? partials + 3 * (size_t)(range.x + tid) : nullptr);

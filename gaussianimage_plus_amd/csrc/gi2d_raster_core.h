@@ -46,7 +46,9 @@ __device__ __forceinline__ GaussRec load_gaussian(int g, const float2 *__restric
 //   (rows / columns of the 16x16 tile, from the conservative box of gi2d_common.h::cull_box, clipped to the
 //   image height); 0 when it reaches nothing.  Evaluating more pixels than necessary never changes a
 //   result (they fail the alpha test); the box guarantees none that passes is left out.
-__device__ __forceinline__ unsigned cull_word_of(const CullBox &box, float tx0, float ty0, int img_h) {
+//   bit 24     min(1, opac * vis) can bind for this gaussian (gi2d_common.h::AlphaRule::clamp)
+#define GI2D_CULL_CLAMP (1u << 24)
+__device__ __forceinline__ unsigned cull_word_of(const CullBox &box, float tx0, float ty0, int img_h, bool clamp) {
     const float last_row = fminf(15.f, (float)(img_h - 1) - ty0);
     const float r0f = fmaxf(ceilf(box.y0 - ty0), 0.f), r1f = fminf(floorf(box.y1 - ty0), last_row);
     const float c0f = fmaxf(ceilf(box.x0 - tx0), 0.f), c1f = fminf(floorf(box.x1 - tx0), 15.f);
@@ -54,19 +56,19 @@ __device__ __forceinline__ unsigned cull_word_of(const CullBox &box, float tx0, 
     const unsigned r0 = (unsigned)r0f, r1 = (unsigned)r1f, c0 = (unsigned)c0f, c1 = (unsigned)c1f;
     const unsigned s0 = r0 >> 2, s1 = r1 >> 2;
     const unsigned strips = ((2u << s1) - 1u) & ~((1u << s0) - 1u);  // bits s0 .. s1
-    return strips | (r0 << 8) | (r1 << 12) | (c0 << 16) | (c1 << 20);
+    return strips | (r0 << 8) | (r1 << 12) | (c0 << 16) | (c1 << 20) | (clamp ? GI2D_CULL_CLAMP : 0u);
 }
-__device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, float ty0, int img_h) {
+__device__ __forceinline__ unsigned cull_word(const GaussRec &r, float tx0, float ty0, int img_h, bool clamp) {
     CullBox box;
     if (!cull_box(r.gx, r.gy, r.a, r.b, r.c, r.opac, box)) return 0u;
-    return cull_word_of(box, tx0, ty0, img_h);
+    return cull_word_of(box, tx0, ty0, img_h, clamp);
 }
 // the same from extents computed once per gaussian (fast path records)
 __device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, float hy, float tx0, float ty0,
-                                                  int img_h) {
+                                                  int img_h, bool clamp) {
     CullBox box;
     if (!cull_box_of(gx, gy, hx, hy, box)) return 0u;
-    return cull_word_of(box, tx0, ty0, img_h);
+    return cull_word_of(box, tx0, ty0, img_h, clamp);
 }
 
 // =========================================================================================== forward
@@ -78,32 +80,71 @@ __device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, 
 // ITS list with packed fp32 (v_pk_fma_f32 & co), entry 2p feeding one accumulator set and 2p+1 another (summed
 // at the end).  A wave needs max(|left|, |right|) / 2 trips instead of |left u right| / 2 (-37 % at that size).
 // Entries are copied GI2D_FWD_CHUNK at a time into a wave-private pair-interleaved buffer -- entries 2p and 2p+1
-// side by side, 20 floats per pair: (gx gx' gy gy') (ha ha' hb hb') (hc hc' op op') (cr cr' cg cg') (cb cb' k k') --
-// so one pair costs four ds_read_b128 + one or two ds_read_b64; the two halves' buffers are 128 bytes out of
-// phase, so the two addresses of one read never share a bank.  Every forward kernel (plain, fast, single-pass)
-// runs this one routine: identical pixels bit for bit.
+// side by side, 20 floats per pair: (gx gx' gy gy') (ha ha' hb hb') (hc hc' op op') (cr cr' cg cg') (cb cb' lim lim')
+// [+ (k k' - -) where final_idx is wanted: 24 floats] -- so one pair costs five ds_read_b128; the two halves' buffers
+// are 128 bytes out of phase, so the two addresses of one read never share a bank.  `lim` is the pair test of
+// gi2d_common.h::AlphaRule (one unsigned compare per pair); a wave none of whose entries can exceed alpha = 1 runs
+// the trips without the two v_min (bit-identical: the min is the identity there).  Every forward kernel (plain, fast,
+// single-pass) runs this one routine: identical pixels bit for bit.
 #define GI2D_FWD_DUMMY GI2D_TILE_LIST_CAP /* index of a never-contributing entry used as list padding */
 #ifndef GI2D_FWD_CHUNK
 #define GI2D_FWD_CHUNK 32                 /* list entries per half copied per trip */
 #endif
-#define GI2D_FWD_HALF (GI2D_FWD_CHUNK / 2 * 20 + 32) /* floats from the left buffer to the right one (incl. bank shift) */
-#define GI2D_FWD_PAIRBUF (GI2D_FWD_HALF + GI2D_FWD_CHUNK / 2 * 20) /* floats per wave */
+#define GI2D_FWD_PF(FIDX) ((FIDX) ? 24 : 20)                             /* floats per staged pair */
+#define GI2D_FWD_HALF_OF(FIDX) (GI2D_FWD_CHUNK / 2 * GI2D_FWD_PF(FIDX) + 32) /* floats from the left buffer to the right one (incl. bank shift) */
+#define GI2D_FWD_PAIRBUF_OF(FIDX) (GI2D_FWD_HALF_OF(FIDX) + GI2D_FWD_CHUNK / 2 * GI2D_FWD_PF(FIDX)) /* floats per wave */
+#define GI2D_FWD_PAIRBUF GI2D_FWD_PAIRBUF_OF(false)
 #define GI2D_FWD_LISTLEN (GI2D_TILE_LIST_CAP + 8)
 
 struct FwdRec {  // one staged entry as the pixel loop consumes it (conic pre-scaled: scale_conic)
     float gx, gy, ha, hb, hc, op, cr, cg, cb;
+    unsigned lim;  // AlphaRule::lim
 };
 
-// lists: [2][GI2D_FWD_LISTLEN] bytes of this wave (left, right); buf: GI2D_FWD_PAIRBUF floats of this wave (16-byte
-// aligned).  cull_of(k) -> cull_word of entry k, rec_of(k) -> FwdRec of entry k (k == GI2D_FWD_DUMMY must give an
-// entry with opacity 0).  Returns the pixel in o0..o2 and, with NEED_FIDX, the last contributing entry (-1: none).
+template <bool NEED_FIDX, bool CLAMP>
+__device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px2, const v2f py2, v2f &a0, v2f &a1,
+                                          v2f &a2, int &last) {
+    constexpr int PF = GI2D_FWD_PF(NEED_FIDX);
+#pragma unroll 2
+    for (int t = 0; t < m; t += 2) {
+        const float4 *q = reinterpret_cast<const float4 *>(mine + (t >> 1) * PF);
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+        const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
+        const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
+        const v2f cb = {q4.x, q4.y};
+        const v2f dx = gx - px2, dy = gy - py2;
+        const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
+        const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
+        const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+        const v2f tt = op * vis;
+        const bool ok0 = pair_lands(sig.x, (unsigned)__float_as_int(q4.z));  // forward.cu:539-541
+        const bool ok1 = pair_lands(sig.y, (unsigned)__float_as_int(q4.w));
+        v2f am = {ok0 ? tt.x : 0.f, ok1 ? tt.y : 0.f};
+        if (CLAMP) am = (v2f){fminf(1.f, am.x), fminf(1.f, am.y)};
+        a0 = __builtin_elementwise_fma(cr, am, a0);
+        a1 = __builtin_elementwise_fma(cg, am, a1);
+        a2 = __builtin_elementwise_fma(cb, am, a2);
+        if (NEED_FIDX) {  // entries ascend within a list: the last one that lands is the largest
+            const float2 ks = *reinterpret_cast<const float2 *>(q + 5);
+            last = ok0 ? __float_as_int(ks.x) : last;
+            last = ok1 ? __float_as_int(ks.y) : last;
+        }
+    }
+}
+
+// lists: [2][GI2D_FWD_LISTLEN] bytes of this wave (left, right); buf: GI2D_FWD_PAIRBUF_OF(NEED_FIDX) floats of this
+// wave (16-byte aligned).  cull_of(k) -> cull_word of entry k, rec_of(k) -> FwdRec of entry k (k == GI2D_FWD_DUMMY must
+// give an entry that never lands: lim 0).  Returns the pixel in o0..o2 and, with NEED_FIDX, the last contributing entry
+// (-1: none).
 template <bool NEED_FIDX, class CullOf, class RecOf>
 __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float *buf, int len, CullOf cull_of,
                                                      RecOf rec_of, float px, float py, float &o0, float &o1,
                                                      float &o2, int &last_k) {
+    constexpr int PF = GI2D_FWD_PF(NEED_FIDX), HALF = GI2D_FWD_HALF_OF(NEED_FIDX);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned char *left = lists, *right = lists + GI2D_FWD_LISTLEN;
     int n_left = 0, n_right = 0;
+    bool clamp_any = false;  // wave-uniform
     for (int base = 0; base < len; base += 64) {
         const int k = base + lane;
         const unsigned w = k < len ? cull_of(k) : 0u;
@@ -115,15 +156,16 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
         if (tr) right[n_right + __popcll(mr & lanemask_lt())] = (unsigned char)k;
         n_left += __popcll(ml);
         n_right += __popcll(mr);
+        clamp_any = clamp_any || __ballot(reach && (w & GI2D_CULL_CLAMP)) != 0ull;
     }
     __builtin_amdgcn_wave_barrier();  // wave-private lists: DS ops of one wave complete in order
 
     const int my_half = (lane >> 3) & 1;           // which list this pixel walks
-    const float *mine = buf + my_half * GI2D_FWD_HALF;
+    const float *mine = buf + my_half * HALF;
     const int bh = lane >> 5, be = lane & 31;      // build role: lanes 0-31 copy left entries, 32-63 right entries
     const unsigned char *blist = bh ? right : left;
     const int bcnt = bh ? n_right : n_left;
-    float *bdst = buf + bh * GI2D_FWD_HALF + (be >> 1) * 20 + (be & 1);
+    float *bdst = buf + bh * HALF + (be >> 1) * PF + (be & 1);
     const int n_max = max(n_left, n_right);
     v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
     const v2f px2 = {px, px}, py2 = {py, py};
@@ -142,7 +184,8 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
             bdst[12] = r.cr;
             bdst[14] = r.cg;
             bdst[16] = r.cb;
-            if (NEED_FIDX) bdst[18] = __int_as_float(k);
+            bdst[18] = __int_as_float((int)r.lim);
+            if (NEED_FIDX) bdst[20] = __int_as_float(k);
         }
         __builtin_amdgcn_wave_barrier();
 #if defined(GI2D_FWD_KNOCK) && GI2D_FWD_KNOCK == 2 /* development aid (wrong results): one trip per chunk */
@@ -150,35 +193,10 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
 #else
         const int m = min(GI2D_FWD_CHUNK, n_max - c0);
 #endif
-        for (int t = 0; t < m; t += 2) {
-            const float4 *q = reinterpret_cast<const float4 *>(mine + t * 10);
-#if defined(GI2D_FWD_KNOCK) && GI2D_FWD_KNOCK == 1 /* development aid (wrong results): 3 of the 5 LDS reads per trip */
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q1;
-            const v2f cb = {q0.x, q0.y};
-#else
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            const v2f cb = *reinterpret_cast<const v2f *>(q + 4);
-#endif
-            const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
-            const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
-            const v2f dx = gx - px2, dy = gy - py2;
-            const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
-            const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
-            const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
-            const v2f tt = op * vis;
-            const v2f alpha = {fminf(1.f, tt.x), fminf(1.f, tt.y)};
-            const bool ok0 = !(sig.x < 0.f || alpha.x < GI2D_ALPHA_MIN);  // forward.cu:541
-            const bool ok1 = !(sig.y < 0.f || alpha.y < GI2D_ALPHA_MIN);
-            const v2f am = {ok0 ? alpha.x : 0.f, ok1 ? alpha.y : 0.f};
-            a0 = __builtin_elementwise_fma(cr, am, a0);
-            a1 = __builtin_elementwise_fma(cg, am, a1);
-            a2 = __builtin_elementwise_fma(cb, am, a2);
-            if (NEED_FIDX) {  // entries ascend within a list: the last one that lands is the largest
-                const float2 ks = *reinterpret_cast<const float2 *>(mine + t * 10 + 18);
-                last = ok0 ? __float_as_int(ks.x) : last;
-                last = ok1 ? __float_as_int(ks.y) : last;
-            }
-        }
+        if (clamp_any)
+            fwd_trips<NEED_FIDX, true>(mine, m, px2, py2, a0, a1, a2, last);
+        else
+            fwd_trips<NEED_FIDX, false>(mine, m, px2, py2, a0, a1, a2, last);
         __builtin_amdgcn_wave_barrier();
     }
     o0 = a0.x + a0.y;
@@ -222,25 +240,25 @@ __device__ __forceinline__ void fwd_store_pixels(float *buf, float o0, float o1,
 // pair buffers.
 struct FwdLds {
     float4 AB[2 * (GI2D_TILE_LIST_CAP + 1)];  // [k]: (gx, gy, ha, hb), (hc, opac, cr, cg)
-    float C[GI2D_TILE_LIST_CAP + 4];          // cb
+    float2 C[GI2D_TILE_LIST_CAP + 2];         // cb, lim (AlphaRule)
     unsigned cullw[GI2D_TILE_LIST_CAP];       // cull_word() of the entry
     unsigned char lists[4][2 * GI2D_FWD_LISTLEN];
-    float4 pairbuf[GI2D_FWD_PAIRBUF];         // 4 waves x GI2D_FWD_PAIRBUF floats
+    float4 pairbuf[GI2D_FWD_PAIRBUF_OF(true)];  // 4 waves x GI2D_FWD_PAIRBUF_OF(true) floats
 };
 
 // phase 1 helper: lane `k` publishes its gaussian (list position k of the tile)
-__device__ __forceinline__ void fwd_stage_entry(FwdLds &sm, int k, const GaussRec &r, unsigned cull) {
+__device__ __forceinline__ void fwd_stage_entry(FwdLds &sm, int k, const GaussRec &r, unsigned cull, unsigned lim) {
     const ConicS s = scale_conic(r.a, r.b, r.c);
     sm.AB[2 * k] = make_float4(r.gx, r.gy, s.ha, s.hb);
     sm.AB[2 * k + 1] = make_float4(s.hc, r.opac, r.cr, r.cg);
-    sm.C[k] = r.cb;
+    sm.C[k] = make_float2(r.cb, __int_as_float((int)lim));
     sm.cullw[k] = cull;
 }
 __device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
-    // padding entry: opacity 0 -> alpha = 0 < 1/255, never contributes
+    // padding entry: opacity 0 and lim 0 -> never lands
     sm.AB[2 * GI2D_FWD_DUMMY] = make_float4(0.f, 0.f, 0.f, 0.f);
     sm.AB[2 * GI2D_FWD_DUMMY + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    sm.C[GI2D_FWD_DUMMY] = 0.f;
+    sm.C[GI2D_FWD_DUMMY] = make_float2(0.f, 0.f);
 }
 
 // phases 2-4 of the forward for one tile whose `len` (<= 256) entries are staged in ascending order.
@@ -257,7 +275,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
     const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
     const bool inside = (i < img_h) && (j < img_w);
-    float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF;
+    float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF_OF(NEED_FIDX);
     float o0, o1, o2;
     int last_k;
     fwd_pixel_half_lists<NEED_FIDX>(
@@ -266,7 +284,8 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
             const float4 A = sm.AB[2 * k], B = sm.AB[2 * k + 1];
             FwdRec r;
             r.gx = A.x, r.gy = A.y, r.ha = A.z, r.hb = A.w, r.hc = B.x, r.op = B.y, r.cr = B.z, r.cg = B.w;
-            r.cb = sm.C[k];
+            const float2 c = sm.C[k];
+            r.cb = c.x, r.lim = (unsigned)__float_as_int(c.y);
             return r;
         },
         (float)j, (float)i, o0, o1, o2, last_k);
@@ -332,17 +351,17 @@ struct BwdLds {
     float4 pix[2 * GI2D_BWD_PIXRECS];
     float4 gA[GI2D_TILE_LIST_CAP];  // gx, gy, ha, hb          (conic pre-scaled: scale_conic)
     float4 gB[GI2D_TILE_LIST_CAP];  // hc, opac, cr, cg
-    float gCb[GI2D_TILE_LIST_CAP];  // cb
+    float2 gC[GI2D_TILE_LIST_CAP];  // cb, lim (gi2d_common.h::AlphaRule)
     float4 gRaw[WITH_ABS ? GI2D_TILE_LIST_CAP : 1];  // a, b, c as given (the |v_xy| sums are per pixel: backward.cu:959)
     unsigned short span[GI2D_TILE_LIST_CAP];        // slot0 | n << 11: the gaussian's items are [slot0, slot0 + n)
     unsigned short item[8 * GI2D_TILE_LIST_CAP];    // k | j << 8: the item's gaussian and which of its row pairs
     static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
     float part[PART_ROWS * PSTR];
-    unsigned short xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | c0 << 8 | c1 << 12 per gaussian
+    unsigned xr[GI2D_TILE_LIST_CAP];  // r0 | r1 << 4 | c0 << 8 | c1 << 12 | clamp << 16 per gaussian
     int wsum[8];
     int n_items;
-    // rows / columns of gaussian k's box: bits 8..23 of its cull word
-    __device__ __forceinline__ void set_box(int k, unsigned cull) { xr[k] = (unsigned short)((cull >> 8) & 0xffffu); }
+    // rows / columns of gaussian k's box and its clamp flag: bits 8..24 of its cull word
+    __device__ __forceinline__ void set_box(int k, unsigned cull) { xr[k] = cull >> 8; }
     __device__ __forceinline__ unsigned box_of(int k) const { return xr[k]; }
 };
 
@@ -374,11 +393,11 @@ __device__ __forceinline__ void bwd_stage_pixels(Lds &sm, int tx, int ty, int im
 }
 
 template <class Lds>
-__device__ __forceinline__ void bwd_stage_entry(Lds &sm, int k, const GaussRec &r) {
+__device__ __forceinline__ void bwd_stage_entry(Lds &sm, int k, const GaussRec &r, unsigned lim) {
     const ConicS s = scale_conic(r.a, r.b, r.c);
     sm.gA[k] = make_float4(r.gx, r.gy, s.ha, s.hb);
     sm.gB[k] = make_float4(s.hc, r.opac, r.cr, r.cg);
-    sm.gCb[k] = r.cb;
+    sm.gC[k] = make_float2(r.cb, __int_as_float((int)lim));
     if constexpr (Lds::HAS_RAW) sm.gRaw[k] = make_float4(r.a, r.b, r.c, 0.f);
 }
 
@@ -445,6 +464,72 @@ __device__ __forceinline__ bool fidx_admits(int idx, float fidx_bits) {
     return !USE_FIDX || idx <= __float_as_int(fidx_bits);
 }
 
+// What one item accumulates, and the loop over its columns (CLAMP: min(1, .) can bind for some item of this wave, see
+// gi2d_common.h::AlphaRule).
+struct BwdItemAcc {
+    v2f S0, S1, S2, gr, gg, gb, ax, ay;
+};
+struct BwdItemIn {
+    float gx, px0;             // centre x, x coordinate of the first column
+    v2f dy, bdy, cdy2;         // the two rows of the pair
+    v2f ha2, opac2, cr2, cg2, cb2;
+    float4 raw;                // a, b, c as given (WITH_ABS)
+    unsigned lim;              // AlphaRule::lim
+    bool in_a, in_b;           // rows of the pair inside the box
+    int idx;                   // position in the sorted list (USE_FIDX)
+    const float4 *rec, *rec_end;
+};
+template <bool WITH_ABS, bool USE_FIDX, bool CLAMP>
+__device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc &o) {
+    const float4 *rec = in.rec;
+    // pixel x coordinates exactly as the forward forms them: (float)j (small integers: stepping by 1.0 stays exact)
+    float px = in.px0;
+#pragma unroll 1
+    for (;; rec += 2) {
+        const float4 P0 = rec[0];
+        float4 P1;
+        if (USE_FIDX) {
+            P1 = rec[1];
+        } else {
+            const float2 h = *reinterpret_cast<const float2 *>(rec + 1);
+            P1 = make_float4(h.x, h.y, 0.f, 0.f);
+        }
+        const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
+        const float dx1 = in.gx - px;
+        px += 1.f;
+        const v2f dx = {dx1, dx1};
+        // == pair_sigma() of the forward, the two rows of the pair per instruction
+        const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(in.ha2, dx, in.bdy), in.cdy2);
+        const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
+        const v2f t = in.opac2 * vis;
+        // backward.cu:903 (idx <= final_idx) and :922-926 (sigma < 0 || alpha < 1/255: the forward's pair test)
+        const bool ok0 = in.in_a && fidx_admits<USE_FIDX>(in.idx, P1.z) && pair_lands(sig.x, in.lim);
+        const bool ok1 = in.in_b && fidx_admits<USE_FIDX>(in.idx, P1.w) && pair_lands(sig.y, in.lim);
+        const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
+        v2f am = tz;
+        if (CLAMP) am = (v2f){fminf(1.f, tz.x), fminf(1.f, tz.y)};
+        // backward.cu:940-946
+        const v2f v_alpha =
+            __builtin_elementwise_fma(in.cb2, voz, __builtin_elementwise_fma(in.cg2, voy, in.cr2 * vox));
+        o.gr = __builtin_elementwise_fma(am, vox, o.gr);
+        o.gg = __builtin_elementwise_fma(am, voy, o.gg);
+        o.gb = __builtin_elementwise_fma(am, voz, o.gb);
+        const v2f w = tz * v_alpha;  // = -v_sigma (backward.cu:948), 0 when the pair is invalid
+        o.S0 += w;
+        const v2f wdx = w * dx;
+        o.S1 += wdx;
+        o.S2 = __builtin_elementwise_fma(wdx, dx, o.S2);
+        if (WITH_ABS) {  // backward.cu:959-960 (commented in the shipped kernel): sum |v_xy|
+            const v2f a2 = {in.raw.x, in.raw.x}, b2 = {in.raw.y, in.raw.y}, c2 = {in.raw.z, in.raw.z};
+            const v2f ux = w * __builtin_elementwise_fma(a2, dx, b2 * in.dy);
+            const v2f uy = w * __builtin_elementwise_fma(b2, dx, c2 * in.dy);
+            o.ax += __builtin_elementwise_abs(ux);
+            o.ay += __builtin_elementwise_abs(uy);
+        }
+        if (rec >= in.rec_end) break;
+    }
+}
+
 template <bool WITH_ABS, bool USE_FIDX = true, bool PRESCANNED = false, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
 __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, int list_base, float tx0, float ty0,
                                              float4 *__restrict__ dst, unsigned long long prescan_incl = 0ull,
@@ -509,10 +594,9 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         if (it < round1) {
 #endif
             const int code = sm.item[it], k = code & 255;
-            const unsigned xr = sm.box_of(k);  // r0 | r1 << 4 | c0 << 8 | c1 << 12
+            const unsigned xr = sm.box_of(k);  // r0 | r1 << 4 | c0 << 8 | c1 << 12 | clamp << 16
             const int r0 = (int)(xr & 15u), r1 = (int)((xr >> 4) & 15u);
             const int p = (r0 >> 1) + (code >> 8);               // items of k: its row pairs in order
-            const bool in_a = 2 * p >= r0, in_b = 2 * p + 1 <= r1;  // a box may start on row B / end on row A of a pair
             const int c_lo = (int)((xr >> 8) & 15u);
 #if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 1 /* development aid (wrong results): one trip per item */
             const int c_hi = c_lo;
@@ -520,69 +604,35 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             const int c_hi = (int)((xr >> 12) & 15u);
 #endif
             const float4 A = sm.gA[k], B = sm.gB[k];
-            const float cb = sm.gCb[k];
-            const float gx = A.x, gy = A.y, opac = B.y;
+            const float2 C = sm.gC[k];
+            BwdItemIn in;
+            in.in_a = 2 * p >= r0, in.in_b = 2 * p + 1 <= r1;  // a box may start on row B / end on row A of a pair
+            in.gx = A.x;
+            const float gy = A.y;
             ConicS s;
             s.ha = A.z, s.hb = A.w, s.hc = B.x;
             // row terms exactly as the forward forms them: dy = gy - (float)i, b*dy, c*dy*dy
             const float py_a = ty0 + (float)(2 * p);
-            const v2f dy = {gy - py_a, gy - (py_a + 1.f)};
-            const v2f bdy = {row_term_b(s, dy.x), row_term_b(s, dy.y)};
-            const v2f cdy2 = {row_term_c(s, dy.x), row_term_c(s, dy.y)};
-            const v2f ha2 = {s.ha, s.ha}, opac2 = {opac, opac};
-            const v2f cr2 = {B.z, B.z}, cg2 = {B.w, B.w}, cb2 = {cb, cb};
-            const int idx = list_base + k;
-            v2f S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
-            v2f gr = {0.f, 0.f}, gg = {0.f, 0.f}, gb = {0.f, 0.f}, ax = {0.f, 0.f}, ay = {0.f, 0.f};
-            float4 raw = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (WITH_ABS) raw = sm.gRaw[k];
-            const float4 *rec = &sm.pix[2 * (p * GI2D_TILE + c_lo)];
-            const float4 *rec_end = rec + 2 * (c_hi - c_lo);
-            // pixel x coordinates exactly as the forward forms them: (float)j (small integers: stepping by 1.0 stays exact)
-            float px = tx0 + (float)c_lo;
-#pragma unroll 1
-            for (;; rec += 2) {
-                const float4 P0 = rec[0];
-                float4 P1;
-                if (USE_FIDX) {
-                    P1 = rec[1];
-                } else {
-                    const float2 h = *reinterpret_cast<const float2 *>(rec + 1);
-                    P1 = make_float4(h.x, h.y, 0.f, 0.f);
-                }
-                const v2f vox = {P0.x, P0.y}, voy = {P0.z, P0.w}, voz = {P1.x, P1.y};
-                const float dx1 = gx - px;
-                px += 1.f;
-                const v2f dx = {dx1, dx1};
-                // == pair_sigma() of the forward, the two rows of the pair per instruction
-                const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha2, dx, bdy), cdy2);
-                const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
-                const v2f t = opac2 * vis;
-                // backward.cu:903 (idx <= final_idx) and :925 (alpha = min(1,t) < 1/255 <=> t < 1/255)
-                const bool ok0 = in_a && fidx_admits<USE_FIDX>(idx, P1.z) && !(sig.x < 0.f || t.x < GI2D_ALPHA_MIN);
-                const bool ok1 = in_b && fidx_admits<USE_FIDX>(idx, P1.w) && !(sig.y < 0.f || t.y < GI2D_ALPHA_MIN);
-                const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
-                const v2f am = {fminf(1.f, tz.x), fminf(1.f, tz.y)};
-                // backward.cu:940-946
-                const v2f v_alpha =
-                    __builtin_elementwise_fma(cb2, voz, __builtin_elementwise_fma(cg2, voy, cr2 * vox));
-                gr = __builtin_elementwise_fma(am, vox, gr);
-                gg = __builtin_elementwise_fma(am, voy, gg);
-                gb = __builtin_elementwise_fma(am, voz, gb);
-                const v2f w = tz * v_alpha;  // = -v_sigma (backward.cu:948), 0 when the pair is invalid
-                S0 += w;
-                const v2f wdx = w * dx;
-                S1 += wdx;
-                S2 = __builtin_elementwise_fma(wdx, dx, S2);
-                if (WITH_ABS) {  // backward.cu:959-960 (commented in the shipped kernel): sum |v_xy|
-                    const v2f a2 = {raw.x, raw.x}, b2 = {raw.y, raw.y}, c2 = {raw.z, raw.z};
-                    const v2f ux = w * __builtin_elementwise_fma(a2, dx, b2 * dy);
-                    const v2f uy = w * __builtin_elementwise_fma(b2, dx, c2 * dy);
-                    ax += __builtin_elementwise_abs(ux);
-                    ay += __builtin_elementwise_abs(uy);
-                }
-                if (rec >= rec_end) break;
-            }
+            in.dy = (v2f){gy - py_a, gy - (py_a + 1.f)};
+            in.bdy = (v2f){row_term_b(s, in.dy.x), row_term_b(s, in.dy.y)};
+            in.cdy2 = (v2f){row_term_c(s, in.dy.x), row_term_c(s, in.dy.y)};
+            in.ha2 = (v2f){s.ha, s.ha}, in.opac2 = (v2f){B.y, B.y};
+            in.cr2 = (v2f){B.z, B.z}, in.cg2 = (v2f){B.w, B.w}, in.cb2 = (v2f){C.x, C.x};
+            in.lim = (unsigned)__float_as_int(C.y);
+            in.idx = list_base + k;
+            in.raw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (WITH_ABS) in.raw = sm.gRaw[k];
+            in.rec = &sm.pix[2 * (p * GI2D_TILE + c_lo)];
+            in.rec_end = in.rec + 2 * (c_hi - c_lo);
+            in.px0 = tx0 + (float)c_lo;
+            const v2f zero2 = {0.f, 0.f};
+            BwdItemAcc o;
+            o.S0 = o.S1 = o.S2 = o.gr = o.gg = o.gb = o.ax = o.ay = zero2;
+            if (__ballot((xr >> 16) & 1u) != 0ull)  // wave-uniform
+                bwd_item_columns<WITH_ABS, USE_FIDX, true>(in, o);
+            else
+                bwd_item_columns<WITH_ABS, USE_FIDX, false>(in, o);
+            const v2f dy = in.dy, S0 = o.S0, S1 = o.S1, S2 = o.S2, gr = o.gr, gg = o.gg, gb = o.gb, ax = o.ax, ay = o.ay;
             // the item's moments (see the head of this section)
             const float u0a = dy.x * S0.x, u0b = dy.y * S0.y;
             res[0] = S1.x + S1.y;                              // T1 = sum w dx
