@@ -218,9 +218,11 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 template <int MODE>
 __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(TilePassArgs a) {
     __shared__ FusedLds sm;
+    int tile;
+    const HeadRow hr = head_row_for(a.lists, a.tile_order, (int)blockIdx.x, tile);
     const float4 *recs = recs_for_tile_pass(a.rs, blockIdx.x == 0 && threadIdx.x == 0);
-    fused_tile<MODE>(sm, a.tile_order[blockIdx.x], a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins,
-                     a.partial_g, a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse);
+    fused_tile<MODE>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins,
+                     a.partial_g, a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);
 }
 
 // The same pass over the tiles of K images in ONE launch (gi2d_batch.h): workgroup b belongs to image k with
@@ -256,10 +258,11 @@ __global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kerne
     k = __builtin_amdgcn_readfirstlane(k);
     local = __builtin_amdgcn_readfirstlane(local);
     const TilePassArgs &a = imgs[k].t;
+    int tile;
+    const HeadRow hr = head_row_for(a.lists, a.tile_order, local, tile);
     const float4 *recs = recs_for_tile_pass(a.rs, local == 0 && threadIdx.x == 0);
-    const int tile = __builtin_amdgcn_readfirstlane(a.tile_order[local]);
     fused_tile<MODE>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
-                     a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse);
+                     a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);
 }
 
 // --------------------------------------------------------------------------------------- reduce

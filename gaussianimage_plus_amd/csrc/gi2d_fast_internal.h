@@ -386,15 +386,38 @@ __device__ __forceinline__ float4 *partial_row(int slot, float4 *__restrict__ pa
 // otherwise (tile-uniform, known after the barrier) everything is emitted again at its true rank.  `emit` must then be idempotent LDS staging for rank < GI2D_TILE_LIST_CAP (entries past the cap are only
 // ever emitted once, at the end).  With OPTIMISTIC the staging is complete and visible to the whole workgroup on
 // return (the usual case costs ONE barrier in all); otherwise the caller's barrier after the call closes it.
+// The first round of loads of a tile's row (header + this lane's first id), separable from the rest so that a caller
+// whose tile index is itself the result of a load (the tile order of the single-pass kernel) can request the row of the
+// tile it EXPECTS -- the identity order of an evenly populated scene -- in the same round as that index, and only
+// re-request on a miss (head_row_for): one dependent memory round trip less at the top of every tile.
+struct HeadRow {
+    int hdr_count, hdr_sorted, id0;
+};
+__device__ __forceinline__ HeadRow head_row_load(const int32_t *__restrict__ lists, int tile) {
+    const int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
+    HeadRow h;
+    h.hdr_count = row[0], h.hdr_sorted = row[1], h.id0 = row[GI2D_FAST_HDR + threadIdx.x];
+    return h;
+}
+// `order[slot]` is the tile this workgroup handles; the row of tile `slot` is requested alongside.
+__device__ __forceinline__ HeadRow head_row_for(const int32_t *__restrict__ lists, const int32_t *__restrict__ order,
+                                                int slot, int &tile) {
+    HeadRow h = head_row_load(lists, slot);
+    tile = __builtin_amdgcn_readfirstlane(order[slot]);
+    if (tile != slot) h = head_row_load(lists, tile);  // workgroup-uniform
+    return h;
+}
 template <bool OPTIMISTIC, class Emit>
 __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty,
                                               const float4 *__restrict__ recs, int32_t *__restrict__ lists,
-                                              int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Emit emit) {
+                                              int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Emit emit,
+                                              const HeadRow *pre = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
-    const int hdr_count_v = row[0], hdr_sorted_v = row[1];
+    const HeadRow hr = pre ? *pre : head_row_load(lists, tile);
+    const int hdr_count_v = hr.hdr_count, hdr_sorted_v = hr.hdr_sorted;
     int my_id[GI2D_FAST_EPT];
-    my_id[0] = row[GI2D_FAST_HDR + tid];
+    my_id[0] = hr.id0;
     // the header is the same for the whole workgroup: say so (vector loads leave it, and everything derived from it --
     // count, sorted length, rounds -- in vector registers; the single-pass tile kernel sits at its 80-register budget)
     const int hdr_count = __builtin_amdgcn_readfirstlane(hdr_count_v);
@@ -451,47 +474,57 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
     // the first entry's record is kept in registers; entries past 256 (rare) fetch theirs again when they are staged
     BinRec r0;
     bool keep[GI2D_FAST_EPT];
-    keep[0] = false;
+    int pos[GI2D_FAST_EPT];
+#pragma unroll
+    for (int u = 0; u < GI2D_FAST_EPT; ++u) keep[u] = false, pos[u] = 0;
+#pragma unroll
+    for (int u = 1; u < GI2D_FAST_EPT; ++u) my_id[u] = -1;
     const auto member = [&](int2 box) {
         int mnx, mny, mxx, mxy;
         unpack_box(box, mnx, mny, mxx, mxy);
         return tx >= mnx && tx < mxx && ty >= mny && ty < mxy;  // the empty box 0/0 contains no tile
     };
-    if (my_id[0] >= 0) {
-        r0 = load_record(recs, my_id[0]);
-        keep[0] = member(r0.box);
-    }
     const int rounds = (count + 255) >> 8;  // tile-uniform
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    if ((wv_s << 6) >= count) {
+        // a wave whose 64 slots lie past the row's end (two of four at 72 candidates per tile) has no entry to load,
+        // test, count or stage: it reports empty groups and waits
+        if (lane == 0) {
 #pragma unroll
-    for (int u = 1; u < GI2D_FAST_EPT; ++u) {
-        keep[u] = false;
-        my_id[u] = -1;
-        if (u < rounds) {
-            const int e = tid + 256 * u;
-            if (e < count) {
-                my_id[u] = row[GI2D_FAST_HDR + e];
-                const float4 *p = recs + 4 * (size_t)my_id[u];
-                keep[u] = member(make_int2(__float_as_int(p[2].w), __float_as_int(p[3].x)));
+            for (int u = 0; u < GI2D_FAST_EPT; ++u) grp[wv + 4 * u] = 0, grp[16 + wv + 4 * u] = 0;
+        }
+    } else {
+        if (my_id[0] >= 0) {
+            r0 = load_record(recs, my_id[0]);
+            keep[0] = member(r0.box);
+        }
+#pragma unroll
+        for (int u = 1; u < GI2D_FAST_EPT; ++u) {
+            if (u < rounds) {
+                const int e = tid + 256 * u;
+                if (e < count) {
+                    my_id[u] = row[GI2D_FAST_HDR + e];
+                    const float4 *p = recs + 4 * (size_t)my_id[u];
+                    keep[u] = member(make_int2(__float_as_int(p[2].w), __float_as_int(p[3].x)));
+                }
             }
         }
-    }
-    GI2D_HEAD_TRACE(12);
-    int pos[GI2D_FAST_EPT];
+        GI2D_HEAD_TRACE(12);
 #pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        pos[u] = 0;
-        if (u < rounds) {
-            const int e = tid + 256 * u;
-            if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
-            const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
-            pos[u] = __popcll(kp & lanemask_lt());
-            if (lane == 0) {
-                grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
-                grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
+        for (int u = 0; u < GI2D_FAST_EPT; ++u) {
+            if (u < rounds) {
+                const int e = tid + 256 * u;
+                if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
+                const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
+                pos[u] = __popcll(kp & lanemask_lt());
+                if (lane == 0) {
+                    grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
+                    grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
+                }
+            } else if (lane == 0) {
+                grp[wv + 4 * u] = 0;
+                grp[16 + wv + 4 * u] = 0;
             }
-        } else if (lane == 0) {
-            grp[wv + 4 * u] = 0;
-            grp[16 + wv + 4 * u] = 0;
         }
     }
     if (OPTIMISTIC && keep[0] && tid < sorted) emit(tid, my_id[0], r0);  // tid < 256 = GI2D_TILE_LIST_CAP

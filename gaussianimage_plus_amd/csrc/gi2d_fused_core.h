@@ -104,7 +104,8 @@ __device__ __forceinline__ void fused_tile(
     FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
     int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
     float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
-    float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse) {
+    float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse,
+    const HeadRow &head_row) {
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int pool_rows = tiles_x * tiles_y * GI2D_TILE_LIST_CAP;  // rows of `partial_big`, the row pool (PrevBox)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -149,7 +150,7 @@ __device__ __forceinline__ void fused_tile(
                 row[1] = z;
                 row[2] = z;
             }
-        });
+        }, &head_row);
     GI2D_TRACE(2);
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 1 /* development aid: instruction / time budget of the phases */
     if (L >= 0) return;

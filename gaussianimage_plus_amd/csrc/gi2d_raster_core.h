@@ -212,7 +212,13 @@ __device__ __forceinline__ void fwd_store_pixels(float *buf, float o0, float o1,
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
-    const bool full_tile = (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
+#ifndef GI2D_FWD_STORE_TRANSPOSED /* development aid: the round-1..3 form, 16-byte stores of whole rows through LDS */
+#define GI2D_FWD_STORE_TRANSPOSED 0
+#endif
+    // One 12-byte store per lane: the 16 lanes of a pixel row write 192 contiguous bytes = three whole 64-byte lines
+    // in one instruction, which is as good for the memory system as the 16-byte stores of the transposed form and
+    // costs a third of its instructions (3 LDS writes, a read, two integer divisions).
+    const bool full_tile = GI2D_FWD_STORE_TRANSPOSED && (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
     if (full_tile) {
         const int r = lane >> 4;
         buf[r * 48 + lx * 3 + 0] = o0;
