@@ -67,6 +67,7 @@ def parse(argv=None):
                    help="images/sec leg on Kodak-shaped synthetic pictures instead of the Kodak fixture")
     p.add_argument("--no-batched", action="store_true", help="skip the `batched` block")
     p.add_argument("--no-static", action="store_true", help="skip the `static_scene_step` block")
+    p.add_argument("--no-dropin", action="store_true", help="skip the `dropin_autograd_step` block")
     p.add_argument("--images-per-gpu-probe", action="store_true",
                    help="also report the aggregate step rate of 2, 3 and 4 independent images stepped concurrently on "
                         "separate HIP streams of this GPU (extra information, not `value`)")
@@ -231,6 +232,8 @@ def run_rank(args):
         }
         if not args.no_static:
             line["static_scene_step"] = static_scene_rate(xyz, L, col, op, gt, n, h, w, dev)
+        if not args.no_dropin:
+            line["dropin_autograd_step"] = dropin_autograd_rate(gt, n)
         if not args.no_batched:
             line["batched"] = batched_rate(n, h, w, dev)
         if images is not None:
@@ -293,6 +296,28 @@ def static_scene_rate(xyz, L, col, op, gt, n, h, w, dev, steps=200):
     hp.check_status()
     return {"steps_per_s": 1e6 / us, "us_per_step": us, "num_intersects": hp.num_intersects(),
             "what": "frozen parameters: no appends to the tile lists, no optimizer (the round-1/2 headline loop)"}
+
+
+def dropin_autograd_rate(gt, n, iters=200, reps=5):
+    """The path a user of the reference runs: the loop of models/gaussianimage_cholesky.py:302-317 (tanh / +bound,
+    project_gaussians_2d, rasterize, L2 loss, loss.backward(), torch.optim.Adam, StepLR) through the drop-in `gsplat`
+    autograd wrappers, as launch.fit_image issues it -- PyTorch's own dispatcher, autograd engine and optimizer included.
+    Median of `reps` fits of `iters` iterations after one warm-up fit."""
+    from gaussianimage_plus_amd import launch
+    from gaussianimage_plus_amd.gsplat import cuda as table, _raster_common
+    launch.fit_image(gt, n, 300, eval_renders=1)  # warm-up: code objects, the caching allocator, the workspace pool
+    runs = sorted(launch.fit_image(gt, n, iters, eval_renders=1)["train_s"] / iters * 1e6 for _ in range(reps))
+    us = runs[len(runs) // 2]
+    return {"us_per_iteration": us, "iters_per_s": 1e6 / us, "us_per_iteration_min_max": [runs[0], runs[-1]], "num_points": n, "iterations": iters, "repeats": reps,
+            "binding": table.BINDING, "status_check": "every forward" if _raster_common.SYNC_EVERY_FORWARD else
+            "one call late (synchronous on a workspace's first use and above half the tile-row capacity)",
+            "loop": "launch.fit_image: tanh, +bound, project_gaussians_2d, rasterize_gaussians_plus, clamp, mse_loss, "
+                    "loss.backward(), torch.optim.Adam.step(), zero_grad, StepLR.step() -- 4 native calls per iteration "
+                    "(project fwd, bin + rasterize fwd, rasterize bwd tiles + reduce, project bwd), the rest is PyTorch: "
+                    "the loop is HOST-bound (profiles/round4_dropin_profile_after.txt: autograd engine, torch.optim.Adam's "
+                    "foreach kernels, mse_loss / tanh / clamp dispatch = three quarters of an iteration)",
+            "first_measurement_round4": {"us_per_iteration": 473.2, "binding": "ctypes", "status_check": "every forward",
+                                         "source": "profiles/round4_dropin_profile_before.txt"}}
 
 
 def batched_rate(n, h, w, dev, ks=(4, 8, 24), iters=60):

@@ -254,7 +254,7 @@ struct BinTarget {
 };
 
 // First thing of every binning kernel (lane of gaussian 0): reset the per-call status words (status[2] is the sticky
-// copy of the overflow flag).
+// copy of the overflow flag; status[3] the fullest tile row above half the capacity the following tile pass sees).
 __device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ status) {
     if (g == 0) {
         status[0] = 0;
@@ -469,6 +469,9 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         atomicOr(&status[1], 1);
         atomicOr(&status[2], 1);
     }
+    // high-water mark for callers that read the status one call late (the autograd wrappers): as long as no row was
+    // more than half full, an overflow cannot be one slowly moving step away
+    if (tid == 0 && hdr_count > GI2D_FAST_C / 2) atomicMax(&status[3], hdr_count);
     if (tid >= count) my_id[0] = -1;
     GI2D_HEAD_TRACE(11);
     // the first entry's record is kept in registers; entries past 256 (rare) fetch theirs again when they are staged

@@ -5,17 +5,27 @@ the forward) -> map -> torch.sort -> gather -> bin edges -> rasterize.  Here one
 on a pooled workspace of the fused fast path (csrc/gi2d_fast.hip):
     gi2d_fast_bin (binning step on the workspace's persistent tile lists)  ->  gi2d_fast_rasterize_forward
 and one backward is gi2d_fast_rasterize_backward_tiles + _reduce on the same workspace: no float atomics,
-bitwise reproducible.  Eight bytes of status are read back AFTER everything is enqueued (the GPU never
-waits for the host): "no intersection at all" gives the background image (rasterize_sum_plus.py:110-118),
-and a tile row overflow (more than 1024 candidates in one tile) re-runs the forward on
-the capacity-free ops (gi2d_bin_gaussians + plain rasterizer), so results are always exact."""
+bitwise reproducible.  "No intersection at all" gives the background image (rasterize_sum_plus.py:110-118) on the
+device.  A tile row overflow (more than 1024 candidates in one tile) re-runs the forward on the capacity-free ops
+(gi2d_bin_gaussians + plain rasterizer), so results are exact -- but the host does not wait for the status words of
+every forward (rounds 1-3 did: one drain of the GPU queue per training iteration, the stall SURVEY 8f-1 exists to
+remove).  A workspace is checked synchronously on its first use and whenever the fullest tile row of its last checked
+pass was above half the row capacity; otherwise the 16 status bytes travel to pinned memory behind the kernels and are
+read when the host next touches the workspace (the backward, or the next forward): by then they have arrived, and the
+GPU never idles.  An overflow found that way -- a row going from <= 512 to > 1024 candidates between two consecutive
+calls -- raises (see _settle); GI2D_WRAPPER_SYNC=1 restores the synchronous check."""
 from __future__ import annotations
+
+import os
 
 import torch
 
 from . import cuda as _C
 
 BLOCK = 16
+# GI2D_WRAPPER_SYNC=1: wait for the status words of every forward before its image is handed on (the behaviour of
+# rounds 1-3: one GPU queue drain per iteration).  Default: see FastWorkspace.must_check_now / _settle.
+SYNC_EVERY_FORWARD = os.environ.get("GI2D_WRAPPER_SYNC", "0") == "1"
 _capacity = {}   # exact path: (device index, N, H, W) -> intersection capacity
 _pool = {}       # fast path: (device index, N, tiles_x, tiles_y) -> idle FastWorkspace objects
 
@@ -42,6 +52,22 @@ def _acquire(xys, num_points, tile_bounds) -> _Lease:
     free = _pool.setdefault(key, [])
     ws = free.pop() if free else _C.FastWorkspace(num_points, tile_bounds, xys)
     return _Lease(key, ws)
+
+
+def _settle(ws, what: str) -> None:
+    """Look at the status words of the last forward on `ws` that has not been checked yet.  A tile row that overflowed
+    there (more than 1024 candidate gaussians in one 16x16 tile, on a workspace whose fullest row was at most half that
+    one call earlier) means an image has already been handed on that was rendered from a truncated tile list: the
+    workspace is emptied, every later call on it is checked before its result is used -- and falls back to the
+    capacity-free ops -- and the caller is told."""
+    st = ws.settle()
+    if st is not None and st[1]:
+        ws.reset()
+        raise RuntimeError(
+            f"gsplat drop-in: a tile row overflowed (> {_C.fast_tile_capacity()} candidate gaussians in one tile) in {what}, "
+            "whose status was read one call late; that call's image was rendered from a truncated tile list. The "
+            "workspace has been emptied and checks every call from now on (exact fallback). Re-run the step, or set "
+            "GI2D_WRAPPER_SYNC=1 to check every forward before its result is used.")
 
 
 def _exact_forward(plus, xys, radii, conics, colors, opacity, img_height, img_width, tile_bounds, block, img_size,
@@ -75,25 +101,31 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
     radii = radii if radii.dtype == torch.int32 else radii.to(torch.int32)
 
     lease = _acquire(xys, num_points, tile_bounds)
-    out_img = _C.fast_forward(lease.ws, xys, radii, conics, colors, opacity, img_height, img_width, radius_clip)
-    any_hit, overflow = lease.ws.status[:2].tolist()  # after everything is enqueued
+    ws = lease.ws
+    _settle(ws, "the previous forward on this workspace")
+    # "not a single intersection -> background image" (rasterize_sum_plus.py:110-118) is decided on the device
+    out_img = _C.fast_forward(ws, xys, radii, conics, colors, opacity, img_height, img_width, radius_clip,
+                              background=background)
     ctx.exact = None
-    if overflow:
-        lease.ws.reset()  # the overflowing row lost entries: its workspace starts from empty lists next time
-        out_img, final_idx, gids, bins, m = _exact_forward(plus, xys, radii, conics, colors, opacity, img_height,
-                                                           img_width, tile_bounds, block, img_size, background,
-                                                           radius_clip, isprint)
-        ctx.exact = (gids, bins, final_idx)
-        any_hit = m > 0
-        lease = None
-    elif not any_hit:
-        out_img = torch.ones(img_height, img_width, colors.shape[-1], device=xys.device) * background
-    final_Ts = torch.ones(img_height, img_width, device=xys.device)
+    if SYNC_EVERY_FORWARD or ws.must_check_now:
+        _, overflow = ws.read_now()
+        if overflow:
+            ws.reset()  # the overflowing row lost entries: its workspace starts from empty lists next time
+            out_img, final_idx, gids, bins, m = _exact_forward(plus, xys, radii, conics, colors, opacity, img_height,
+                                                               img_width, tile_bounds, block, img_size, background,
+                                                               radius_clip, isprint)
+            if m < 1:  # no intersection at all: the exact ops wrote the background; nothing to differentiate
+                gids = None
+            ctx.exact = (gids, bins, final_idx)
+            lease = None
+    else:
+        ws.post()  # looked at when the host next needs this workspace (the backward, or the next forward)
+    # rasterize_sum.py returns these; the plus wrapper drops them (final_T is never updated: forward.cu:558)
+    final_Ts = None if plus else torch.ones(img_height, img_width, device=xys.device)
     cnt_gs_counts = None if plus else torch.zeros(img_height, img_width, dtype=torch.int32, device=xys.device)
 
     ctx.img_width, ctx.img_height = img_width, img_height
     ctx.BLOCK_H, ctx.BLOCK_W = BLOCK_H, BLOCK_W
-    ctx.num_intersects = 1 if any_hit else 0
     ctx.radius_clip = float(radius_clip)
     ctx.lease = lease
     ctx.save_for_backward(xys, radii, conics, colors, opacity)
@@ -102,17 +134,19 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
 
 def backward_impl(ctx, plus: bool, v_out_img):
     xys, radii, conics, colors, opacity = ctx.saved_tensors
-    if ctx.num_intersects == 0:  # rasterize_sum_plus.py:198-202
-        v_abs = None if plus else torch.zeros(xys.size(0), 4, device=xys.device)
-        return (torch.zeros_like(xys), torch.zeros_like(conics), torch.zeros_like(colors),
-                torch.zeros_like(opacity), v_abs)
     v_out_img = v_out_img.contiguous()
     if ctx.exact is not None:
         gids, bins, final_idx = ctx.exact
+        if gids is None:  # rasterize_sum_plus.py:198-202: no intersection, zero gradients
+            v_abs = None if plus else torch.zeros(xys.size(0), 4, device=xys.device)
+            return (torch.zeros_like(xys), torch.zeros_like(conics), torch.zeros_like(colors),
+                    torch.zeros_like(opacity), v_abs)
         v_xy, v_conic, v_colors, v_opacity, v_abs = _C.rasterize_backward_fast(
             ctx.img_height, ctx.img_width, gids, bins, xys, radii, conics, colors, opacity, final_idx, v_out_img,
             ctx.radius_clip, with_abs=not plus)
     else:
+        _settle(ctx.lease.ws, "this backward's forward")
+        # without a single intersection the tile pass finds empty rows and the per-gaussian sums are zeros
         v_xy, v_conic, v_colors, v_opacity, v_abs = _C.fast_backward(
             ctx.lease.ws, xys, radii, v_out_img, ctx.img_height, ctx.img_width, ctx.radius_clip, with_abs=not plus)
     return v_xy, v_conic, v_colors, v_opacity.view_as(opacity), v_abs

@@ -12,11 +12,26 @@ cnt_gs_counts, bindings.cu:506-508) and rasterize_sum_backward returns 5 (with v
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ... import _lib
 
 _TILE = 16
+
+# The compiled op table (csrc/torch_ext/gi2d_torch_ext.cpp, built by __graft_entry__.build(): the pybind module of
+# ext.cpp:16-66 over the same C ABI).  The ctypes functions below are the fallback OF THE BINDING -- no C++ compiler at
+# hand, GI2D_BINDING=ctypes, or a development variant of the library selected with GI2D_LIB (the compiled module is
+# linked against the product library) -- never of the kernels.
+_ext = None
+if os.environ.get("GI2D_BINDING", "compiled") != "ctypes" and not os.environ.get("GI2D_LIB"):
+    try:
+        _lib.load()  # torch's HIP runtime and the (checked) product library first
+        from ... import _gi2d_torch as _ext
+    except ImportError:
+        _ext = None
+BINDING = "compiled" if _ext is not None else "ctypes"
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -259,28 +274,84 @@ def rasterize_backward_fast(img_height, img_width, gaussian_ids_sorted, tile_bin
 
 
 # ------------------------------------------------------------------------------- fused fast path
+def fast_tile_capacity() -> int:
+    """Candidate gaussians a tile row of the fused fast path holds (include/gi2d.h gi2d_fast_tile_capacity)."""
+    return int(_lib.load().gi2d_fast_tile_capacity())
+
+
 class FastWorkspace:
     """A workspace of the fused fast path (include/gi2d.h "fused fast path"): allocated and initialised once,
-    then reused by every forward/backward pair of the same problem shape."""
+    then reused by every forward/backward pair of the same problem shape.
+
+    status (device int32[4]) = {any intersection, overflow of this pass, sticky overflow, fullest tile row seen above
+    half the row capacity}.  The autograd wrappers do not wait for it on every forward (that would drain the GPU queue
+    once per iteration): `post()` starts an asynchronous copy into pinned host memory behind the kernels just enqueued,
+    `settle()` -- at the next forward or backward that uses the workspace -- reads what has arrived by then."""
 
     def __init__(self, num_points, tile_bounds, like):
         self.n, self.tx, self.ty = int(num_points), int(tile_bounds[0]), int(tile_bounds[1])
         nbytes = _lib.load().gi2d_fast_workspace_bytes(self.n, self.tx, self.ty)
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=like.device)
         self.status = torch.zeros(4, dtype=torch.int32, device=like.device)
+        self.host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._event = torch.cuda.Event()
+        self.event = None        # self._event once it is recorded behind the status copy of an unchecked forward
+        self.fullest = None      # fullest tile row the last CHECKED pass saw (0: at most half the capacity); None: unknown
         self.reset(like)
 
     def reset(self, like=None):
         """Empty tile lists: at creation, and after an overflow (its lost entries leave lists and boxes inconsistent)."""
         t = self.buf if like is None else like
         with torch.cuda.device(t.device):
-            _lib.call("gi2d_fast_workspace_init", self.buf.data_ptr(), self.buf.numel(), self.n, self.tx, self.ty,
-                      _stream(t))
+            if _ext is not None:
+                _ext.fast_workspace_init(self.buf, self.n, self.tx, self.ty)
+            else:
+                _lib.call("gi2d_fast_workspace_init", self.buf.data_ptr(), self.buf.numel(), self.n, self.tx, self.ty,
+                          _stream(t))
+        self.event, self.fullest = None, None
+
+    def post(self):
+        """Asynchronous copy of the status words behind everything enqueued so far on the current stream."""
+        with torch.cuda.device(self.buf.device):
+            self.host.copy_(self.status, non_blocking=True)
+            self._event.record()
+            self.event = self._event
+
+    def settle(self):
+        """(any_hit, overflow) of the last forward whose status has not been looked at yet, or None if there is none.
+        Waits for the copy only if it has not landed yet (by the time the host comes back -- at the backward, or at the
+        next iteration's forward -- it has)."""
+        if self.event is None:
+            return None
+        self.event.synchronize()
+        self.event = None
+        any_hit, overflow, _, fullest = self.host.tolist()
+        self.fullest = fullest
+        return any_hit, overflow
+
+    def read_now(self):
+        """Blocking read of the status of the pass just enqueued."""
+        any_hit, overflow, _, fullest = self.status.tolist()
+        self.event, self.fullest = None, fullest
+        return any_hit, overflow
+
+    @property
+    def must_check_now(self) -> bool:
+        """A pass on a workspace whose fullest tile row is unknown (first use, or after a reset) or was above half the
+        row capacity is checked before its result is handed on; otherwise the check trails by one call."""
+        return self.fullest is None or self.fullest > 0
 
 
-def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_width, radius_clip):
+def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_width, radius_clip, background=None):
     """gi2d_fast_bin (binning step + records on the workspace's persistent lists) + gi2d_fast_rasterize_forward
-    -> out_img[H,W,3]; ws.status = {any intersection, overflow}."""
+    -> out_img[H,W,3]; ws.status = {any intersection, overflow, sticky overflow, fullest row above half capacity}.
+    With `background` the device itself writes the background image when not a single gaussian lands
+    (rasterize_sum_plus.py:110-118)."""
+    if _ext is not None:
+        return _ext.fast_forward(ws.buf, ws.status, ws.n, ws.tx, ws.ty, xys, radii, conics, colors, opacities,
+                                 int(img_height), int(img_width), float(radius_clip), background)
+    if background is not None:
+        _chk(background, "background", torch.float32)
     for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (opacities, "opacities")):
         _chk(t, nm, torch.float32)
     _chk(radii, "radii", torch.int32)
@@ -291,14 +362,16 @@ def fast_forward(ws, xys, radii, conics, colors, opacities, img_height, img_widt
         _lib.call("gi2d_fast_bin", ws.n, xys.data_ptr(), radii.data_ptr(), conics.data_ptr(), colors.data_ptr(),
                   opacities.data_ptr(), ws.tx, ws.ty, float(radius_clip), ws.buf.data_ptr(), ws.buf.numel(),
                   ws.status.data_ptr(), st)
-        _lib.call("gi2d_fast_rasterize_forward", ws.n, ws.tx, ws.ty, w, h, None, ws.buf.data_ptr(), ws.buf.numel(),
-                  ws.status.data_ptr(), None, None, out_img.data_ptr(), st)
+        _lib.call("gi2d_fast_rasterize_forward", ws.n, ws.tx, ws.ty, w, h, _ptr(background), ws.buf.data_ptr(),
+                  ws.buf.numel(), ws.status.data_ptr(), None, None, out_img.data_ptr(), st)
     return out_img
 
 
 def fast_backward(ws, xys, radii, v_output, img_height, img_width, radius_clip, with_abs=False):
     """gi2d_fast_rasterize_backward_tiles + _reduce on the workspace the forward filled.
     -> (v_xy, v_conic, v_colors, v_opacity[N,1], v_abs_xys|None)"""
+    if _ext is not None:
+        return _ext.fast_backward(ws.buf, ws.n, ws.tx, ws.ty, v_output, int(img_height), int(img_width), bool(with_abs))
     _chk(xys, "xys", torch.float32)
     _chk(radii, "radii", torch.int32)
     _chk(v_output, "v_output", torch.float32)
@@ -422,3 +495,16 @@ for _n in ("nd_rasterize_forward", "nd_rasterize_backward", "nd_rasterize_sum_fo
            "rasterize_forward", "rasterize_backward", "project_gaussians_forward",
            "project_gaussians_backward", "compute_sh_forward", "compute_sh_backward"):
     globals()[_n] = _unsupported(_n)
+
+
+# ------------------------------------------------------------------------------- the compiled table takes over
+_COMPILED_NAMES = ("project_gaussians_2d_forward", "project_gaussians_2d_backward",
+                   "project_gaussians_2d_covariance_forward", "project_gaussians_2d_covariance_backward",
+                   "project_gaussians_2d_scale_rot_forward", "project_gaussians_2d_scale_rot_backward",
+                   "compute_cov2d_bounds", "compute_cov2d_bounds_xy", "map_gaussian_to_intersects", "get_tile_bin_edges",
+                   "rasterize_sum_forward", "rasterize_sum_backward", "rasterize_sum_plus_forward",
+                   "rasterize_sum_plus_backward")
+CTYPES_TABLE = {n: globals()[n] for n in _COMPILED_NAMES}  # kept reachable: tests hold the two bindings to each other
+if _ext is not None:
+    for _n in _COMPILED_NAMES:
+        globals()[_n] = getattr(_ext, _n)

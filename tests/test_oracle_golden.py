@@ -44,9 +44,32 @@ def test_call_shape_record(golden_dir):
     import inspect
     import gaussianimage_plus_amd.gsplat.cuda as C
     for name, kinds in ops.items():
-        sig = inspect.signature(getattr(C, name))
+        # the ctypes table (the binding's fallback) ...
+        sig = inspect.signature(C.CTYPES_TABLE.get(name, getattr(C, name)))
         positional = [p for p in sig.parameters.values() if p.default is inspect.Parameter.empty]
         assert len(positional) <= len(kinds) <= len(sig.parameters), name
+        # ... and the compiled table (csrc/torch_ext), whose signature pybind11 writes into the docstring
+        fn = getattr(C, name)
+        if C.BINDING == "compiled" and name in C.CTYPES_TABLE:
+            head = fn.__doc__.splitlines()[0]
+            args = head[head.index("(") + 1:head.rindex(") ->")]
+            params = [a for a in _split_top_level(args) if a.strip()]
+            required = [a for a in params if "=" not in a]
+            assert len(required) <= len(kinds) <= len(params), (name, head)
+
+
+def _split_top_level(text):
+    """Split a pybind11 signature's argument list at the commas that are not inside brackets."""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        depth += ch in "[(" 
+        depth -= ch in "])"
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    return out + [cur]
 
 
 def test_oracle_reproduces_golden_vectors(oracle, golden_dir):
