@@ -161,6 +161,7 @@ class TilePassTimers:
         return out
 
     def close(self) -> None:
+        self.cancel()  # a plan still armed with these handles must not outlive them
         for h in self.handles:
             load().gi2d_timer_destroy(h)
         self.handles = []

@@ -465,6 +465,13 @@ int gi2d_timer_destroy(void *timer) {
     KernelTimer *t = (KernelTimer *)timer;
     if (!t) return GI2D_OK;
     if (g_armed_timer == t) g_armed_timer = nullptr;
+    // a plan that still holds this timer must not hand its (about to be destroyed) events to a later launch
+    if (g_timer_plan.list)
+        for (int i = 0; i < g_timer_plan.count; ++i)
+            if (g_timer_plan.list[i] == t) {
+                g_timer_plan.list = nullptr;
+                break;
+            }
     (void)hipEventDestroy(t->begin);
     (void)hipEventDestroy(t->end);
     delete t;

@@ -55,6 +55,9 @@ namespace gi2d {
 typedef int4 PrevBox;
 #define GI2D_POOL_CURSOR 8 /* word of tile row 0's header (words 2..15 of a header are padding) */
 #define GI2D_NO_ROW ((int)0x80000000) /* partial-row code of an entry whose pool row lies past the pool's end */
+/* bits of the status words 1 (this pass) and 2 (sticky): 1 a tile row overflowed, 2 the log quantiser's parking list
+   (gi2d_train.hip), 4 the row pool ran out */
+#define GI2D_STATUS_POOL 4
 __host__ __device__ __forceinline__ PrevBox no_box() { return make_int4(0, 0, -1, 0); }
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // Workgroup size of the one-lane-per-gaussian kernels (project+fill, reduce+project backward, optimizer update):
@@ -170,8 +173,12 @@ __device__ __forceinline__ FillPending fill_diff_begin(int g, bool member, int m
     const int ntiles = member ? (mxx - mnx) * (mxy - mny) : 0;
     int cap = old.w;
     if (ntiles > GI2D_FAST_S && ntiles > cap) {  // its run of pool rows (see PrevBox): rare, and rarer still after the first time
-        f.pool = atomicAdd(&lists[GI2D_POOL_CURSOR], ntiles);
-        cap = ntiles;
+        // A run that has to grow grows by at least half: a gaussian swelling tile by tile (36, 42, 49, ... tiles: the
+        // large gaussians of a fixed-population fit, whose workspace is never emptied) would otherwise abandon a run per
+        // step -- the pool is a bump allocator, nothing is handed back before gi2d_fast_workspace_init -- and leak many
+        // times its live size; with geometric growth the abandoned runs sum to less than twice the live one.
+        cap = max(ntiles, cap + (cap >> 1));
+        f.pool = atomicAdd(&lists[GI2D_POOL_CURSOR], cap);
     }
     prev_box[g] = make_int4(nw.x, nw.y, f.pool, cap);
     if (!member) return f;  // its old entries are dropped by the tile pass (they fail the membership test)
@@ -356,9 +363,9 @@ __device__ __forceinline__ float4 *partial_row(int slot, float4 *__restrict__ pa
                                                int pool_rows, int32_t *__restrict__ status) {
     if (slot >= 0) return partial_g + GI2D_FAST_ROW * (size_t)slot;
     const int row = -slot - 1;
-    if (row < 0 || row >= pool_rows) {  // the pool ran out (PrevBox): as a tile row that overflowed
-        atomicOr(&status[1], 1);
-        atomicOr(&status[2], 1);
+    if (row < 0 || row >= pool_rows) {  // the pool ran out (PrevBox): the caller falls back as for a tile row that
+        atomicOr(&status[1], GI2D_STATUS_POOL);  // overflowed, but is told which of the two it was
+        atomicOr(&status[2], GI2D_STATUS_POOL);
         return nullptr;
     }
     return partial_big + GI2D_FAST_ROW * (size_t)row;

@@ -331,6 +331,8 @@ class HotPath:
             if self.mode == "fused":
                 self._reset_workspace()  # the overflowed rows lost entries: start over from empty lists
             what = "a tile row" if self.mode == "fused" else f"the intersection capacity {self.capacity}"
+            if self.mode == "fused" and (now | sticky) & 4:  # GI2D_STATUS_POOL (csrc/gi2d_fast_internal.h)
+                what = "the row pool (gradient rows of gaussians on more than 32 tiles)"
             raise RuntimeError(f"{what} overflowed (M={m}); results of the last step are invalid")
 
     def kernel_timers(self, steps: int):

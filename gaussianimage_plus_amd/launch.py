@@ -330,7 +330,8 @@ def main(argv=None):
     ap.add_argument("--grow_iter", type=int, default=5000)
     ap.add_argument("--images_per_gpu", type=int, default=1,
                     help="images fitted concurrently on each GPU (native loop): in lockstep with one launch per kernel for "
-                         "all of them, or, with --streams / --quantize, one HIP stream and one host thread each")
+                         "all of them (plain AND --quantize fits, as --batch_groups batches), or, with --streams, one HIP "
+                         "stream and one host thread each")
     ap.add_argument("--single_host_thread", action="store_true",
                     help="issue the concurrent images' launches round-robin from one host thread instead")
     ap.add_argument("--batch_groups", type=int, default=3,

@@ -315,6 +315,11 @@ class NativeFitter:
         if sticky & 2:
             raise RuntimeError("more variances tie with an extreme of the log-quantiser range than the parking list "
                                "holds; results invalid")
+        if (now | sticky) & 4:  # GI2D_STATUS_POOL (csrc/gi2d_fast_internal.h)
+            self._reset_bins()
+            raise RuntimeError("the row pool of the fused fast path ran out (gaussians on more than 32 tiles own runs of "
+                               "gradient rows from a bump allocator of tiles x 256 rows that is only emptied with the "
+                               "workspace); results invalid -- the workspace has been emptied, re-run the stretch")
         if now or sticky:
             self._reset_bins()
             raise RuntimeError("a tile row overflowed (> 1024 candidate gaussians in one tile); results invalid")
@@ -798,15 +803,24 @@ class BatchFitter:
     iteration count; image sizes and populations may differ."""
 
     def __init__(self, fitters):
-        assert 1 <= len(fitters) <= 64
+        if not 1 <= len(fitters) <= 64:
+            raise ValueError(f"a batch holds 1 .. 64 images, got {len(fitters)}")
         f0 = fitters[0]
-        for f in fitters:
-            assert (f.kind, f.optimizer, f.lr, f.betas, f.eps, f.lr_step, f.lr_gamma, f.iteration, f.opt_start) == \
-                   (f0.kind, f0.optimizer, f0.lr, f0.betas, f0.eps, f0.lr_step, f0.lr_gamma, f0.iteration, f0.opt_start)
-            assert f.dev == f0.dev and (f.quant is None) == (f0.quant is None)
+        # (ValueError, not assert: under `python -O` a mismatch would otherwise train every image with fitter 0's schedule)
+        for i, f in enumerate(fitters):
+            mine = (f.kind, f.optimizer, f.lr, f.betas, f.eps, f.lr_step, f.lr_gamma, f.iteration, f.opt_start)
+            first = (f0.kind, f0.optimizer, f0.lr, f0.betas, f0.eps, f0.lr_step, f0.lr_gamma, f0.iteration, f0.opt_start)
+            if mine != first:
+                raise ValueError(f"fitter {i} of a batch differs from fitter 0 in (kind, optimizer, lr, betas, eps, "
+                                 f"lr_step, lr_gamma, iteration, opt_start): {mine} != {first}")
+            if f.dev != f0.dev or (f.quant is None) != (f0.quant is None):
+                raise ValueError(f"fitter {i} of a batch is on another device or differs in quantisation-aware mode")
             if f.quant is not None:  # quantisation-aware batch: one quantiser configuration, one schedule
-                assert (f.q_bits, f.q_rot_bit, f.q_lr, f.q_lr_step, f.q_lr_gamma, f.quant_start) == \
-                       (f0.q_bits, f0.q_rot_bit, f0.q_lr, f0.q_lr_step, f0.q_lr_gamma, f0.quant_start)
+                mine = (f.q_bits, f.q_rot_bit, f.q_lr, f.q_lr_step, f.q_lr_gamma, f.quant_start)
+                first = (f0.q_bits, f0.q_rot_bit, f0.q_lr, f0.q_lr_step, f0.q_lr_gamma, f0.quant_start)
+                if mine != first:
+                    raise ValueError(f"fitter {i} of a batch differs from fitter 0 in its quantiser configuration "
+                                     f"(bits, rot bit, q_lr, q_lr_step, q_lr_gamma, quant_start): {mine} != {first}")
         self.fitters = list(fitters)
         self.lib, self.dev = f0.lib, f0.dev
         k = len(self.fitters)

@@ -223,7 +223,7 @@ def test_batched_entry_rejects_bad_batches():
     assert rc != 0 and b"share model kind" in lib.gi2d_last_error_string()
     rc = lib.gi2d_train_steps_batched(2, states, table.data_ptr(), 64, lr3, 0.9, 0.999, 1e-8, 1, 1, None)
     assert rc != 0 and b"batch table" in lib.gi2d_last_error_string()
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError, match="differs from fitter 0"):
         BatchFitter([a, b])
     # a table that is not 16-byte aligned, more than 64 images, no images
     c = _fitters("cholesky", "adam", [(64, 64, 150)])[0]

@@ -36,7 +36,13 @@ def test_bench_line_has_the_contract_fields():
     assert r["traffic"] is None  # the committed counters are for the default workload, not this one
     assert r["traffic_source"].startswith("none:")
     assert d["metric"].endswith("144x96")
-    assert r["kernel_samples"] == 3 and r["avg_kernel_us"] >= r["min_kernel_us"] > 0  # 24 steps, every 8th timed
+    # five timed regions of 24 steps each, every 2nd tile pass carries an event pair
+    assert d["repeats"] == 5 and len(d["ms_per_step_each_region"]) == 5
+    assert sorted(d["ms_per_step_each_region"])[2] == d["ms_per_step"]  # the median region
+    assert r["kernel_samples"] == 60 and r["avg_kernel_us"] >= r["min_kernel_us"] > 0
+    assert d["roofline_valu"]["source"].startswith("none:")  # counters are stored for the default workload only
+    dr = d["dropin_autograd_step"]
+    assert dr["us_per_iteration"] > 0 and dr["binding"] in ("compiled", "ctypes") and dr["num_points"] == 3000
     im = d["images_per_s"]
     assert im["unit"] == "images/s" and im["images"] == 2 and im["iterations_per_image"] == 200 and im["value"] > 0
     assert abs(im["value"] - im["images"] / im["wall_s"]) <= 1e-9 * im["value"]
@@ -44,6 +50,7 @@ def test_bench_line_has_the_contract_fields():
     assert [row["image"] for row in im["rank0_images"]] == ["kodim01", "kodim02"]
     assert all(10 < row["psnr"] < 60 and row["best_model_gaussians"] > 0 for row in im["rank0_images"])
     assert im["images_concurrent_per_gpu"] == 2 and im["batches_per_gpu"] == 2  # three asked for, two images to share
+    assert im["per_rank"] == [{"rank": 0, "images": 2, "batches": 2, "images_per_batch": [1, 1]}]
     st = d["static_scene_step"]
     assert st["steps_per_s"] > 0 and st["num_intersects"] > 0
     ks = d["batched"]["per_k"]
@@ -76,6 +83,7 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
     assert d["images_per_s"]["images"] == 2 and "rank i mod 2" in d["images_per_s"]["workload"]
+    assert [(r["rank"], r["images"], r["batches"]) for r in d["images_per_s"]["per_rank"]] == [(0, 1, 1), (1, 1, 1)]
 
 
 def test_launcher_cli_runs_both_loops_and_reports_the_average_line():

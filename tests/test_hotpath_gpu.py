@@ -445,7 +445,7 @@ def test_row_pool_overflow_is_flagged_and_step_safe_recovers():
         hp.set_v_out(v)
     fused.step(pipelined=False)
     assert int(fused.nth[:n_big].min()) == 64
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="row pool"):  # told apart from a tile row that overflowed
         fused.check_status()
     fused.step_safe()
     exact.step()
@@ -457,3 +457,31 @@ def test_row_pool_overflow_is_flagged_and_step_safe_recovers():
         hp.step(pipelined=False)
         hp.check_status()
     assert torch.equal(fused.out_img, exact.out_img) and torch.equal(fused.v_params, exact.v_params)
+
+
+def test_slowly_growing_gaussians_do_not_leak_the_row_pool():
+    """The pool is a bump allocator that is only emptied with the workspace (fixed-population fits never do that): a run
+    that has to grow is re-allocated with at least half as much again, so the runs a gaussian swelling tile by tile
+    leaves behind sum to at most 3 x its last capacity = 4.5 x its live rows (measured here: 5.8 x the peak of the live
+    sum over 40 steps, the peaks not being simultaneous); a new run per step -- the round-3 behaviour -- hands out
+    ~25 x, more than this pool holds, and ends in a fit whose gradient rows are dropped."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    n_big, n_small, h, w = 30, 500, 512, 768
+    xyz, L, col, op = _big_and_small(n_big, n_small, h, w, 33, sigma=(28.0, 34.0))
+    n = n_big + n_small
+    fused = HotPath(n, h, w, device=DEV, mode="fused")
+    fused.set_v_out(_v_out(h, w, 6))
+    steps, peak_live = 40, 0
+    for step in range(steps):
+        L[:n_big] *= np.float32(1.025)  # +2.5 % per step: the tile box gains a row or a column every few steps
+        fused.set_inputs(xyz, L, col, op)
+        fused.step(pipelined=False)
+        fused.check_status()
+        nth = fused.nth[:n_big]
+        peak_live = max(peak_live, int(nth[nth > 32].sum()))
+    cursor = int(fused.ws[:64].view(torch.int32)[8].item())   # GI2D_POOL_CURSOR: rows handed out since the last init
+    pool_rows = fused.T * 256
+    assert int((fused.nth[:n_big] > 32).sum()) >= 20 and peak_live > 3000, "the scene must exercise the pool"
+    print(f"row pool: {cursor} rows handed out over {steps} steps for {peak_live} live rows (pool {pool_rows})")
+    assert cursor <= 7 * peak_live, (cursor, peak_live)
+    assert cursor < 0.5 * pool_rows

@@ -170,3 +170,96 @@ def test_no_grad_render_and_training_forward_can_interleave(gs, oracle):
     c_t.grad = None
     fwd(c_t).sum().backward()
     assert torch.equal(g1, c_t.grad) and not torch.equal(other, img)
+
+
+def _crowded_scene(npts, h, w, seed):
+    """`npts` small gaussians whose centres all lie inside ONE 16x16 tile of an h x w image (cholesky parameters)."""
+    rng = np.random.default_rng(seed)
+    cx, cy = 24.0 + rng.uniform(-5, 5, npts), 24.0 + rng.uniform(-5, 5, npts)  # tile (1, 1), away from its edges
+    xyz = np.stack([cx / (0.5 * w) - 1.0, cy / (0.5 * h) - 1.0], 1).astype(np.float32)
+    L = np.stack([rng.uniform(0.25, 0.4, npts), rng.uniform(-0.05, 0.05, npts), rng.uniform(0.25, 0.4, npts)], 1)
+    col = rng.uniform(0, 1, (npts, 3)).astype(np.float32) * 0.01
+    return xyz, L.astype(np.float32), col, np.ones((npts, 1), np.float32)
+
+
+def _render_and_grad(gs, oracle, xyz, L, col, op, h, w):
+    tb = oracle.tile_bounds(h, w)
+    t = lambda a, g=False: torch.from_numpy(a).to(DEV).requires_grad_(g)
+    x_t, L_t, c_t, o_t = t(xyz), t(L), t(col, True), t(op)
+    xys, depths, radii, conics, nth = gs.project_gaussians_2d(x_t, L_t, h, w, tb)
+    img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, c_t, o_t, h, w, background=torch.ones(3, device=DEV))
+    v = torch.from_numpy(np.random.default_rng(5).normal(size=(h, w, 3)).astype(np.float32) * 1e-3).to(DEV)
+    (img * v).sum().backward()
+    return img, c_t.grad, (xys, depths, radii, conics, nth), v
+
+
+def test_a_tile_row_beyond_its_capacity_falls_back_to_the_capacity_free_ops(gs, oracle):
+    """1300 gaussians in ONE tile: more candidates than a tile row of the fused fast path holds (1024).  A workspace's
+    first forward is checked before its image is handed on, finds the overflow and redoes the work on the exact ops --
+    with the reference's rule intact that only the 256 lowest ids of the tile are rasterized (forward.cu:553)."""
+    from gaussianimage_plus_amd.gsplat import cuda as table
+    npts, h, w = 1300, 48, 64
+    assert npts > table.fast_tile_capacity()
+    xyz, L, col, op = _crowded_scene(npts, h, w, 1)
+    img, g_col, proj, v = _render_and_grad(gs, oracle, xyz, L, col, op, h, w)
+    d = [p.detach().cpu().numpy() for p in proj]
+    want, okg = _stage_check(oracle, h, w, d[0], d[1], d[2], d[3], d[4], col, op, img.detach().cpu().numpy(),
+                             v.cpu().numpy(), {"colors": g_col.cpu().numpy()})
+    assert float(g_col[256 + 50:].abs().max()) == 0.0  # ids beyond the cap received nothing
+
+
+def test_an_overflow_found_one_call_late_raises_and_the_retry_is_exact(gs, oracle):
+    """The status words of a forward are read when the host next touches the workspace (no GPU queue drain per
+    iteration).  A tile row that goes from at most half its capacity to beyond it between two consecutive calls on the
+    same workspace is therefore found late: that must be loud, and the same call repeated must then be exact."""
+    from gaussianimage_plus_amd.gsplat import _raster_common
+    if _raster_common.SYNC_EVERY_FORWARD:
+        pytest.skip("GI2D_WRAPPER_SYNC=1: every forward is checked before its image is used")
+    npts, h, w = 1300, 48, 64
+    rng = np.random.default_rng(2)
+    calm = (rng.uniform(-0.9, 0.9, (npts, 2)).astype(np.float32),
+            np.stack([rng.uniform(0.3, 0.6, npts), np.zeros(npts), rng.uniform(0.3, 0.6, npts)], 1).astype(np.float32),
+            rng.uniform(0, 1, (npts, 3)).astype(np.float32), np.ones((npts, 1), np.float32))
+    _render_and_grad(gs, oracle, *calm, h, w)   # first use of the workspace: checked at once, rows far below half full
+    _render_and_grad(gs, oracle, *calm, h, w)   # from now on the check trails by one call
+    crowded = _crowded_scene(npts, h, w, 3)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        _render_and_grad(gs, oracle, *crowded, h, w)
+    img, g_col, proj, v = _render_and_grad(gs, oracle, *crowded, h, w)  # the emptied workspace checks at once again
+    d = [p.detach().cpu().numpy() for p in proj]
+    _stage_check(oracle, h, w, d[0], d[1], d[2], d[3], d[4], crowded[2], crowded[3], img.detach().cpu().numpy(),
+                 v.cpu().numpy(), {"colors": g_col.cpu().numpy()})
+
+
+def test_compiled_and_ctypes_op_tables_agree_bit_for_bit(oracle):
+    """csrc/torch_ext (the pybind module of ext.cpp:16-66) and the ctypes table are two bindings of ONE C ABI."""
+    from gaussianimage_plus_amd.gsplat import cuda as table
+    if table.BINDING != "compiled":
+        pytest.skip("the compiled op table is not built (no C++ compiler?)")
+    npts, h, w = 3000, 96, 160
+    xyz, L, col, op = synth_cholesky(npts, h, w, 17)
+    tb = oracle.tile_bounds(h, w)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    a = (npts, 3.0, t(xyz), t(L), h, w, tb, 0.01, 1.0, False)
+    got, ref = table.project_gaussians_2d_forward(*a), table.CTYPES_TABLE["project_gaussians_2d_forward"](*a)
+    assert len(got) == len(ref) == 5 and all(torch.equal(x, y) for x, y in zip(got, ref))
+    xys, depths, radii, conics, nth = got
+    v_xy, v_conic = torch.randn_like(xys), torch.randn_like(conics)
+    b = (npts, t(xyz), t(L), h, w, radii, conics, v_xy, None, v_conic)
+    got, ref = table.project_gaussians_2d_backward(*b), table.CTYPES_TABLE["project_gaussians_2d_backward"](*b)
+    assert len(got) == len(ref) == 3 and all(torch.equal(x, y) for x, y in zip(got, ref))
+    gids, bins, status = table.bin_gaussians(xys, radii, tb, 1.0, 8 * npts)
+    gids = gids[:int(status[0])].contiguous()  # the reference's ops take exactly num_intersects entries
+    bg = torch.ones(3, device=DEV)
+    c = (tb, (16, 16, 1), (w, h, 1), gids, bins, xys, conics, t(col), t(op), bg, False)
+    for name, n_out in (("rasterize_sum_forward", 4), ("rasterize_sum_plus_forward", 3)):
+        got, ref = getattr(table, name)(*c), table.CTYPES_TABLE[name](*c)
+        assert len(got) == len(ref) == n_out and all(torch.equal(x, y) for x, y in zip(got, ref)), name
+    out_img, final_Ts, final_idx = got
+    v_out = torch.randn_like(out_img) * 1e-3
+    d = (h, w, 16, 16, gids, bins, xys, conics, t(col), t(op), bg, final_Ts, final_idx, v_out, None)
+    for name, n_out in (("rasterize_sum_backward", 5), ("rasterize_sum_plus_backward", 4)):
+        got, ref = getattr(table, name)(*d), table.CTYPES_TABLE[name](*d)
+        assert len(got) == len(ref) == n_out and all(torch.equal(x, y) for x, y in zip(got, ref)), name
+    with pytest.raises(RuntimeError):
+        table.project_gaussians_2d_forward(npts, 3.0, t(xyz).cpu(), t(L), h, w, tb, 0.01, 1.0, False)  # CHECK_INPUT
