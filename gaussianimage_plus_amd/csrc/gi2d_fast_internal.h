@@ -599,8 +599,9 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
 #define GI2D_ORDER_BINS (GI2D_FAST_C + 1) /* populations 0 .. GI2D_FAST_C */
 #define GI2D_CU_SLOTS 256
 #define GI2D_ORDER_MAX_TILES 2048 /* larger grids run in several rounds of resident workgroups and balance themselves */
+// `always`: skip the "worth it?" test below (the training update kernel, which only asks every 16th step).
 __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile_bins, int num_tiles,
-                                                   int32_t *__restrict__ tile_order) {
+                                                   int32_t *__restrict__ tile_order, bool always = false) {
     if (num_tiles <= GI2D_CU_SLOTS || num_tiles > GI2D_ORDER_MAX_TILES) return;  // order stays the identity
     __shared__ int hist[GI2D_ORDER_BINS + 1];
     const int tid = threadIdx.x, bs = blockDim.x;  // 64 or 256 lanes
@@ -630,7 +631,7 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
         __syncthreads();
         mx = 0, sm = 0;
         for (int k = 0; k < (bs >> 6); ++k) mx = max(mx, red_max[k]), sm += red_sum[k];
-        if (4 * mx * num_tiles <= 7 * sm) return;  // workgroup-uniform
+        if (!always && 4 * mx * num_tiles <= 7 * sm) return;  // workgroup-uniform
     }
     __syncthreads();
 #pragma unroll

@@ -548,15 +548,18 @@ void gi2d_oracle_rasterize_forward_sum(int tiles_x, int tiles_y, int img_w, int 
  * v_conic[3], v_rgb[3], v_opacity), with the two v_xy terms taken part by part
  * (|v_sigma a dx| + |v_sigma b dy|, ...);
  * `v_abs_xy` f32[N*4] = (sum v_x, sum v_y, sum |v_x|, sum |v_y|) over pixels, the quantity
- * rasterize_sum.py:308,328 returns for `screenspace_points` (backward.cu:932,959-960). */
-void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img_w, int img_h,
-                                        const int32_t *gaussian_ids_sorted,
-                                        const int32_t *tile_bins, int tile_bins_rows,
-                                        const float *xys, const float *conics, const float *rgbs,
-                                        const float *opacities, const int32_t *final_idx,
-                                        const float *v_output, float *v_xy, float *v_conic,
-                                        float *v_rgb, float *v_opacity, uint8_t *ambig,
-                                        float *abs9, float *v_abs_xy) {
+ * rasterize_sum.py:308,328 returns for `screenspace_points` (backward.cu:932,959-960).
+ * `amb9` f32[N*9] (optional): sum of |term| over the FLAGGED pairs of the gaussian alone, landed or not -- what a
+ * correct machine that puts those pairs on the other side of a cut-off may differ by at most (the bound the tests hold
+ * the masked gaussians to). */
+void gi2d_oracle_rasterize_backward_sum_ex(int n, int tiles_x, int tiles_y, int img_w, int img_h,
+                                           const int32_t *gaussian_ids_sorted,
+                                           const int32_t *tile_bins, int tile_bins_rows,
+                                           const float *xys, const float *conics, const float *rgbs,
+                                           const float *opacities, const int32_t *final_idx,
+                                           const float *v_output, float *v_xy, float *v_conic,
+                                           float *v_rgb, float *v_opacity, uint8_t *ambig,
+                                           float *abs9, float *v_abs_xy, float *amb9) {
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
@@ -566,6 +569,7 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
     double *aacc = v_abs_xy ? (double *)calloc(stride * (size_t)nthreads, sizeof(double)) : NULL;
     double *wacc = abs9 ? (double *)calloc(stride * (size_t)nthreads, sizeof(double)) : NULL;
     uint8_t *amb_t = ambig ? (uint8_t *)calloc((size_t)n * (size_t)nthreads, 1) : NULL;
+    double *bacc = (amb9 && ambig) ? (double *)calloc(stride * (size_t)nthreads, sizeof(double)) : NULL;
 #pragma omp parallel
     {
         int tid = 0;
@@ -576,6 +580,7 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
         double *AA = aacc ? aacc + stride * (size_t)tid : NULL;
         double *AW = wacc ? wacc + stride * (size_t)tid : NULL;
         uint8_t *AM = amb_t ? amb_t + (size_t)n * (size_t)tid : NULL;
+        double *AB = bacc ? bacc + stride * (size_t)tid : NULL;
 #pragma omp for schedule(dynamic, 4)
         for (int tile = 0; tile < tiles_x * tiles_y; ++tile) {
             int ty = tile / tiles_x, tx = tile % tiles_x;
@@ -589,7 +594,7 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
                 float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
                 float gx = xys[2 * g], gy = xys[2 * g + 1], opac = opacities[g];
                 float r0 = rgbs[3 * g], r1 = rgbs[3 * g + 1], r2 = rgbs[3 * g + 2];
-                double s[9] = {0}, sa[9] = {0}, sw[9] = {0};
+                double s[9] = {0}, sa[9] = {0}, sw[9] = {0}, sb[9] = {0};
                 int amb = 0, any = 0;
                 for (int ly = 0; ly < GI2D_BLOCK_Y; ++ly)
                     for (int lx = 0; lx < GI2D_BLOCK_X; ++lx) {
@@ -597,17 +602,33 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
                         if (i >= img_h || j >= img_w) continue;
                         int pix = i * img_w + j;
                         float dx, dy, vis, alpha;
-                        if (idx > final_idx[pix]) {
-                            /* backward.cu:903: not a contributor of this pixel in the forward.  It may be one by a hair:
-                             * a pair whose alpha the forward put just BELOW 1/255 never extends final_idx, so the gate
-                             * skips it here before its alpha is looked at -- the ambiguity report must not depend on
-                             * that (found at 2040x1356: one gaussian in 50 000 escaped the flag this way). */
-                            if (AM) (void)pair_eval(a, b, c, gx, gy, opac, (float)j, (float)i, &dx, &dy, &vis, &alpha, &amb);
-                            continue;
+                        /* backward.cu:903: idx > final_idx -- not a contributor of this pixel in the forward.  It may be
+                         * one by a hair: a pair whose alpha the forward put just BELOW 1/255 never extends final_idx, so
+                         * the gate skips it before its alpha is looked at -- the ambiguity report must not depend on
+                         * that (found at 2040x1356: one gaussian in 50 000 escaped the flag this way). */
+                        const int gated = idx > final_idx[pix];
+                        int pamb = 0;
+                        if (gated && !AM) continue;
+                        const int lands = pair_eval(a, b, c, gx, gy, opac, (float)j, (float)i, &dx, &dy, &vis, &alpha,
+                                                    AM ? &pamb : NULL);
+                        if (pamb) {
+                            amb = 1;
+                            if (AB) { /* what the flagged pair adds if it lands: the bound for the masked gaussian */
+                                float vo0 = v_output[3 * pix], vo1 = v_output[3 * pix + 1], vo2 = v_output[3 * pix + 2];
+                                double va = fabs((double)r0 * vo0 + (double)r1 * vo1 + (double)r2 * vo2);
+                                double vs = fabs((double)opac * vis) * va, al = fabs((double)alpha);
+                                sb[0] += vs * (fabs((double)a * dx) + fabs((double)b * dy));
+                                sb[1] += vs * (fabs((double)b * dx) + fabs((double)c * dy));
+                                sb[2] += 0.5 * vs * dx * dx;
+                                sb[3] += 0.5 * vs * fabs((double)dx * dy);
+                                sb[4] += 0.5 * vs * dy * dy;
+                                sb[5] += al * fabs((double)vo0);
+                                sb[6] += al * fabs((double)vo1);
+                                sb[7] += al * fabs((double)vo2);
+                                sb[8] += fabs((double)vis) * va;
+                            }
                         }
-                        if (!pair_eval(a, b, c, gx, gy, opac, (float)j, (float)i, &dx, &dy, &vis,
-                                       &alpha, AM ? &amb : NULL))
-                            continue;
+                        if (gated || !lands) continue;
                         float vo0 = v_output[3 * pix], vo1 = v_output[3 * pix + 1],
                               vo2 = v_output[3 * pix + 2];
                         float t[9];
@@ -644,6 +665,8 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
                         if (AW) AW[(size_t)g * 9 + k] += sw[k];
                     }
                 if (AM && amb) AM[g] = 1;
+                if (AB && amb)
+                    for (int k = 0; k < 9; ++k) AB[(size_t)g * 9 + k] += sb[k];
             }
         }
     }
@@ -677,11 +700,30 @@ void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img
             v_abs_xy[4 * g + 3] = (float)sa[1];
         }
         if (ambig) ambig[g] = (uint8_t)amb;
+        if (bacc)
+            for (int k = 0; k < 9; ++k) {
+                double v = 0.0;
+                for (int t = 0; t < nthreads; ++t) v += bacc[stride * (size_t)t + (size_t)g * 9 + k];
+                amb9[(size_t)g * 9 + k] = (float)v;
+            }
     }
     free(acc);
     free(aacc);
     free(wacc);
     free(amb_t);
+    free(bacc);
+}
+void gi2d_oracle_rasterize_backward_sum(int n, int tiles_x, int tiles_y, int img_w, int img_h,
+                                        const int32_t *gaussian_ids_sorted,
+                                        const int32_t *tile_bins, int tile_bins_rows,
+                                        const float *xys, const float *conics, const float *rgbs,
+                                        const float *opacities, const int32_t *final_idx,
+                                        const float *v_output, float *v_xy, float *v_conic,
+                                        float *v_rgb, float *v_opacity, uint8_t *ambig,
+                                        float *abs9, float *v_abs_xy) {
+    gi2d_oracle_rasterize_backward_sum_ex(n, tiles_x, tiles_y, img_w, img_h, gaussian_ids_sorted, tile_bins,
+                                          tile_bins_rows, xys, conics, rgbs, opacities, final_idx, v_output, v_xy,
+                                          v_conic, v_rgb, v_opacity, ambig, abs9, v_abs_xy, NULL);
 }
 
 int gi2d_oracle_num_threads(void) {

@@ -219,9 +219,10 @@ def rasterize_sum_forward(tb, block, img_size, gaussian_ids_sorted, tile_bins, x
 
 def rasterize_sum_backward(img_h, img_w, block_h, block_w, gaussian_ids_sorted, tile_bins, xys, conics,
                            colors, opacities, background, final_Ts, final_idx, v_output,
-                           v_output_alpha=None, with_aux=False):
+                           v_output_alpha=None, with_aux=False, with_amb9=False):
     """Argument order of _C.rasterize_sum[_plus]_backward (bindings.cu:1166-1314).
-    -> (v_xy, v_conic, v_colors, v_opacity[N,1]) (+ ambig[N], abs9[N,9], v_abs_xy[N,4])"""
+    -> (v_xy, v_conic, v_colors, v_opacity[N,1]) (+ ambig[N], abs9[N,9], v_abs_xy[N,4]) (+ amb9[N,9]: what the pairs
+    flagged as ambiguous add to each gaussian at most -- the bound for the gaussians the mask sets aside)"""
     assert block_h == 16 and block_w == 16
     gids, bins = _i(gaussian_ids_sorted), _i(tile_bins)
     xys, conics, colors, opac = _f(xys), _f(conics), _f(colors), _f(opacities)
@@ -233,10 +234,13 @@ def rasterize_sum_backward(img_h, img_w, block_h, block_w, gaussian_ids_sorted, 
     amb = np.zeros((n,), np.uint8) if with_aux else None
     abs9 = np.zeros((n, 9), np.float32) if with_aux else None
     vabs = np.zeros((n, 4), np.float32) if with_aux else None
-    lib().gi2d_oracle_rasterize_backward_sum(
+    amb9 = np.zeros((n, 9), np.float32) if (with_aux and with_amb9) else None
+    lib().gi2d_oracle_rasterize_backward_sum_ex(
         C.c_int(n), C.c_int(tb[0]), C.c_int(tb[1]), C.c_int(img_w), C.c_int(img_h), _p(gids), _p(bins),
         C.c_int(bins.shape[0]), _p(xys), _p(conics), _p(colors), _p(opac), _p(fidx), _p(vout), _p(v_xy),
-        _p(v_conic), _p(v_rgb), _p(v_op), _p(amb), _p(abs9), _p(vabs))
+        _p(v_conic), _p(v_rgb), _p(v_op), _p(amb), _p(abs9), _p(vabs), _p(amb9))
+    if with_aux and with_amb9:
+        return v_xy, v_conic, v_rgb, v_op, amb, abs9, vabs, amb9
     if with_aux:
         return v_xy, v_conic, v_rgb, v_op, amb, abs9, vabs
     return v_xy, v_conic, v_rgb, v_op

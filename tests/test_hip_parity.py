@@ -227,15 +227,27 @@ def test_rasterize_forward_matches_golden(C, oracle, golden_dir):
         assert res[0].shape == (h, w, 3)
 
 
-def _check_backward(name, got, want, gamb, abs9):
+def _check_backward(name, got, want, gamb, abs9, amb9=None):
+    """Every gaussian the oracle does not flag: 1e-5 of its conditioning-weighted absolute terms.  The flagged ones
+    (a pair within the band around a cut-off: 0.09 % of them at N = 50 000, 0.65 % at N = 10 000) are not simply set
+    aside: with `amb9` -- what the oracle says their flagged pairs add at most -- they are held to that bound on top of
+    the same relative tolerance: two correct machines may put a flagged pair on different sides of the cut-off, and by
+    nothing else may they differ."""
     ok = gamb == 0
     v_xy, v_conic, v_rgb, v_op = [n(x) for x in got[:4]]
-    cols = [(v_xy, want[0], abs9[:, 0:2]), (v_conic, want[1], abs9[:, 2:5]), (v_rgb, want[2], abs9[:, 5:8]),
-            (v_op.reshape(-1, 1), want[3].reshape(-1, 1), abs9[:, 8:9])]
+    cols = [(v_xy, want[0], abs9[:, 0:2], 0, 2), (v_conic, want[1], abs9[:, 2:5], 2, 5), (v_rgb, want[2], abs9[:, 5:8], 5, 8),
+            (v_op.reshape(-1, 1), want[3].reshape(-1, 1), abs9[:, 8:9], 8, 9)]
     worst = 0
-    for (a, b, s), nm in zip(cols, ["v_xy", "v_conic", "v_rgb", "v_opacity"]):
+    for (a, b, s, c0, c1), nm in zip(cols, ["v_xy", "v_conic", "v_rgb", "v_opacity"]):
         mask = np.repeat(ok[:, None], a.shape[1], 1)
         worst = max(worst, check_close(f"{name} {nm}", a, b, s, mask=mask, atol=1e-12))
+        if amb9 is not None and (~ok).any():
+            bound = 1.001 * amb9[~ok, c0:c1] + 1e-5 * s[~ok] + 1e-12
+            diff = np.abs(a[~ok].astype(np.float64) - b[~ok].astype(np.float64))
+            over = diff > bound
+            assert not over.any(), (f"{name} {nm}: {int(over.sum())} elements of the {int((~ok).sum())} flagged gaussians "
+                                    f"differ by more than their flagged pairs can explain; worst "
+                                    f"{float((diff / bound).max()):.3g} of the bound")
     return worst
 
 
@@ -318,11 +330,12 @@ def test_full_path_at_baseline_sizes(C, oracle, npts, h, w):
     gt = synth_gt(h, w, 1)
     v_out = (2 * (np.clip(out_o, 0, 1) - gt) / (3 * h * w)).astype(np.float32)
     want = oracle.rasterize_sum_backward(h, w, 16, 16, ref["gids_sorted"], ref["tile_bins"], ref["xys"],
-                                         ref["conics"], col, op, None, fT_o, fidx_o, v_out, with_aux=True)
+                                         ref["conics"], col, op, None, fT_o, fidx_o, v_out, with_aux=True, with_amb9=True)
     got = C.rasterize_sum_plus_backward(h, w, 16, 16, srt["gaussian_ids_sorted"], srt["tile_bins"], xys_t,
                                         conics_t, t(col), t(op), bg, fT, t(fidx_o), t(v_out), None,
                                         cum_tiles_hit=cum, inv_perm=srt["inv_perm"])
-    _check_backward(f"N={npts}", got, want[:4], want[4], want[5])
+    print(f"N={npts}: {int((want[4] != 0).sum())} of {npts} gaussians flagged (held to their flagged pairs' own terms)")
+    _check_backward(f"N={npts}", got, want[:4], want[4], want[5], amb9=want[7])
 
     # property: the forward is linear in the colours (same visibility set) ...
     out2, _, _ = C.rasterize_sum_plus_forward(tb, (16, 16, 1), (w, h, 1), srt["gaussian_ids_sorted"],

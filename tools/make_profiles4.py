@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/rp3 (tools/profile_round3.sh) into the tracked evidence under profiles/:
+"""Turn gpurun_out/rp<N> (tools/profile_round4.sh; N = the ROUND environment variable, default 4) into the tracked
+evidence under profiles/:
     round3_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the workload (head, c4_2k, batched,
                                          c5_rs_quant, trained_fit)
     round3_bench_under_rocprof.json      the JSON line bench.py printed under the profiler (head workload)
@@ -7,8 +8,11 @@
     round3_batched_plain.txt             tools/batch_time.py K = 4 / 8 / 24 without the profiler
     round3_pmc_summary.txt               mean counter value per kernel, one line per workload, kernel and --pmc pass
     traffic.json                         HBM bytes per launch per kernel and workload (read by bench.py for
-                                         roofline.traffic)
-usage: python tools/make_profiles3.py"""
+                                         roofline.traffic), the VALU counters of the same kernels (roofline_valu) and the
+                                         lane model of the bench scene (tools/lane_model.py)
+    round4_dropin_profile_after.txt      the drop-in autograd loop under cProfile
+    round4_kodak_fit_50k_run.txt         the images/s leg alone (24 Kodak images x 50 000 iterations)
+usage: python tools/make_profiles4.py"""
 import collections
 import csv
 import glob
@@ -17,10 +21,12 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "rp3")
+ROUND = os.environ.get("ROUND", "4")
+SRC = os.path.join(ROOT, "gpurun_out", "rp" + ROUND)
 DST = os.path.join(ROOT, "profiles")
-TAG = "round3"
-NAMES = {"head": "bench", "c4": "c4_2k", "batched": "batched", "c5": "c5_rs_quant", "fit": "trained_fit"}
+TAG = "round" + ROUND
+NAMES = {"head": "bench", "c4": "c4_2k", "batched": "batched", "c5": "c5_rs_quant", "fit": "trained_fit",
+         "frozen": "frozen_scene", "trained": "trained_scene"}
 
 
 def short(name):
@@ -61,15 +67,20 @@ for work, name in NAMES.items():
                          f"v{m[k]['vgpr']} s{m[k]['sgpr']} lds {m[k]['lds']} scratch {m[k]['scratch']}  " +
                          " ".join(f"{c}={round(v)}" for c, v in sorted(vals[k].items())))
     kernels = {}
-    for k in fetch:
-        if k not in write:
-            continue
-        f_kib, w_kib = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
-        kernels[f"{k[0]} @grid {k[1]}"] = {
-            "kernel": k[0], "grid": k[1], "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
+    sq1, sq1_meta = counters(work, "sq1")
+    for k in sorted(set(fetch) | set(sq1)):
+        entry = {"kernel": k[0], "grid": k[1]}
+        if k in fetch and k in write:
+            f_kib, w_kib = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
             # MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950
             # -> doubled (an upper bound for the narrower reads in these kernels); WRITE_SIZE is exact
-            "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024)}
+            entry.update({"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib,
+                          "hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024)})
+        if k in sq1 and sq1_meta[k]["launches"] >= 3 and "SQ_INSTS_VALU" in sq1[k]:
+            entry["valu"] = {c: sq1[k][c] for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES",
+                                                    "SQ_WAIT_ANY") if c in sq1[k]}
+        if len(entry) > 2:
+            kernels[f"{k[0]} @grid {k[1]}"] = entry
     cfg = None
     out_file = os.path.join(SRC, f"{work}.out")
     if work in ("head", "c4") and os.path.exists(out_file):
@@ -83,8 +94,16 @@ for work, name in NAMES.items():
                 open(os.path.join(DST, f"{TAG}_c4_2k_under_rocprof.json"), "w").write(js[-1])
     elif work == "batched":
         cfg = {"num_points": 50000, "height": 512, "width": 768, "images_per_launch": 24}
+    elif work == "frozen":
+        cfg = {"num_points": 50000, "height": 512, "width": 768, "frozen": True}
+    wl = {"workload": name, "config": cfg, "kernels": kernels}
+    lane = os.path.join(SRC, "lane_model.json")
+    if work == "head" and os.path.exists(lane):
+        js = [l for l in open(lane) if l.startswith("{")]
+        if js:
+            wl["lane_model"] = json.loads(js[-1])
     if kernels:
-        workloads.append({"workload": name, "config": cfg, "kernels": kernels})
+        workloads.append(wl)
 
 open(os.path.join(DST, f"{TAG}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 plain = [l for l in open(os.path.join(SRC, "bench_plain.json")) if l.startswith("{")]
@@ -94,11 +113,16 @@ bp = os.path.join(SRC, "batched_plain.out")
 if os.path.exists(bp):
     open(os.path.join(DST, f"{TAG}_batched_plain.txt"), "w").write(
         "".join(l for l in open(bp) if l.startswith("K=") or l.startswith("single")))
+for src, dst in (("dropin_profile.txt", f"{TAG}_dropin_profile_after.txt"), ("kodak50k.out", f"{TAG}_kodak_fit_50k_run.txt"),
+                 ("trained_fit.out", f"{TAG}_trained_scene_fit.txt")):
+    if os.path.exists(os.path.join(SRC, src)):
+        keep = [l for l in open(os.path.join(SRC, src)) if "amdgpu.ids" not in l]
+        open(os.path.join(DST, dst), "w").write("".join(keep))
 for work in ("c5", "fit"):
     f = os.path.join(SRC, f"{work}.out")
     if os.path.exists(f):
         keep = [l for l in open(f) if ("us/iter" in l or "images/s" in l or l.startswith("best"))]
         open(os.path.join(DST, f"{TAG}_{NAMES[work]}_run.txt"), "w").write("".join(keep))
-json.dump({"source": f"profiles/{TAG}_pmc_summary.txt (tools/profile_round3.sh, separate --pmc passes)",
+json.dump({"source": f"profiles/{TAG}_pmc_summary.txt (tools/profile_round4.sh, separate --pmc passes)",
            "workloads": workloads}, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print("\n".join(lines))

@@ -1,18 +1,23 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence kept under profiles/round3_*: for each workload the kernel-trace stats and separate
-# --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ groups; never combined with other trace domains).
-#   gpurun --timeout 1200 -- 'bash tools/profile_round3.sh'      then      python tools/make_profiles3.py
+# Collect the rocprofv3 evidence kept under profiles/round<N>_* (ROUND, default 4; round 3's files were made by the
+# same script): for each workload the kernel-trace stats and separate --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ
+# groups; never combined with other trace domains).
+#   gpurun --timeout 1200 -- 'bash tools/profile_round4.sh'      then      python tools/make_profiles4.py
 # workloads: head    bench.py's timed loop (Cholesky, N=50 000, 768x512, training iterations)
 #            c4      the same at 2040x1356 (BASELINE config 4)
 #            batched 24 images per launch (tools/batch_time.py, N=50 000)
 #            c5      rotation-scale model, quantisation-aware iterations, N=30 000 (tools/quant_time.py)
 #            fit     24 Kodak images x 10 000 iterations as one batch (tools/kodak_fit.py): trained scenes, prune / grow
+#            frozen  bench scene with frozen parameters (tools/static_steps.py): the instruction-count yardstick
+#            trained one Kodak picture fitted with the launcher's schedule, then frozen (tools/trained_scene.py)
+#            dropin  the drop-in autograd loop under cProfile (tools/profile_autograd_loop.py)
 set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/rp3
+ROUND=${ROUND:-4}
+OUT=$REPO/gpurun_out/rp$ROUND
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-HEAD="--no-cpu-baseline --images 0 --no-batched --no-static"
+HEAD="--no-cpu-baseline --images 0 --no-batched --no-static --no-dropin"
 C4="$HEAD --height 1356 --width 2040"
 stats() { # name, program...
   local name=$1; shift
@@ -26,7 +31,7 @@ pmc() { # name, pass, counters (quoted), program...
 }
 SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS"
 SQ2="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
-mkdir -p $OUT/head $OUT/c4 $OUT/batched $OUT/c5 $OUT/fit
+mkdir -p $OUT/head $OUT/c4 $OUT/batched $OUT/c5 $OUT/fit $OUT/frozen $OUT/trained
 stats head $REPO/bench.py $HEAD
 echo "head stats done"
 for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc head $1 "$2" $REPO/bench.py $HEAD --steps 20 --warmup 5; done
@@ -49,5 +54,14 @@ echo "c5 done"
 stats fit $REPO/tools/kodak_fit.py 24 10000 1
 pmc fit sq1 "$SQ1" $REPO/tools/kodak_fit.py 24 1000 1
 echo "fit done"
+pmc frozen sq1 "$SQ1" $REPO/tools/static_steps.py 30
+python3 $REPO/tools/trained_scene.py fit 0 50000 /tmp/trained_scene.pt > $OUT/trained_fit.out 2>&1 || true
+pmc trained sq1 "$SQ1" $REPO/tools/trained_scene.py steps 30
+stats trained $REPO/tools/trained_scene.py steps 200
+echo "frozen + trained scene done"
+python3 $REPO/tools/profile_autograd_loop.py 50000 500 > $OUT/dropin_profile.txt 2>&1 || true
+python3 $REPO/tools/kodak_fit.py 24 50000 3 > $OUT/kodak50k.out 2>&1 || true
+(cd $REPO && python3 tools/lane_model.py > $OUT/lane_model.json 2> /dev/null) || true
+echo "dropin + kodak done"
 cd $REPO && python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 tail -n 1 $OUT/bench_plain.json | cut -c1-400
