@@ -516,3 +516,59 @@ def test_cull_box_never_drops_a_contributing_pair(C, oracle, seed):
     img.backward(t(v_out))
     _check_backward_extreme("cull stress wrapper", (xys_t.grad, conics_t.grad, col_t.grad, op_t.grad), want[:4],
                             want[4], want[5])
+
+
+def test_nan_parameters_and_odd_opacities_follow_the_reference_comparisons(C, oracle):
+    """forward.cu:539-541 skips a pair on `sigma < 0 || alpha < 1/255` with alpha = min(1, opac * vis): every comparison
+    with a NaN is false and fminf(1, NaN) = 1, so a gaussian with a NaN among its parameters lands on EVERY pixel of its
+    tiles with alpha = 1; opacity <= 0 never lands; opacity > 1 clamps.  The kernels test a pair with one range compare
+    (gi2d_common.h::AlphaRule) and drop the v_min where no entry of a wave can exceed alpha 1 -- the corner cases must
+    come out as the oracle's (= the reference's) comparisons give them."""
+    h, w, npts = 48, 64, 40
+    tb = oracle.tile_bounds(h, w)
+    rng = np.random.default_rng(9)
+    xys = (rng.random((npts, 2)) * np.array([w, h])).astype(np.float32)
+    s = rng.uniform(1.0, 3.0, (npts, 2)).astype(np.float32)
+    conics = np.stack([1 / s[:, 0] ** 2, rng.uniform(-0.05, 0.05, npts).astype(np.float32), 1 / s[:, 1] ** 2], 1).astype(np.float32)
+    radii = np.ceil(3 * s.max(1)).astype(np.int32)
+    col = rng.uniform(0.1, 1.0, (npts, 3)).astype(np.float32)
+    op = rng.uniform(0.3, 1.0, (npts, 1)).astype(np.float32)
+    conics[3, 1] = np.nan                        # NaN conic: sigma NaN everywhere
+    op[7, 0] = np.nan                            # NaN opacity
+    op[11, 0], op[12, 0], op[13, 0] = 0.0, -0.5, 1.0 / 300.0   # never land
+    op[17, 0], op[18, 0] = 2.5, 40.0             # min(1, .) binds
+    xys[21] = [np.nan, 20.0]                     # NaN centre: listed in no tile by the binning (radius box of NaN)
+    m, cum = oracle.compute_cumulative_intersects(_num_tiles_hit(xys, radii, tb))
+    _, _, so, go, bins = oracle.bin_and_sort_gaussians(npts, m, xys, np.zeros(npts, np.float32), radii, cum, tb, 1.0)
+    out_o, fT_o, fidx_o = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, xys, conics, col, op)
+    bg = torch.ones(3, device=DEV)
+    out, fT, fidx = C.rasterize_sum_plus_forward(tb, (16, 16, 1), (w, h, 1), t(go), t(bins), t(xys), t(conics), t(col),
+                                                 t(op), bg, False)
+    got = n(out)
+    assert np.array_equal(np.isnan(got), np.isnan(out_o))  # (NaN colours times alpha: none here; NaN centre is unlisted)
+    np.testing.assert_allclose(got, out_o, rtol=2e-5, atol=2e-6)
+    # the gaussians with a NaN conic / opacity add their colour at full weight to every pixel of every tile they are in
+    tile = lambda p: (int(p[1]) // 16) * tb[0] + int(p[0]) // 16
+    for g in (3, 7):
+        t0 = tile(xys[g])
+        ty, tx = divmod(t0, tb[0])
+        px = got[16 * ty + 3, 16 * tx + 3]
+        assert (px >= col[g] - 1e-5).all()
+    # fused fast path: same image
+    ws = C.FastWorkspace(npts, tb, t(xys))
+    img = C.fast_forward(ws, t(xys), t(radii), t(conics), t(col), t(op), h, w, 1.0)
+    assert torch.equal(img, out)
+
+
+def _num_tiles_hit(xys, radii, tb):
+    """Tiles of the box of the int radius (helpers.cuh:16-50), as the projection kernels count them."""
+    out = np.zeros(len(radii), np.int32)
+    for g, ((x, y), r) in enumerate(zip(xys, radii)):
+        if not (x == x and y == y) or r <= 0:
+            continue
+        mnx = min(max(0, int(np.trunc((x - r) / 16.0))), tb[0])
+        mxx = min(max(0, int(np.trunc((x + r) / 16.0 + 1))), tb[0])
+        mny = min(max(0, int(np.trunc((y - r) / 16.0))), tb[1])
+        mxy = min(max(0, int(np.trunc((y + r) / 16.0 + 1))), tb[1])
+        out[g] = max(mxx - mnx, 0) * max(mxy - mny, 0)
+    return out

@@ -162,9 +162,10 @@ def test_rasterizer_forward_and_backward_equal_float64_autograd(oracle, rv):
 # ---- the reference's OWN CPU rasterizer (_torch_impl.py:354-421 `rasterize_forward`), one gaussian per call, summed;
 # ---- gradients by autograd through the same calls (tests/golden/make_refras_vectors.py -> refras_vectors.npz)
 
-@pytest.fixture(scope="module")
-def rr(golden_dir):
-    return np.load(os.path.join(golden_dir, "refras_vectors.npz"))
+@pytest.fixture(scope="module", params=["refras_vectors.npz", "refras_vectors_large.npz"])
+def rr(golden_dir, request):
+    """40x56 / 46 gaussians, and (round 4) 72x104 / 160 gaussians: tests/golden/make_refras_vectors.py [REFRAS_LARGE=1]"""
+    return np.load(os.path.join(golden_dir, request.param))
 
 
 def refras_lists(oracle, rr):
