@@ -67,6 +67,7 @@ struct TilePassArgs {
     float grad_scale;
     float *tile_sse;
     const int32_t *tile_order;
+    int32_t *big_tile;  // two-phase tile pass: which tiles the small form left to the general one (FastWs::big_tile)
 };
 
 // One image's arguments of the per-gaussian fitting kernels (project+fill, reduce+update).
@@ -103,6 +104,7 @@ static inline TilePassArgs tile_pass_args(const FastWs &w, int n, int tiles_x, i
     a.grad_scale = grad_scale;
     a.tile_sse = tile_sse;
     a.tile_order = w.tile_order;
+    a.big_tile = w.big_tile;
     return a;
 }
 

@@ -215,54 +215,106 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 }
 
 // ----------------------------------------------------------------- forward + backward in one pass
-template <int MODE>
-__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_kernel(TilePassArgs a) {
-    __shared__ FusedLds sm;
+// PHASE 0: every tile, general form (256 staged entries: 26 KB of LDS, six workgroups per CU) -- what a launch of at
+//          most one residency round of the chip runs (one 768x512 image: 1536 tiles).
+// PHASE 1: the SMALL form (GI2D_SMALL_CAP staged entries: 18 KB, 62 registers, EIGHT workgroups per CU) on every tile
+//          whose row holds at most that many candidates; a fuller row is only marked (`big_tile`) ...
+// PHASE 2: ... and handled by the general form in a second launch whose other workgroups return at once.
+// The per-tile code is the same template (fused_tile<MODE, CAP>), so a tile's results do not depend on the phase.
+template <int MODE, int PHASE>
+__device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int slot, bool first) {
+    constexpr int CAP = PHASE == 1 ? GI2D_SMALL_CAP : GI2D_TILE_LIST_CAP;
+    __shared__ FusedLdsT<CAP> sm;
     int tile;
-    const HeadRow hr = head_row_for(a.lists, a.tile_order, (int)blockIdx.x, tile);
-    const float4 *recs = recs_for_tile_pass(a.rs, blockIdx.x == 0 && threadIdx.x == 0);
-    fused_tile<MODE>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins,
-                     a.partial_g, a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);
+    HeadRow hr;
+    if (PHASE == 2) {  // (the caller has looked at big_tile: only tiles the small form passed over arrive here)
+        tile = __builtin_amdgcn_readfirstlane(a.tile_order[slot]);
+        hr = head_row_load(a.lists, tile);
+    } else {
+        hr = head_row_for(a.lists, a.tile_order, slot, tile);
+    }
+    if (PHASE == 1) {
+        const bool big = __builtin_amdgcn_readfirstlane(hr.hdr_count) > GI2D_SMALL_CAP;  // workgroup-uniform
+        if (threadIdx.x == 0) a.big_tile[tile] = big ? 1 : 0;
+        if (big) return;
+    }
+    const float4 *recs = recs_for_tile_pass(a.rs, first && threadIdx.x == 0);
+    // (phase 2 loops over tiles: its loop keeps the lane's invariants alive, so the forward's trips are not unrolled there)
+    fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
+                          a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);
+}
+
+// Phase 2 finds nothing to do on the scenes the two-phase form is for (large images: sparse rows), and ten thousand
+// workgroups that only look and return cost several us of dispatch: a phase-2 workgroup therefore looks at a STRIP of
+// GI2D_PHASE2_STRIP consecutive slots at once and handles the ones that were passed over one after the other (a barrier
+// between two tiles: they share its LDS).
+#define GI2D_PHASE2_STRIP 8
+// workgroups per CU the register allocator leaves room for, by phase: the loop of phase 2 keeps the lane's invariants
+// alive across tiles (80 registers and a few dwords of scratch at six per CU -- and a kernel with ANY scratch pays
+// ~200 us per dispatch here while the runtime re-arms the queue's scratch: measured) -- so it is built for four (five still left one of the four kernels with 12 bytes of it)
+#define GI2D_PHASE_OCC(PHASE) ((PHASE) == 1 ? GI2D_SMALL_OCC : (PHASE) == 2 ? 4 : GI2D_FUSED_OCC)
+static inline unsigned phase2_blocks(long long slots) { return (unsigned)((slots + GI2D_PHASE2_STRIP - 1) / GI2D_PHASE2_STRIP); }
+
+template <int MODE, int PHASE>
+__global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel(TilePassArgs a) {
+    if (PHASE == 2) {
+        // which slots of the strip were passed over: lane i looks at slot i (ONE round of two dependent loads for the
+        // whole strip -- slot by slot it was sixteen), a ballot makes the answer scalar
+        const int tiles = a.tiles_x * a.tiles_y, lane = threadIdx.x & 63;
+        const int s0 = (int)blockIdx.x * GI2D_PHASE2_STRIP, mine = s0 + lane;
+        const bool big = lane < GI2D_PHASE2_STRIP && mine < tiles && a.big_tile[a.tile_order[mine]] != 0;
+        unsigned long long todo = __ballot(big);
+        while (todo) {  // workgroup-uniform: every wave computed the same mask
+            const int slot = s0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            tile_pass_workgroup<MODE, PHASE>(a, slot, false);
+            __syncthreads();  // the next tile stages into the same LDS
+        }
+    } else {
+        tile_pass_workgroup<MODE, PHASE>(a, (int)blockIdx.x, blockIdx.x == 0);
+    }
 }
 
 // The same pass over the tiles of K images in ONE launch (gi2d_batch.h): workgroup b belongs to image k with
 // tile_start[k] <= b < tile_start[k + 1] and handles that image's tile tile_order[b - tile_start[k]]; everything else
 // is the single-image kernel's code, so every image's results are those of its own launch bit for bit.
-template <int MODE>
-__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kernel(
-    const BatchImage *__restrict__ imgs, const int *__restrict__ tile_start, int k_images, int uniform_tiles,
-    int xcd_map) {
-    __shared__ FusedLds sm;
-    int k, local;
-    if ((int)blockIdx.x < xcd_map * uniform_tiles) {
+__device__ __forceinline__ void batched_slot(int b, const int *__restrict__ tile_start, int k_images, int uniform_tiles,
+                                             int xcd_map, int &k, int &local) {
+    if (b < xcd_map * uniform_tiles) {
         // Images with the same tile count: the first 8 * floor(K / 8) of them (`xcd_map` images) go to the XCDs whole --
         // image k's tiles to the workgroups b with b % 8 == k % 8.  Workgroups are dealt to the eight XCDs round-robin, so
         // one image's records, tile rows and gradient rows stay in ONE XCD's 4 MiB L2 instead of being fetched into all
         // eight (placement is a speed choice only: any mapping is correct).  The K % 8 images left over follow in plain
         // order, spread over all XCDs: giving them an XCD each would leave the other XCDs idle for a whole image (12 images
         // then took the time of 16).
-        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int x = b & 7, j = b >> 3;
         const int slot = j / uniform_tiles;
         k = slot * 8 + x;
         local = j - slot * uniform_tiles;
     } else if (uniform_tiles > 0) {
-        k = (int)blockIdx.x / uniform_tiles;
-        local = (int)blockIdx.x - k * uniform_tiles;
+        k = b / uniform_tiles;
+        local = b - k * uniform_tiles;
     } else {
-        k = batch_find(tile_start, k_images, (int)blockIdx.x);
-        local = (int)blockIdx.x - tile_start[k];
+        k = batch_find(tile_start, k_images, b);
+        local = b - tile_start[k];
     }
     // image and tile are the same for the whole workgroup: say so (the integer divisions above leave them in vector
     // registers, and everything derived from them -- the argument block's loads, the tile's row and column -- would
     // follow: 4 more VGPRs than the single-image kernel, i.e. spills at this kernel's 80-register budget)
     k = __builtin_amdgcn_readfirstlane(k);
     local = __builtin_amdgcn_readfirstlane(local);
-    const TilePassArgs &a = imgs[k].t;
-    int tile;
-    const HeadRow hr = head_row_for(a.lists, a.tile_order, local, tile);
-    const float4 *recs = recs_for_tile_pass(a.rs, local == 0 && threadIdx.x == 0);
-    fused_tile<MODE>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
-                     a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);
+}
+// Batched launches stay single-phase: measured at K = 8 / 24 of 768x512 images, the small form alone is 5 ... 8 % faster
+// per tile it serves, but a scene whose fuller tiles sit above GI2D_SMALL_CAP (9 % of the tiles of tools/batch_time.py's
+// scenes, half of a trained Kodak scene's) hands those to a second launch at lower occupancy, and the look at every
+// slot costs a launch of its own: net +-0 on Kodak, -6 % at K = 24.
+template <int MODE>
+__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kernel(
+    const BatchImage *__restrict__ imgs, const int *__restrict__ tile_start, int k_images, int uniform_tiles,
+    int xcd_map) {
+    int k, local;
+    batched_slot((int)blockIdx.x, tile_start, k_images, uniform_tiles, xcd_map, k, local);
+    tile_pass_workgroup<MODE, 0>(imgs[k].t, local, local == 0);
 }
 
 // --------------------------------------------------------------------------------------- reduce
@@ -416,6 +468,22 @@ static KernelTimer *next_timer() {
     } while (0)
 
 namespace gi2d {
+// A single-image launch of more tiles than the chip holds at once (six general-form workgroups per CU x 256 CUs) runs in
+// two phases: the small form on every tile it can serve, at eight workgroups per CU, then the general form on the rest
+// (2040x1356 at 50 000 gaussians: tile pass 70.2 -> 64.6 us).  One image of up to 1536 tiles (768x512) is a single
+// residency round either way and stays one launch; so do batched launches (see fast_fwdbwd_batched_kernel).
+#ifndef GI2D_TWO_PHASE_TILES
+#define GI2D_TWO_PHASE_TILES (256 * GI2D_FUSED_OCC) /* development aid: a huge value keeps every launch single-phase */
+#endif
+static inline bool two_phase_tile_pass(long long tiles) { return tiles > GI2D_TWO_PHASE_TILES; }
+// one launch with an optional start / stop event (the two phases of a timed tile pass carry one event each)
+template <class K, class... A>
+static void launch_between(K kernel, dim3 grid, dim3 block, hipStream_t st, hipEvent_t begin, hipEvent_t end, A... args) {
+    if (begin || end)
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, st, begin, end, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+}
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
                              hipStream_t st) {
     if (total_blocks <= 0) return GI2D_OK;
@@ -423,12 +491,13 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
 #ifndef GI2D_NO_XCD_MAP /* development aid: what the XCD-aware mapping buys */
     if (uniform_tiles > 0) xcd_map = k_images & ~7;
 #endif
+    const dim3 grid((unsigned)total_blocks), block(256);
+    const BatchImage *imgs = (const BatchImage *)b.img;
+    const int *starts = (const int *)b.head->tile_start;
     if (mode == 0)
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<0>, dim3((unsigned)total_blocks), dim3(256), st,
-                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles, xcd_map);
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<0>, grid, block, st, imgs, starts, k_images, uniform_tiles, xcd_map);
     else
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<1>, dim3((unsigned)total_blocks), dim3(256), st,
-                          (const BatchImage *)b.img, (const int *)b.head->tile_start, k_images, uniform_tiles, xcd_map);
+        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<1>, grid, block, st, imgs, starts, k_images, uniform_tiles, xcd_map);
     return check_launch("batched tile pass");
 }
 }  // namespace gi2d
@@ -621,10 +690,23 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
     TilePassArgs a = tile_pass_args(w, n, tiles_x, tiles_y, (int)w_, (int)h, status, out_img,
                                     v_output ? v_output : target, v_output ? 0.f : grad_scale,
                                     v_output ? nullptr : tile_sse);
-    if (v_output)
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<0>, dim3((unsigned)t), dim3(256), (hipStream_t)st, a);
-    else
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_kernel<1>, dim3((unsigned)t), dim3(256), (hipStream_t)st, a);
+    const dim3 grid((unsigned)t), block(256);
+    if (two_phase_tile_pass(t)) {
+        KernelTimer *tm = next_timer();
+        if (v_output) {
+            launch_between(fast_fwdbwd_kernel<0, 1>, grid, block, (hipStream_t)st, tm ? tm->begin : nullptr, nullptr, a);
+            launch_between(fast_fwdbwd_kernel<0, 2>, dim3(phase2_blocks(t)), block, (hipStream_t)st, nullptr,
+                           tm ? tm->end : nullptr, a);
+        } else {
+            launch_between(fast_fwdbwd_kernel<1, 1>, grid, block, (hipStream_t)st, tm ? tm->begin : nullptr, nullptr, a);
+            launch_between(fast_fwdbwd_kernel<1, 2>, dim3(phase2_blocks(t)), block, (hipStream_t)st, nullptr,
+                           tm ? tm->end : nullptr, a);
+        }
+    } else if (v_output) {
+        GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<0, 0>), grid, block, (hipStream_t)st, a);
+    } else {
+        GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<1, 0>), grid, block, (hipStream_t)st, a);
+    }
     if (background)
         hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
                            status, background, out_img);

@@ -82,6 +82,8 @@ struct FastWs {
                            //                    per gaussian (its box in row-major order), allocated by the binning step
     int32_t *tile_order;   // [T]                tile handled by workgroup b of the single-pass tile kernel: a
                            //                    permutation that balances tile populations over the CUs
+    int32_t *big_tile;     // [T]                two-phase tile pass (gi2d_fast.hip): 1 = the small form passed this tile
+                           //                    over (its row holds more candidates than that form stages), 0 = done
     size_t bytes;
 };
 static FastWs carve_fast(void *base, int n, int num_tiles) {
@@ -99,6 +101,8 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     // lists, tile_order and prev_box carry state from call to call: they sit in front of every region whose offset
     // depends on the gaussian count, so a workspace initialised for a capacity can be used with any smaller population
     w.tile_order = (int32_t *)(b + off);
+    off += align_up(t * sizeof(int32_t));
+    w.big_tile = (int32_t *)(b + off);
     off += align_up(t * sizeof(int32_t));
     w.prev_box = (PrevBox *)(b + off);
     off += align_up(nn * sizeof(PrevBox));

@@ -51,30 +51,40 @@ namespace gi2d {
                             second, 256-workgroup round; 23.7 KB gets 6) */
 #endif
 
-struct FusedLds {
+// CAP: list entries the staging arrays hold.  GI2D_TILE_LIST_CAP (256: forward.cu:553) for the general kernel; the
+// small form (GI2D_SMALL_CAP) serves the tiles whose ROW holds at most that many candidates -- every tile of a
+// 2040x1356 image at 50 000 gaussians, every tile of the uniform bench scene, every tile of a fit's first 45 000
+// iterations -- from 18 KB of LDS and 62 registers instead of 26 KB and 76: EIGHT workgroups per CU instead of six.
+// The tile pass is short of runnable waves, not of issue slots: launches with more tiles than the chip
+// holds at once run the small form first and the general one on the tiles it passed over (gi2d_fast.hip).
+#define GI2D_SMALL_CAP 128
+template <int CAP>
+struct FusedLdsT {
     static constexpr int PSTR = 9;
     static constexpr bool HAS_FIDX = false;
     static constexpr bool HAS_RAW = false;
     static constexpr int PART_ROWS = GI2D_BWD_PART_ROWS;
-    float4 gA[GI2D_TILE_LIST_CAP + 1];  // gx, gy, ha, hb      (entry CAP: the forward's never-contributing padding;
-    float4 gB[GI2D_TILE_LIST_CAP + 1];  // hc, opac, cr, cg     conic pre-scaled: gi2d_common.h::scale_conic)
-    float2 gC[GI2D_TILE_LIST_CAP + 2];  // cb, lim (gi2d_common.h::AlphaRule)
-    unsigned cullw[GI2D_TILE_LIST_CAP]; // cull_word() of the entry
+    static constexpr int LISTLEN = CAP + 8;
+    static constexpr int IDS = CAP == GI2D_TILE_LIST_CAP ? GI2D_FAST_C : CAP;  // candidates of the row the head sorts
+    float4 gA[CAP + 1];  // gx, gy, ha, hb      (entry CAP: the forward's never-contributing padding;
+    float4 gB[CAP + 1];  // hc, opac, cr, cg     conic pre-scaled: gi2d_common.h::scale_conic)
+    float2 gC[CAP + 2];  // cb, lim (gi2d_common.h::AlphaRule)
+    unsigned cullw[CAP]; // cull_word() of the entry
     float sse_w[4];
     int scan_w[8];  // per-wave totals of the backward's item scan (outside the overlay: written during the forward phase)
     int grp[32];    // tile_list_head: survivors per 64 entries (ascending part, appended part)
     union {
         struct {
-            int ids[GI2D_FAST_C];
+            int ids[IDS];
         };
         struct {  // forward phase
-            unsigned char lists[4][2 * GI2D_FWD_LISTLEN];  // per wave: left-half list, right-half list
-            float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats; afterwards the RGB transpose stage
+            unsigned char lists[4][2 * LISTLEN];  // per wave: left-half list, right-half list
+            float4 pairbuf[GI2D_FWD_PAIRBUF];  // 4 waves x GI2D_FWD_PAIRBUF floats
         };
         struct {  // backward phase (member names as BwdLds: bwd_run_tile is shared)
             float4 pix[2 * GI2D_BWD_PIXRECS];
-            unsigned short span[GI2D_TILE_LIST_CAP];
-            unsigned short item[8 * GI2D_TILE_LIST_CAP];
+            unsigned short span[CAP];
+            unsigned short item[8 * CAP];
             float part[GI2D_BWD_PART_ROWS * PSTR];
             int wsum[8];
             int n_items;
@@ -82,32 +92,44 @@ struct FusedLds {
         struct {  // partial-row code of the entry (see fast path: >= 0 gaussian-major, < 0 big): written by the head,
                   // read when the backward starts -- in bytes the forward's buffers do not reach and the backward only
                   // writes in its hand-off (`part`), behind the barrier that follows the reads
-            char fwd_reach[sizeof(unsigned char) * 4 * 2 * GI2D_FWD_LISTLEN + sizeof(float4) * GI2D_FWD_PAIRBUF];
-            int slot[GI2D_TILE_LIST_CAP];
+            char fwd_reach[sizeof(unsigned char) * 4 * 2 * LISTLEN + sizeof(float4) * GI2D_FWD_PAIRBUF];
+            int slot[CAP];
         };
     };
     // rows / columns of entry k's box: its cull word stays staged through both phases
     __device__ __forceinline__ void set_box(int, unsigned) {}
     __device__ __forceinline__ unsigned box_of(int k) const { return cullw[k] >> 8; }
 };
+typedef FusedLdsT<GI2D_TILE_LIST_CAP> FusedLds;
+typedef FusedLdsT<GI2D_SMALL_CAP> FusedLdsSmall;
+#define GI2D_SMALL_OCC 8 /* workgroups per CU of the small form: 62 registers, 18.2 KB */
 
 // measured: 26.5 KB still leaves room for six workgroups per CU, 27.1 KB does not
 static_assert(GI2D_FUSED_OCC < 6 || sizeof(FusedLds) <= 26624,
               "FusedLds: the sixth workgroup per CU needs <= 26 KB (see GI2D_FUSED_OCC)");
+static_assert(sizeof(FusedLdsSmall) <= 160 * 1024 / GI2D_SMALL_OCC - 512, "FusedLdsSmall: eight workgroups per CU need <= 19.5 KB");
+// slot[] must lie inside `part` (dead until the hand-off) in both forms
+static_assert(offsetof(FusedLds, slot) >= offsetof(FusedLds, part) &&
+                  offsetof(FusedLds, slot) + sizeof(int) * GI2D_TILE_LIST_CAP <= offsetof(FusedLds, wsum),
+              "FusedLds: the partial-row codes must overlay the hand-off buffer only");
+static_assert(offsetof(FusedLdsSmall, slot) >= offsetof(FusedLdsSmall, part) &&
+                  offsetof(FusedLdsSmall, slot) + sizeof(int) * GI2D_SMALL_CAP <= offsetof(FusedLdsSmall, wsum),
+              "FusedLdsSmall: the partial-row codes must overlay the hand-off buffer only");
 
 // MODE 0: `vsrc` is the gradient image v_output[H,W,3].
 // MODE 1: `vsrc` is the target image gt[H,W,3]; the pixel gradient is that of mean((clamp(out,0,1) - gt)^2):
 //         grad_scale * (clamp(out) - gt) where the clamp passes gradient (models/gaussianimage_cholesky.py:307-310
 //         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
-template <int MODE>
+template <int MODE, int CAP = GI2D_TILE_LIST_CAP, int FWD_UNROLL = GI2D_FWD_UNROLL>
 __device__ __forceinline__ void fused_tile(
-    FusedLds &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
+    FusedLdsT<CAP> &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
     int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
     float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
     float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse,
     const HeadRow &head_row) {
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int pool_rows = tiles_x * tiles_y * GI2D_TILE_LIST_CAP;  // rows of `partial_big`, the row pool (PrevBox)
+    static_assert(CAP <= GI2D_TILE_LIST_CAP, "at most the reference's 256 entries of a tile are rasterized");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int lx = tid & 15, ly = tid >> 4;  // == (lane & 15, wv * 4 + (lane >> 4)): wave wv owns pixel rows 4wv..4wv+3
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
@@ -125,9 +147,9 @@ __device__ __forceinline__ void fused_tile(
 
     // ---- the tile's row -> validated, ordered, staged list (gi2d_fast_internal.h::tile_list_head)
     if (tid == 0) {
-        sm.gA[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sm.gB[GI2D_TILE_LIST_CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
-        sm.gC[GI2D_TILE_LIST_CAP] = make_float2(0.f, 0.f);            // lim 0: never lands
+        sm.gA[CAP] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sm.gB[CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
+        sm.gC[CAP] = make_float2(0.f, 0.f);            // lim 0: never lands
     }
     GI2D_TRACE(1);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
@@ -135,7 +157,7 @@ __device__ __forceinline__ void fused_tile(
         sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
             const GaussRec &r = br.r;
             const int slot = partial_slot(g, br.box, tx, ty, br.pool);
-            if (rank < GI2D_TILE_LIST_CAP) {
+            if (rank < CAP) {  // (the small form only sees rows of at most CAP candidates: always)
                 const ConicS cs = scale_conic(r.a, r.b, r.c);
                 sm.gA[rank] = make_float4(r.gx, r.gy, cs.ha, cs.hb);
                 sm.gB[rank] = make_float4(cs.hc, r.opac, r.cr, r.cg);
@@ -157,7 +179,7 @@ __device__ __forceinline__ void fused_tile(
 #endif
     // records staged and every lane done with sm.ids (tile_list_head<true> returns behind its last barrier): the overlay
     // may now hold the forward's buffers
-    const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
+    const int len = L > CAP ? CAP : L;
     GI2D_TRACE(3);
 
     // ---- forward (the routine every forward kernel shares: gi2d_raster_core.h::fwd_pixel_half_lists)
@@ -165,7 +187,7 @@ __device__ __forceinline__ void fused_tile(
     float o0, o1, o2;
     int last_unused;
     GI2D_TRACE(4);
-    fwd_pixel_half_lists<false>(
+    fwd_pixel_half_lists<false, CAP, FWD_UNROLL>(
         sm.lists[wv], mybuf, len, [&](int k) { return sm.cullw[k]; },
         [&](int k) {
             const float4 A = sm.gA[k], B = sm.gB[k];

@@ -101,11 +101,14 @@ struct FwdRec {  // one staged entry as the pixel loop consumes it (conic pre-sc
     unsigned lim;  // AlphaRule::lim
 };
 
-template <bool NEED_FIDX, bool CLAMP>
+#ifndef GI2D_FWD_UNROLL
+#define GI2D_FWD_UNROLL 2 /* trips per loop body: two let the LDS reads of one trip overlap the arithmetic of the other */
+#endif
+template <bool NEED_FIDX, bool CLAMP, int UNROLL = GI2D_FWD_UNROLL>
 __device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px2, const v2f py2, v2f &a0, v2f &a1,
                                           v2f &a2, int &last) {
     constexpr int PF = GI2D_FWD_PF(NEED_FIDX);
-#pragma unroll 2
+#pragma unroll UNROLL
     for (int t = 0; t < m; t += 2) {
         const float4 *q = reinterpret_cast<const float4 *>(mine + (t >> 1) * PF);
         const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
@@ -136,13 +139,14 @@ __device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px
 // wave (16-byte aligned).  cull_of(k) -> cull_word of entry k, rec_of(k) -> FwdRec of entry k (k == GI2D_FWD_DUMMY must
 // give an entry that never lands: lim 0).  Returns the pixel in o0..o2 and, with NEED_FIDX, the last contributing entry
 // (-1: none).
-template <bool NEED_FIDX, class CullOf, class RecOf>
+// CAP: entries the caller's staging arrays hold (the lists are CAP + 8 bytes each, entry CAP is the padding entry).
+template <bool NEED_FIDX, int CAP = GI2D_TILE_LIST_CAP, int UNROLL = GI2D_FWD_UNROLL, class CullOf, class RecOf>
 __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float *buf, int len, CullOf cull_of,
                                                      RecOf rec_of, float px, float py, float &o0, float &o1,
                                                      float &o2, int &last_k) {
     constexpr int PF = GI2D_FWD_PF(NEED_FIDX), HALF = GI2D_FWD_HALF_OF(NEED_FIDX);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned char *left = lists, *right = lists + GI2D_FWD_LISTLEN;
+    unsigned char *left = lists, *right = lists + (CAP + 8);
     int n_left = 0, n_right = 0;
     bool clamp_any = false;  // wave-uniform
     for (int base = 0; base < len; base += 64) {
@@ -173,7 +177,7 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
     for (int c0 = 0; c0 < n_max; c0 += GI2D_FWD_CHUNK) {
         {
             const int e = c0 + be;
-            const int k = e < bcnt ? (int)blist[e] : GI2D_FWD_DUMMY;
+            const int k = e < bcnt ? (int)blist[e] : CAP;  // entry CAP: the never-landing padding entry
             const FwdRec r = rec_of(k);
             bdst[0] = r.gx;
             bdst[2] = r.gy;
@@ -194,9 +198,9 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
         const int m = min(GI2D_FWD_CHUNK, n_max - c0);
 #endif
         if (clamp_any)
-            fwd_trips<NEED_FIDX, true>(mine, m, px2, py2, a0, a1, a2, last);
+            fwd_trips<NEED_FIDX, true, UNROLL>(mine, m, px2, py2, a0, a1, a2, last);
         else
-            fwd_trips<NEED_FIDX, false>(mine, m, px2, py2, a0, a1, a2, last);
+            fwd_trips<NEED_FIDX, false, UNROLL>(mine, m, px2, py2, a0, a1, a2, last);
         __builtin_amdgcn_wave_barrier();
     }
     o0 = a0.x + a0.y;

@@ -489,3 +489,45 @@ def test_slowly_growing_gaussians_do_not_leak_the_row_pool():
     print(f"row pool: {cursor} rows handed out over {steps} steps for {peak_live} live rows (pool {pool_rows})")
     assert cursor <= 7 * peak_live, (cursor, peak_live)
     assert cursor < 0.5 * pool_rows
+
+
+def test_two_phase_tile_pass_on_a_large_image_with_crowded_tiles_equals_the_exact_path():
+    """An image of more tiles than the chip holds at once (here 64 x 40 = 2560 > 1536) runs its single-pass tile kernel in
+    two phases (csrc/gi2d_fast.hip): the small form (128 staged entries, eight workgroups per CU) on the tiles whose
+    row holds at most 128 candidates, the general form on the ones it passed over.  A scene with both kinds of tile --
+    a sparse background and three crowded regions with 130 ... 700 gaussians per tile, above and below the 256-entry
+    cap -- must come out bit for bit as the capacity-free ops compute it, in the given-gradient and the L2-target mode,
+    and again after the gaussians have moved (rows with appended and departed entries)."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    h, w = 640, 1024
+    n_bg, n_cl = 9000, 6000
+    rng = np.random.default_rng(77)
+    xyz_b, L_b, col_b, op_b = synth_cholesky(n_bg, h, w, 78)
+    centres = np.array([[-0.5, -0.4], [0.3, 0.5], [0.7, -0.6]], np.float32)
+    which = rng.integers(0, 3, n_cl)
+    spread = np.array([0.06, 0.03, 0.025], np.float32)[which][:, None]
+    xyz_c = (centres[which] + rng.normal(size=(n_cl, 2)).astype(np.float32) * spread).clip(-0.98, 0.98)
+    L_c = np.stack([rng.uniform(0.4, 1.2, n_cl), rng.uniform(-0.2, 0.2, n_cl), rng.uniform(0.4, 1.2, n_cl)], 1).astype(np.float32)
+    col_c = rng.uniform(0, 0.02, (n_cl, 3)).astype(np.float32)
+    xyz, L = np.concatenate([xyz_b, xyz_c]), np.concatenate([L_b, L_c])
+    col, op = np.concatenate([col_b, col_c]), np.ones((n_bg + n_cl, 1), np.float32)
+    n = n_bg + n_cl
+    fused = HotPath(n, h, w, device=DEV, mode="fused")
+    exact = HotPath(n, h, w, device=DEV, mode="exact")
+    assert fused.T > 1536
+    v = _v_out(h, w, 5)
+    for step in range(3):
+        if step:
+            xyz = (xyz + rng.normal(size=xyz.shape).astype(np.float32) * 0.004).clip(-0.98, 0.98)
+        for hp in (fused, exact):
+            hp.set_inputs(xyz, L, col, op)
+            hp.set_v_out(v)
+            hp.step(pipelined=False)
+            hp.check_status()
+        ids, tbins = fused.tile_lists()
+        pop = (tbins[:, 1] - tbins[:, 0]).cpu().numpy()
+        assert (pop > 256).sum() >= 3 and ((pop > 128) & (pop <= 256)).sum() >= 5 and (pop <= 128).mean() > 0.9, \
+            "the scene must have tiles on both sides of the small form's capacity and of the 256-entry cap"
+        for a, b in ((fused.out_img, exact.out_img), (fused.v_params, exact.v_params), (fused.v_mean2d, exact.v_mean2d),
+                     (fused.v_rgb, exact.v_rgb), (fused.v_opac, exact.v_opac)):
+            assert torch.equal(a, b), step
