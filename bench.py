@@ -363,6 +363,10 @@ def batched_rate(n, h, w, dev, ks=(4, 8, 24), iters=60):
         torch.cuda.synchronize(dev)
         kus = timers.us()
         timers.close()
+        # which form those passes took (include/gi2d.h: gi2d_batch_tile_pass_form; decided from the previous call's report)
+        two = bool(_lib.load().gi2d_batch_tile_pass_form(b.table.data_ptr()))
+        kname = ("gi2d::fast_fwdbwd_batched_kernel<1, 1> + gi2d::fast_fwdbwd_batched_kernel<1, 2>" if two
+                 else "gi2d::fast_fwdbwd_batched_kernel<1, 0>")
         for f in fits:
             f.check_status()
         m = [int(f.nth[:n].sum().item()) for f in fits]
@@ -371,12 +375,14 @@ def batched_rate(n, h, w, dev, ks=(4, 8, 24), iters=60):
         out.append({"images_per_launch": k, "image_iters_per_s": k * 1e6 / us, "us_per_batch_iteration": us,
                     "us_per_image_iteration": us / k, "tile_pass_kernel_us": avg,
                     "tile_pass_us_per_image": avg / k, "algorithmic_bytes_per_launch": nbytes,
-                    "roofline": {"bound": "hbm", "kernel": "gi2d::fast_fwdbwd_batched_kernel<1>",
+                    "tile_pass_form": "two launches (small form, then general form on fuller tiles)" if two
+                    else "one launch (general form)",
+                    "roofline": {"bound": "hbm", "kernel": kname,
                                  "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                 "traffic": pmc_traffic("gi2d::fast_fwdbwd_batched_kernel<1>", n, h, w, k)[0],
-                                 "traffic_source": pmc_traffic("gi2d::fast_fwdbwd_batched_kernel<1>", n, h, w, k)[1]},
-                    "roofline_valu": valu_roofline("gi2d::fast_fwdbwd_batched_kernel<1>", n, h, w, avg, k),
+                                 "traffic": pmc_traffic(kname, n, h, w, k)[0],
+                                 "traffic_source": pmc_traffic(kname, n, h, w, k)[1]},
+                    "roofline_valu": valu_roofline(kname, n, h, w, avg, k),
                     "num_intersects_mean": float(np.mean(m))})
         del b, fits
         torch.cuda.empty_cache()

@@ -63,6 +63,7 @@ SIGNATURES.update({
     # several images per launch: host array of struct gi2d_train_state* / of struct gi2d_fast_image
     "gi2d_train_steps_batched": [_i, _p, _p, _sz, _p, C.c_double, C.c_double, _f, _i, _i, _p],
     "gi2d_fast_rasterize_forward_backward_batched": [_i, _p, _p, _sz, _p],
+    "gi2d_batch_tile_pass_form": [_p],
     "gi2d_train_prune": [_p, _p, _sz, _p, _p],
     "gi2d_train_grow": [_p, _i, _i, _p, _i, _p, _sz, _p, _p],
     # quantisers: struct gi2d_quant_spec* (gaussianimage_plus_amd/quantize.py::_QuantSpec)
@@ -101,6 +102,14 @@ def load() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
             "gaussianimage_plus_amd/csrc`). There is no CPU fallback for this path.")
     lib = C.CDLL(LIB_PATH)
+    for name in STRING_FUNCS:
+        getattr(lib, name).restype = C.c_char_p
+    ver = lib.gi2d_version().decode()  # first: a development build is named before any of its symbols is looked up
+    if "dev[" in ver and os.environ.get("GI2D_ALLOW_DEV_BUILD") != "1":
+        raise RuntimeError(
+            f"{LIB_PATH} is a development build ({ver}): cut-off / knock-out switches give wrong results on purpose. "
+            "Rebuild with `make -C gaussianimage_plus_amd/csrc` (no EXTRA), or set GI2D_ALLOW_DEV_BUILD=1 for a "
+            "measurement script that knows what it loads.")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -109,14 +118,6 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t
-    for name in STRING_FUNCS:
-        getattr(lib, name).restype = C.c_char_p
-    ver = lib.gi2d_version().decode()
-    if "dev[" in ver and os.environ.get("GI2D_ALLOW_DEV_BUILD") != "1":
-        raise RuntimeError(
-            f"{LIB_PATH} is a development build ({ver}): cut-off / knock-out switches give wrong results on purpose. "
-            "Rebuild with `make -C gaussianimage_plus_amd/csrc` (no EXTRA), or set GI2D_ALLOW_DEV_BUILD=1 for a "
-            "measurement script that knows what it loads.")
     _lib = lib
     return lib
 

@@ -134,7 +134,13 @@ struct BatchImage {
 // Device layout of a batch table: [0, 65) tile-pass workgroup index at which image k starts (entry K = total),
 // [128, 193) the same for the per-gaussian kernels, then the K argument blocks.
 struct BatchHead {
-    int tile_start[128];
+    int tile_start[96];  // GI2D_BATCH_MAX + 1 used
+    // How many tiles of the batch had a row above GI2D_SMALL_CAP candidates in the last tile pass of the current call
+    // (counted from the passes' marks when the call ends; the table is rewritten, and this word cleared, when a call
+    // starts): read back behind the call's kernels, it tells the NEXT call on this table whether the two-phase tile
+    // pass pays (gi2d_fast.hip::batch_pass_begin).  A hint: never a correctness input.
+    int big_seen;
+    int reserved[31];
     int pg_start[128];
 };
 struct BatchTable {
@@ -164,7 +170,12 @@ void write_batch_table(const BatchTable &table, const BatchImage *imgs, int k_im
                        hipStream_t st);
 // gi2d_fast.hip: the batched single-pass tile kernel (MODE 1: L2-loss gradient against t.vsrc = target) over
 // `total_blocks` = head->tile_start[K] workgroups; uniform_tiles > 0: every image has that many tiles.
+// `two_phase`: small form on every tile it can serve, general form on the rest (batch_pass_begin says when).
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
-                             hipStream_t st);
+                             bool two_phase, hipStream_t st);
+// Bracket of one C-ABI call's batched tile passes on table `batch`: _begin answers "two-phase?" from what the previous
+// call on the same table reported (without waiting for anything), _end queues the read-back of this call's report.
+bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st);
+void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st);
 
 }  // namespace gi2d

@@ -24,7 +24,11 @@
 // Capacity contract: at most GI2D_FAST_C (1024) candidates per tile row, of which the 256 lowest ids are
 // rasterized (forward.cu:553).  A fuller row sets status[1] and the caller must fall back to the exact path
 // (gi2d_bin_gaussians + plain ops) and re-initialise the workspace.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -221,8 +225,9 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 //          whose row holds at most that many candidates; a fuller row is only marked (`big_tile`) ...
 // PHASE 2: ... and handled by the general form in a second launch whose other workgroups return at once.
 // The per-tile code is the same template (fused_tile<MODE, CAP>), so a tile's results do not depend on the phase.
+// `mark_big` (batched launches): the general form marks the rows above GI2D_SMALL_CAP too -- batch_pass_end counts them.
 template <int MODE, int PHASE>
-__device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int slot, bool first) {
+__device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int slot, bool first, bool mark_big = false) {
     constexpr int CAP = PHASE == 1 ? GI2D_SMALL_CAP : GI2D_TILE_LIST_CAP;
     __shared__ FusedLdsT<CAP> sm;
     int tile;
@@ -233,10 +238,10 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
     } else {
         hr = head_row_for(a.lists, a.tile_order, slot, tile);
     }
-    if (PHASE == 1) {
+    if (PHASE == 1 || (PHASE == 0 && mark_big)) {
         const bool big = __builtin_amdgcn_readfirstlane(hr.hdr_count) > GI2D_SMALL_CAP;  // workgroup-uniform
         if (threadIdx.x == 0) a.big_tile[tile] = big ? 1 : 0;
-        if (big) return;
+        if (PHASE == 1 && big) return;
     }
     const float4 *recs = recs_for_tile_pass(a.rs, first && threadIdx.x == 0);
     // (phase 2 loops over tiles: its loop keeps the lane's invariants alive, so the forward's trips are not unrolled there)
@@ -304,17 +309,75 @@ __device__ __forceinline__ void batched_slot(int b, const int *__restrict__ tile
     k = __builtin_amdgcn_readfirstlane(k);
     local = __builtin_amdgcn_readfirstlane(local);
 }
-// Batched launches stay single-phase: measured at K = 8 / 24 of 768x512 images, the small form alone is 5 ... 8 % faster
-// per tile it serves, but a scene whose fuller tiles sit above GI2D_SMALL_CAP (9 % of the tiles of tools/batch_time.py's
-// scenes, half of a trained Kodak scene's) hands those to a second launch at lower occupancy, and the look at every
-// slot costs a launch of its own: net +-0 on Kodak, -6 % at K = 24.
-template <int MODE>
-__global__ __launch_bounds__(256, GI2D_FUSED_OCC) void fast_fwdbwd_batched_kernel(
-    const BatchImage *__restrict__ imgs, const int *__restrict__ tile_start, int k_images, int uniform_tiles,
+// The lane's own (image, slot) of workgroup index b -- phase 2 looks at a strip of them at once.
+__device__ __forceinline__ void batched_slot_of_lane(int b, const int *__restrict__ tile_start, int k_images,
+                                                     int uniform_tiles, int xcd_map, int &k, int &local) {
+    if (b < xcd_map * uniform_tiles) {
+        const int x = b & 7, j = b >> 3, slot = j / uniform_tiles;
+        k = slot * 8 + x;
+        local = j - slot * uniform_tiles;
+    } else if (uniform_tiles > 0) {
+        k = b / uniform_tiles;
+        local = b - k * uniform_tiles;
+    } else {
+        int lo = 0, hi = k_images;  // tile_start[lo] <= b < tile_start[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tile_start[mid] <= b) lo = mid; else hi = mid;
+        }
+        k = lo;
+        local = b - tile_start[lo];
+    }
+}
+// PHASE as in fast_fwdbwd_kernel.  Measured at K = 8 / 24 of 768x512 images: the small form is 5 ... 8 % faster per
+// tile it serves, but a scene whose fuller tiles sit above GI2D_SMALL_CAP (9 % of the tiles of tools/batch_time.py's
+// scenes, half of a trained Kodak scene's) hands those to a second launch at lower occupancy (net -6 % at K = 24), so
+// the two-phase form is used on a batch only while no row of it is that full -- batch_pass_begin.
+template <int MODE, int PHASE>
+__global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_batched_kernel(
+    const BatchImage *__restrict__ imgs, const BatchHead *__restrict__ head, int k_images, int uniform_tiles,
     int xcd_map) {
+    const int *tile_start = head->tile_start;
     int k, local;
-    batched_slot((int)blockIdx.x, tile_start, k_images, uniform_tiles, xcd_map, k, local);
-    tile_pass_workgroup<MODE, 0>(imgs[k].t, local, local == 0);
+    if (PHASE == 2) {
+        const int total = uniform_tiles > 0 ? k_images * uniform_tiles : tile_start[k_images], lane = threadIdx.x & 63;
+        const int s0 = (int)blockIdx.x * GI2D_PHASE2_STRIP, mine = s0 + lane;
+        bool big = false;
+        if (lane < GI2D_PHASE2_STRIP && mine < total) {
+            batched_slot_of_lane(mine, tile_start, k_images, uniform_tiles, xcd_map, k, local);
+            const TilePassArgs &t = imgs[k].t;
+            big = t.big_tile[t.tile_order[local]] != 0;
+        }
+        unsigned long long todo = __ballot(big);
+        while (todo) {
+            const int b = s0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            batched_slot(b, tile_start, k_images, uniform_tiles, xcd_map, k, local);
+            tile_pass_workgroup<MODE, PHASE>(imgs[k].t, local, false);
+            __syncthreads();
+        }
+    } else {
+        batched_slot((int)blockIdx.x, tile_start, k_images, uniform_tiles, xcd_map, k, local);
+        tile_pass_workgroup<MODE, PHASE>(imgs[k].t, local, local == 0, true);
+    }
+}
+
+// How many tiles of the batch the last tile pass marked as too full for the small form: one number per call, read back
+// behind the call's kernels (batch_pass_end).  head->big_seen is zero when the call starts (write_batch_table).
+__global__ __launch_bounds__(256) void batch_count_big_kernel(const BatchImage *__restrict__ imgs,
+                                                              BatchHead *__restrict__ head, int k_images) {
+    const int total = head->tile_start[k_images];
+    int mine = 0;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < total; b += gridDim.x * 256) {
+        int lo = 0, hi = k_images;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (head->tile_start[mid] <= b) lo = mid; else hi = mid;
+        }
+        mine += imgs[lo].t.big_tile[b - head->tile_start[lo]] != 0;
+    }
+    const int upto = wave_inclusive_scan(mine);
+    if ((threadIdx.x & 63) == 63 && upto) atomicAdd(&head->big_seen, upto);
 }
 
 // --------------------------------------------------------------------------------------- reduce
@@ -485,7 +548,7 @@ static void launch_between(K kernel, dim3 grid, dim3 block, hipStream_t st, hipE
         hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
 }
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
-                             hipStream_t st) {
+                             bool two_phase, hipStream_t st) {
     if (total_blocks <= 0) return GI2D_OK;
     int xcd_map = 0;  // images placed on the XCDs whole (see the kernel): a multiple of 8
 #ifndef GI2D_NO_XCD_MAP /* development aid: what the XCD-aware mapping buys */
@@ -493,12 +556,98 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
 #endif
     const dim3 grid((unsigned)total_blocks), block(256);
     const BatchImage *imgs = (const BatchImage *)b.img;
-    const int *starts = (const int *)b.head->tile_start;
-    if (mode == 0)
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<0>, grid, block, st, imgs, starts, k_images, uniform_tiles, xcd_map);
-    else
-        GI2D_LAUNCH_TIMED(fast_fwdbwd_batched_kernel<1>, grid, block, st, imgs, starts, k_images, uniform_tiles, xcd_map);
+    if (two_phase) {
+        KernelTimer *tm = next_timer();
+        const dim3 grid2(phase2_blocks(total_blocks));
+        if (mode == 0) {
+            launch_between((fast_fwdbwd_batched_kernel<0, 1>), grid, block, st, tm ? tm->begin : nullptr, nullptr, imgs,
+                           b.head, k_images, uniform_tiles, xcd_map);
+            launch_between((fast_fwdbwd_batched_kernel<0, 2>), grid2, block, st, nullptr, tm ? tm->end : nullptr, imgs,
+                           b.head, k_images, uniform_tiles, xcd_map);
+        } else {
+            launch_between((fast_fwdbwd_batched_kernel<1, 1>), grid, block, st, tm ? tm->begin : nullptr, nullptr, imgs,
+                           b.head, k_images, uniform_tiles, xcd_map);
+            launch_between((fast_fwdbwd_batched_kernel<1, 2>), grid2, block, st, nullptr, tm ? tm->end : nullptr, imgs,
+                           b.head, k_images, uniform_tiles, xcd_map);
+        }
+    } else if (mode == 0) {
+        GI2D_LAUNCH_TIMED((fast_fwdbwd_batched_kernel<0, 0>), grid, block, st, imgs, b.head, k_images, uniform_tiles,
+                          xcd_map);
+    } else {
+        GI2D_LAUNCH_TIMED((fast_fwdbwd_batched_kernel<1, 0>), grid, block, st, imgs, b.head, k_images, uniform_tiles,
+                          xcd_map);
+    }
     return check_launch("batched tile pass");
+}
+
+// ---- which form the next call's batched tile passes take (see BatchHead::big_seen)
+// One record per batch table the process has used (keyed by its device address; a freed table's record is reused by
+// whatever is allocated there next, which costs at most one call in the slower form).
+struct BatchHint {
+    int *host = nullptr;  // pinned: where the report of the last call lands
+    hipEvent_t landed = nullptr;
+    bool pending = false;
+    int total = 0;  // tiles of the batch when that report was queued
+    int last = -1;  // tiles above GI2D_SMALL_CAP in the last pass of the last call that reported; -1: nothing known yet
+};
+static std::mutex g_hint_mu;
+static std::unordered_map<const void *, BatchHint> g_hints;
+// GI2D_BATCH_TILE_PASS = general | two-phase | auto (default): tests force either form
+static int batch_pass_override() {
+    static const int v = [] {
+        const char *e = std::getenv("GI2D_BATCH_TILE_PASS");
+        if (!e) return -1;
+        return !std::strcmp(e, "two-phase") ? 1 : !std::strcmp(e, "general") ? 0 : -1;
+    }();
+    return v;
+}
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+// Two launches pay while the general form has next to nothing to do: the tiles it gets run at four workgroups per CU,
+// eight slots to a workgroup (measured: 9 % of the tiles there cost more than the small form saves on the rest).
+#define GI2D_BATCH_BIG_SHARE 50 /* two-phase up to one tile in 50 above GI2D_SMALL_CAP */
+bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st) {
+    const int forced = batch_pass_override();
+    if (forced >= 0) return forced == 1;
+    if (stream_is_capturing(st)) return false;  // a captured call takes the form that is never slow
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    BatchHint &h = g_hints[batch];
+    if (h.pending && hipEventQuery(h.landed) == hipSuccess) {
+        h.last = *h.host;
+        h.pending = false;
+    }
+#ifdef GI2D_BATCH_LOG /* development aid: one line per call */
+    fprintf(stderr, "[gi2d batch %p] tiles %d, above the small form's capacity at the last report: %d\n", batch,
+            total_blocks, h.last);
+#endif
+    return h.last >= 0 && (long long)h.last * GI2D_BATCH_BIG_SHARE <= total_blocks;
+}
+void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st) {
+    if (batch_pass_override() >= 0 || total_blocks <= 0 || stream_is_capturing(st)) return;
+    const BatchHead *head = b.head;
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    BatchHint &h = g_hints[batch];
+    if (h.pending) {  // the previous report has not been looked at: is it there by now?
+        if (hipEventQuery(h.landed) != hipSuccess) return;  // still in flight: its buffer is not ours to overwrite yet
+        h.last = *h.host;
+        h.pending = false;
+    }
+    if (!h.host && (hipHostMalloc((void **)&h.host, sizeof(int), hipHostMallocDefault) != hipSuccess ||
+                    hipEventCreateWithFlags(&h.landed, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipGetLastError();  // no hint, no two-phase passes: nothing else depends on it
+        h.host = nullptr;
+        return;
+    }
+    const int blocks = (total_blocks + 255) / 256;
+    hipLaunchKernelGGL(batch_count_big_kernel, dim3((unsigned)(blocks < 64 ? blocks : 64)), dim3(256), 0, st,
+                       (const BatchImage *)b.img, b.head, k_images);
+    if (hipMemcpyAsync(h.host, &head->big_seen, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+        hipEventRecord(h.landed, st) == hipSuccess)
+        h.pending = true, h.total = total_blocks;
+    else
+        (void)hipGetLastError();
 }
 }  // namespace gi2d
 
@@ -713,6 +862,20 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
     return check_launch("fast rasterize forward+backward");
 }
 
+int gi2d_batch_tile_pass_form(const void *batch) {
+    const int forced = batch_pass_override();
+    if (forced >= 0) return forced;
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    const auto it = g_hints.find(batch);
+    if (it == g_hints.end()) return 0;
+    BatchHint &h = it->second;
+    if (h.pending && hipEventQuery(h.landed) == hipSuccess) {
+        h.last = *h.host;
+        h.pending = false;
+    }
+    return h.last >= 0 && (long long)h.last * GI2D_BATCH_BIG_SHARE <= h.total ? 1 : 0;
+}
+
 int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast_image *images, void *batch,
                                                  size_t batch_bytes, gi2d_stream_t st) {
     if (num_images < 1 || num_images > GI2D_BATCH_MAX || !images) {
@@ -759,7 +922,11 @@ int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast
     head.tile_start[num_images] = blocks;
     BatchTable b = carve_batch(batch, num_images);
     write_batch_table(b, host_imgs.data(), num_images, head, (hipStream_t)st);
-    return launch_tile_pass_batched(given ? 0 : 1, b, num_images, blocks, uniform ? tiles0 : 0, (hipStream_t)st);
+    const bool two_phase = batch_pass_begin(batch, blocks, (hipStream_t)st);
+    const int rc = launch_tile_pass_batched(given ? 0 : 1, b, num_images, blocks, uniform ? tiles0 : 0, two_phase,
+                                            (hipStream_t)st);
+    batch_pass_end(batch, b, num_images, blocks, (hipStream_t)st);
+    return rc;
 }
 
 int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h,

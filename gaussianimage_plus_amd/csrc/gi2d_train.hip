@@ -1673,6 +1673,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
     head.tile_start[num_images] = tile_blocks;
     head.pg_start[num_images] = pg_blocks;
     write_batch_table(b, host_imgs.data(), num_images, head, st);
+    const bool two_phase = batch_pass_begin(batch, tile_blocks, st);
     const BatchImage *imgs = b.img;
     const int *pg_start = b.head->pg_start;
     const dim3 gg((unsigned)pg_blocks), bb(bs);
@@ -1692,7 +1693,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
                 hipLaunchKernelGGL(train_project_fill_quant_batched_kernel<2>, gg, bb, 0, st, imgs, pg_start, num_images);
             else
                 hipLaunchKernelGGL(train_project_fill_quant_batched_kernel<1>, gg, bb, 0, st, imgs, pg_start, num_images);
-            int rc = launch_tile_pass_batched(1, b, num_images, tile_blocks, uniform ? tiles0 : 0, st);
+            int rc = launch_tile_pass_batched(1, b, num_images, tile_blocks, uniform ? tiles0 : 0, two_phase, st);
             if (rc != GI2D_OK) return rc;
             AdamStep a[3], aq[3];
             for (int k = 0; k < 3; ++k) {
@@ -1711,6 +1712,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
                                    aq[1], aq[2], step);
             }
         }
+        batch_pass_end(batch, b, num_images, tile_blocks, st);
         return check_launch("train steps (batched, quantised)");
     }
     if (s0->kind == 2)
@@ -1721,7 +1723,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
         hipLaunchKernelGGL(train_project_fill_batched_kernel<kCovariance>, gg, bb, 0, st, imgs, pg_start, num_images);
     for (int it = 0; it < count; ++it) {
         const int step = first_step + it;
-        int rc = launch_tile_pass_batched(1, b, num_images, tile_blocks, uniform ? tiles0 : 0, st);
+        int rc = launch_tile_pass_batched(1, b, num_images, tile_blocks, uniform ? tiles0 : 0, two_phase, st);
         if (rc != GI2D_OK) return rc;
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s0->beta3, eps, step, adan_opt);
@@ -1732,6 +1734,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
         GI2D_DISPATCH_RU(s0->kind, more, adan_opt);
 #undef GI2D_LAUNCH_RU
     }
+    batch_pass_end(batch, b, num_images, tile_blocks, st);
     return check_launch("train steps (batched)");
 }
 

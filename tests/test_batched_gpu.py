@@ -314,3 +314,64 @@ def test_best_model_error_of_a_large_image_is_the_sum_of_its_tile_errors():
     want = float(f.tile_sse.double().sum())
     got = float(f.best_sse[1 if f.best_sse[1] < float("inf") else 0])
     assert abs(got - want) <= 1e-5 * want, (got, want)
+
+
+def _placed_fitters(scenes):
+    """Cholesky-model fitters on hand-placed gaussians: (h, w, n_sparse, n_cluster) -- n_sparse small gaussians (about
+    3 px, a dozen candidates per tile) spread over the image, n_cluster more piled into one tile."""
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    out = []
+    for i, (h, w, n_sparse, n_cluster) in enumerate(scenes):
+        rng = np.random.default_rng(900 + i)
+        n = n_sparse + n_cluster
+        u = rng.uniform(-0.98, 0.98, (n, 2))
+        if n_cluster:  # inside the tile at pixel (40 .. 48, 40 .. 48)
+            u[n_sparse:, 0] = (rng.uniform(40, 48, n_cluster) + 0.5) / (0.5 * w) - 1.0
+            u[n_sparse:, 1] = (rng.uniform(40, 48, n_cluster) + 0.5) / (0.5 * h) - 1.0
+        L = np.stack([rng.uniform(0.8, 1.6, n), rng.uniform(-0.3, 0.3, n), rng.uniform(0.8, 1.6, n)], 1)
+        init = {"xyz": torch.from_numpy(np.arctanh(u).astype(np.float32)), "chol": torch.from_numpy(L.astype(np.float32)),
+                "feat": torch.from_numpy(rng.uniform(0, 0.2, (n, 3)).astype(np.float32)),
+                "bound": torch.tensor([0.5, 0.0, 0.5])}
+        out.append(NativeFitter(synthetic_image(h, w, 70 + i).to(DEV), n, kind="cholesky", lr=1e-3, seed=5, init=init))
+    return out
+
+
+def test_batched_tile_pass_forms_give_the_same_bits_and_follow_the_reported_row_sizes():
+    """gi2d_batch_tile_pass_form (include/gi2d.h): the first call on a table runs the general form; its report -- tiles
+    with more than 128 candidates -- decides the next call's.  A batch with a handful of crowded tiles (600 gaussians in
+    one tile of 1536) takes the two-launch form, whose second launch then has real work; a batch whose every tile is
+    crowded stays with the general form.  Either way every image's state equals the single-image calls' bit for bit."""
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    lib = _lib.load()
+    sparse = [(384, 512, 2500, 600), (512, 384, 2500, 0)]
+    alone, together = _placed_fitters(sparse), _placed_fitters(sparse)
+    batch = BatchFitter(together)
+    form = lambda b: int(lib.gi2d_batch_tile_pass_form(C.c_void_p(b.table.data_ptr())))
+    assert form(batch) == 0  # nothing known about this table yet
+    forms = []
+    for count in (2, 3, 4):
+        for f in alone:
+            f.train(count)
+        batch.train(count)
+        torch.cuda.synchronize()
+        forms.append(form(batch))
+    assert forms == [1, 1, 1], forms  # i.e. the calls of 3 and 4 iterations ran as two launches
+    for i, (a, b) in enumerate(zip(alone, together)):
+        a.check_status(), b.check_status()
+        _assert_same(a, b, f"two-launch form, image {i}")
+    assert int(together[0].status[3]) >= 512, "the crowded tile is what the second launch is for"
+
+    crowded = [(64, 64, 3000, 0), (64, 80, 3500, 0)]
+    alone, together = _placed_fitters(crowded), _placed_fitters(crowded)
+    batch = BatchFitter(together)
+    for count in (2, 3):
+        for f in alone:
+            f.train(count)
+        batch.train(count)
+        torch.cuda.synchronize()
+        assert form(batch) == 0
+    for i, (a, b) in enumerate(zip(alone, together)):
+        a.check_status(), b.check_status()
+        _assert_same(a, b, f"general form, image {i}")

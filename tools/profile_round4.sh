@@ -5,7 +5,8 @@
 #   gpurun --timeout 1200 -- 'bash tools/profile_round4.sh'      then      python tools/make_profiles4.py
 # workloads: head    bench.py's timed loop (Cholesky, N=50 000, 768x512, training iterations)
 #            c4      the same at 2040x1356 (BASELINE config 4)
-#            batched 24 images per launch (tools/batch_time.py, N=50 000)
+#            batched 24 images per launch (bench.py's `batched` block: tools/batched_bench_scene.py; timings without the
+#                    profiler for K = 4 / 8 / 24 on tools/batch_time.py's scenes)
 #            c5      rotation-scale model, quantisation-aware iterations, N=30 000 (tools/quant_time.py)
 #            fit     24 Kodak images x 10 000 iterations as one batch (tools/kodak_fit.py): trained scenes, prune / grow
 #            frozen  bench scene with frozen parameters (tools/static_steps.py): the instruction-count yardstick
@@ -42,11 +43,11 @@ stats c4 $REPO/bench.py $C4
 for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc c4 $1 "$2" $REPO/bench.py $C4 --steps 20 --warmup 5; done
 pmc c4 sq1 "$SQ1" $REPO/bench.py $C4 --steps 20 --warmup 5
 echo "c4 done"
-stats batched $REPO/tools/batch_time.py 50000 512 768 cholesky 24
+stats batched $REPO/tools/batched_bench_scene.py 24
 python3 $REPO/tools/batch_time.py 50000 512 768 cholesky 4 8 24 > $OUT/batched_plain.out 2>&1 || true
-for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc batched $1 "$2" $REPO/tools/batch_time.py 50000 512 768 cholesky 24; done
-pmc batched sq1 "$SQ1" $REPO/tools/batch_time.py 50000 512 768 cholesky 24
-pmc batched sq2 "$SQ2" $REPO/tools/batch_time.py 50000 512 768 cholesky 24
+for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc batched $1 "$2" $REPO/tools/batched_bench_scene.py 24; done
+pmc batched sq1 "$SQ1" $REPO/tools/batched_bench_scene.py 24
+pmc batched sq2 "$SQ2" $REPO/tools/batched_bench_scene.py 24
 echo "batched done"
 stats c5 $REPO/tools/quant_time.py 30000 400 scale_rot
 pmc c5 sq1 "$SQ1" $REPO/tools/quant_time.py 30000 100 scale_rot
