@@ -151,7 +151,7 @@ __device__ __forceinline__ void fused_tile(
         sm.gB[CAP] = make_float4(0.f, 0.f, 0.f, 0.f);  // opacity 0: alpha = 0 < 1/255
         sm.gC[CAP] = make_float2(0.f, 0.f);            // lim 0: never lands
     }
-    GI2D_TRACE(1);
+    GI2D_TRACE_VALUE(1, (unsigned long long)blockIdx.x);  // the launch slot (single-image launches)
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
     const int L = tile_list_head<true>(
         sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {

@@ -18,15 +18,31 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 h, w = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 768)
 dev = torch.device("cuda:0")
 xyz, L, col, op = synth_cholesky(n, h, w, 3047)
-hp = HotPath(n, h, w, device=dev)
-hp.set_inputs(xyz, L, col, op)
-hp.set_target(torch.from_numpy(synth_gt(h, w, 1)).to(dev))
 lib = _lib.load()
 lib.gi2d_debug_set_trace.argtypes = [ctypes.c_void_p]
-trace = torch.zeros(hp.T, 16, dtype=torch.int64, device=dev)
-assert lib.gi2d_debug_set_trace(trace.data_ptr()) == 0
-for _ in range(20):
-    hp.step()
+TRAIN = os.environ.get("TRACE_TRAIN", "0") == "1"  # the fitter's training iterations (tile order renewed every 16th step)
+if TRAIN:
+    import bench
+
+    class _Fit:  # the two things the report below asks of `hp`
+        def __init__(self):
+            self.f = bench.make_fitter(torch.from_numpy(synth_gt(h, w, 1)).to(dev), xyz, L, col, n, h, w)
+            self.T = self.f.tx * self.f.ty
+
+        def num_intersects(self):
+            return int(self.f.nth[:n].sum().item())
+    hp = _Fit()
+    trace = torch.zeros(hp.T, 16, dtype=torch.int64, device=dev)
+    assert lib.gi2d_debug_set_trace(trace.data_ptr()) == 0
+    hp.f.train(int(os.environ.get("TRACE_STEPS", "36")))
+else:
+    hp = HotPath(n, h, w, device=dev)
+    hp.set_inputs(xyz, L, col, op)
+    hp.set_target(torch.from_numpy(synth_gt(h, w, 1)).to(dev))
+    trace = torch.zeros(hp.T, 16, dtype=torch.int64, device=dev)
+    assert lib.gi2d_debug_set_trace(trace.data_ptr()) == 0
+    for _ in range(20):
+        hp.step()
 torch.cuda.synchronize()
 raw = trace.cpu().numpy()
 order_cols = [0, 11, 12, 13, 2, 3, 5, 6, 7, 8, 9, 10]
@@ -72,3 +88,20 @@ simd0 = (hw >> 4) & 3
 print("wave 0 on SIMD 0/1/2/3:", np.bincount(simd0, minlength=4))
 per_cu_simd = np.array([np.bincount(simd0[inv == i], minlength=4) for i in range(len(keys))])
 print("per CU, workgroups whose wave 0 sits on the same SIMD: max", per_cu_simd.max(1).mean().round(2), "(mean over CUs)")
+# workgroup index -> CU: is the dealing regular?  (trace rows are indexed by TILE; column 1 holds the workgroup's slot)
+slot = raw[:, 1].astype(np.int64)
+if len(np.unique(slot)) == hp.T:
+    by_slot = np.empty(hp.T, np.int64)
+    by_slot[slot] = np.arange(hp.T)
+    cu_of_slot = inv[by_slot]
+    x0 = np.arange(0, hp.T, 8)  # the workgroups of XCC (slot % 8 == 0)
+    print("XCC of slots 0..15:", xcc[by_slot[:16]])
+    seq = cu_of_slot[x0]
+    print("CU index (within this trace's numbering) of slots 0, 8, 16, ...:", seq[:72])
+    for period in (32, 64, 96, 128, 192):
+        same = np.mean([cu_of_slot[s] == cu_of_slot[s + 8 * period] for s in range(hp.T - 8 * period)])
+        print(f"  slots s and s + 8 x {period} on the same CU: {same:.3f}")
+    same256 = np.mean([cu_of_slot[s] == cu_of_slot[s + 256] for s in range(hp.T - 256)])
+    print(f"  slots s and s + 256 on the same CU: {same256:.3f}")
+    np.save(os.path.join(ROOT, "gpurun_out", f"trace_by_slot_{int(TRAIN)}.npy"), raw[by_slot])  # every column, for offline looks
+    np.save(os.path.join(ROOT, "gpurun_out", f"trace_tile_of_slot_{int(TRAIN)}.npy"), by_slot)
