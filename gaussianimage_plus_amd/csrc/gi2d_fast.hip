@@ -628,6 +628,18 @@ void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int to
     if (batch_pass_override() >= 0 || total_blocks <= 0 || stream_is_capturing(st)) return;
     const BatchHead *head = b.head;
     std::lock_guard<std::mutex> lock(g_hint_mu);
+    if (g_hints.size() > 256 && !g_hints.count(batch)) {  // tables come and go: forget those with nothing in flight
+        for (auto it = g_hints.begin(); it != g_hints.end();) {
+            BatchHint &old = it->second;
+            if (old.pending && hipEventQuery(old.landed) != hipSuccess) {
+                ++it;
+                continue;
+            }
+            if (old.landed) (void)hipEventDestroy(old.landed);
+            if (old.host) (void)hipHostFree(old.host);
+            it = g_hints.erase(it);
+        }
+    }
     BatchHint &h = g_hints[batch];
     if (h.pending) {  // the previous report has not been looked at: is it there by now?
         if (hipEventQuery(h.landed) != hipSuccess) return;  // still in flight: its buffer is not ours to overwrite yet
