@@ -201,9 +201,11 @@ def run_rank(args):
         # one launch of the general form up to one residency round of the chip (1536 tiles); larger images run the tile
         # pass in two launches -- the small form, then the general one on the tiles it passed over (csrc/gi2d_fast.hip):
         # the events bracket both, the stored counters are summed over both
-        tiles = ((w + 15) // 16) * ((h + 15) // 16)
-        kernel = "gi2d::fast_fwdbwd_kernel<1, 0>" if tiles <= 1536 else \
-            "gi2d::fast_fwdbwd_kernel<1, 1> + gi2d::fast_fwdbwd_kernel<1, 2>"
+        # (which of the two the timed calls took: gi2d_batch_tile_pass_form on the fitter's workspace -- two launches
+        # while no row is fuller than the small form's 128 candidates)
+        two = bool(_lib.load().gi2d_batch_tile_pass_form(fit.ws.data_ptr()))
+        kernel = "gi2d::fast_fwdbwd_kernel<1, 1> + gi2d::fast_fwdbwd_kernel<1, 2>" if two else \
+            "gi2d::fast_fwdbwd_kernel<1, 0>"
         traffic, traffic_src = pmc_traffic(kernel, n, h, w)
         line = {
             "metric": f"training iters/sec (fwd+bwd rasterize) at N Gaussians, {w}x{h}",

@@ -175,6 +175,14 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
                              bool two_phase, hipStream_t st);
 // Bracket of one C-ABI call's batched tile passes on table `batch`: _begin answers "two-phase?" from what the previous
 // call on the same table reported (without waiting for anything), _end queues the read-back of this call's report.
+// (the same bracket for a single image of more than one residency round of tiles, keyed by its workspace; _begin is
+// false for smaller images, which never run as two launches)
+bool single_pass_begin(const void *ws, long long tiles, hipStream_t st);
+void single_pass_end(const void *ws, const FastWs &w, long long tiles, hipStream_t st);
+// gi2d_fast_rasterize_forward_backward with the form given: 1 two launches, 0 one, -1 the C entry's own rule
+int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned img_w, unsigned img_h, const float *background,
+                               const float *v_output, const float *target, float grad_scale, float *tile_sse, void *ws,
+                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form);
 bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st);
 void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st);
 

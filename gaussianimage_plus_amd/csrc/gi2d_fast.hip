@@ -254,6 +254,10 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
 // GI2D_PHASE2_STRIP consecutive slots at once and handles the ones that were passed over one after the other (a barrier
 // between two tiles: they share its LDS).
 #define GI2D_PHASE2_STRIP 8
+// a single image of more tiles than one residency round of the general form may run as two launches (see the launch code)
+#ifndef GI2D_TWO_PHASE_TILES
+#define GI2D_TWO_PHASE_TILES (256 * GI2D_FUSED_OCC) /* development aid: a huge value keeps every launch single-phase */
+#endif
 // workgroups per CU the register allocator leaves room for, by phase: the loop of phase 2 keeps the lane's invariants
 // alive across tiles (80 registers and a few dwords of scratch at six per CU -- and a kernel with ANY scratch pays
 // ~200 us per dispatch here while the runtime re-arms the queue's scratch: measured) -- so it is built for four (five still left one of the four kernels with 12 bytes of it)
@@ -276,7 +280,9 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
             __syncthreads();  // the next tile stages into the same LDS
         }
     } else {
-        tile_pass_workgroup<MODE, PHASE>(a, (int)blockIdx.x, blockIdx.x == 0);
+        // (a large image in the general form marks its fuller tiles too: single_pass_end counts them)
+        tile_pass_workgroup<MODE, PHASE>(a, (int)blockIdx.x, blockIdx.x == 0,
+                                         a.tiles_x * a.tiles_y > GI2D_TWO_PHASE_TILES);
     }
 }
 
@@ -378,6 +384,15 @@ __global__ __launch_bounds__(256) void batch_count_big_kernel(const BatchImage *
     }
     const int upto = wave_inclusive_scan(mine);
     if ((threadIdx.x & 63) == 63 && upto) atomicAdd(&head->big_seen, upto);
+}
+
+// the same for one image; *out is zero when the kernel starts (single_pass_end clears it in front)
+__global__ __launch_bounds__(256) void count_big_kernel(const int32_t *__restrict__ big_tile, int tiles,
+                                                        int32_t *__restrict__ out) {
+    int mine = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) mine += big_tile[t] != 0;
+    const int upto = wave_inclusive_scan(mine);
+    if ((threadIdx.x & 63) == 63 && upto) atomicAdd(out, upto);
 }
 
 // --------------------------------------------------------------------------------------- reduce
@@ -535,9 +550,6 @@ namespace gi2d {
 // two phases: the small form on every tile it can serve, at eight workgroups per CU, then the general form on the rest
 // (2040x1356 at 50 000 gaussians: tile pass 70.2 -> 64.6 us).  One image of up to 1536 tiles (768x512) is a single
 // residency round either way and stays one launch; so do batched launches (see fast_fwdbwd_batched_kernel).
-#ifndef GI2D_TWO_PHASE_TILES
-#define GI2D_TWO_PHASE_TILES (256 * GI2D_FUSED_OCC) /* development aid: a huge value keeps every launch single-phase */
-#endif
 static inline bool two_phase_tile_pass(long long tiles) { return tiles > GI2D_TWO_PHASE_TILES; }
 // one launch with an optional start / stop event (the two phases of a timed tile pass carry one event each)
 template <class K, class... A>
@@ -580,20 +592,28 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
     return check_launch("batched tile pass");
 }
 
-// ---- which form the next call's batched tile passes take (see BatchHead::big_seen)
-// One record per batch table the process has used (keyed by its device address; a freed table's record is reused by
-// whatever is allocated there next, which costs at most one call in the slower form).
-struct BatchHint {
+// ---- which form the next call's tile passes take
+// The two-launch form pays only while NO tile is fuller than GI2D_SMALL_CAP: its second launch is as long as one tile's
+// whole dependent chain (~15 us) the moment it has a single tile to serve, whatever the size of the first (measured on
+// Kodak batches: 8 us for three tiles of 4608, 17 us next to another stream's launch), against 5 ... 10 % of the first.
+// So every pass marks its fuller tiles (`big_tile`), a call that may use the form ends with a counting kernel and an
+// asynchronous 4-byte copy to pinned memory, and the next call on the same key -- a batch table, or a single image's
+// workspace -- looks at the number if its event has fired.  Nothing waits; a stale or missing answer costs speed for
+// one call, never correctness (the second launch serves whatever the first passed over).
+// One record per key the process has used (a device address; a freed buffer's record is reused by whatever is allocated
+// there next).
+struct PassHint {
     int *host = nullptr;  // pinned: where the report of the last call lands
     hipEvent_t landed = nullptr;
     bool pending = false;
-    int total = 0;  // tiles of the batch when that report was queued
-    int last = -1;  // tiles above GI2D_SMALL_CAP in the last pass of the last call that reported; -1: nothing known yet
+    long long total = 0, min_total = 0;  // tiles when that report was queued; smallest launch the form is used on
+    int last = -1;        // tiles above GI2D_SMALL_CAP in the last pass of the last call that reported; -1: nothing known
 };
 static std::mutex g_hint_mu;
-static std::unordered_map<const void *, BatchHint> g_hints;
-// GI2D_BATCH_TILE_PASS = general | two-phase | auto (default): tests force either form
-static int batch_pass_override() {
+static std::unordered_map<const void *, PassHint> g_hints;
+// GI2D_BATCH_TILE_PASS = general | two-phase | auto (default): tests and measurements force either form (batched
+// launches and single images of more than GI2D_TWO_PHASE_TILES tiles alike)
+static int pass_form_override() {
     static const int v = [] {
         const char *e = std::getenv("GI2D_BATCH_TILE_PASS");
         if (!e) return -1;
@@ -605,32 +625,40 @@ static bool stream_is_capturing(hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
 }
-// Two launches pay while the general form has next to nothing to do: the tiles it gets run at four workgroups per CU,
-// eight slots to a workgroup (measured: 9 % of the tiles there cost more than the small form saves on the rest).
-#define GI2D_BATCH_BIG_SHARE 50 /* two-phase up to one tile in 50 above GI2D_SMALL_CAP */
-bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st) {
-    const int forced = batch_pass_override();
-    if (forced >= 0) return forced == 1;
-    if (stream_is_capturing(st)) return false;  // a captured call takes the form that is never slow
-    std::lock_guard<std::mutex> lock(g_hint_mu);
-    BatchHint &h = g_hints[batch];
+static void hint_poll(PassHint &h) {
     if (h.pending && hipEventQuery(h.landed) == hipSuccess) {
         h.last = *h.host;
         h.pending = false;
     }
-#ifdef GI2D_BATCH_LOG /* development aid: one line per call */
-    fprintf(stderr, "[gi2d batch %p] tiles %d, above the small form's capacity at the last report: %d\n", batch,
-            total_blocks, h.last);
-#endif
-    return h.last >= 0 && (long long)h.last * GI2D_BATCH_BIG_SHARE <= total_blocks;
 }
-void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st) {
-    if (batch_pass_override() >= 0 || total_blocks <= 0 || stream_is_capturing(st)) return;
-    const BatchHead *head = b.head;
+// smallest launch the form is used on: below it the small form's higher occupancy has nothing to fill (one 768x512 image
+// is six workgroups per CU in either form) and the second launch's look at every slot costs what the first saves
+#define GI2D_BATCH_TWO_PHASE_MIN (8 * GI2D_TWO_PHASE_TILES) /* measured: eight 768x512 images -6 %; one image per
+                                                               launch on three streams +40 % in time (a Kodak shard
+                                                               of three images 1.10 -> 0.78 images/s) */
+static bool hint_says_two_phase(const PassHint &h, long long total, long long min_total) {
+    return h.last == 0 && total >= min_total;
+}
+static bool pass_form_begin(const void *key, long long total, long long min_total, hipStream_t st) {
+    const int forced = pass_form_override();
+    if (forced >= 0) return forced == 1 && total >= 1;
+    if (total < min_total || stream_is_capturing(st)) return false;  // a captured call takes the form that is never slow
     std::lock_guard<std::mutex> lock(g_hint_mu);
-    if (g_hints.size() > 256 && !g_hints.count(batch)) {  // tables come and go: forget those with nothing in flight
+    PassHint &h = g_hints[key];
+    hint_poll(h);
+#ifdef GI2D_BATCH_LOG /* development aid: one line per call */
+    fprintf(stderr, "[gi2d tile-pass form %p] tiles %lld, above the small form's capacity at the last report: %d\n", key,
+            total, h.last);
+#endif
+    return hint_says_two_phase(h, total, min_total);
+}
+// `count_word`: device word that holds the number of marked tiles once everything queued on `st` so far has run
+static void pass_form_end(const void *key, const int *count_word, long long total, long long min_total,
+                          hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_hint_mu);
+    if (g_hints.size() > 256 && !g_hints.count(key)) {  // buffers come and go: forget those with nothing in flight
         for (auto it = g_hints.begin(); it != g_hints.end();) {
-            BatchHint &old = it->second;
+            PassHint &old = it->second;
             if (old.pending && hipEventQuery(old.landed) != hipSuccess) {
                 ++it;
                 continue;
@@ -640,7 +668,7 @@ void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int to
             it = g_hints.erase(it);
         }
     }
-    BatchHint &h = g_hints[batch];
+    PassHint &h = g_hints[key];
     if (h.pending) {  // the previous report has not been looked at: is it there by now?
         if (hipEventQuery(h.landed) != hipSuccess) return;  // still in flight: its buffer is not ours to overwrite yet
         h.last = *h.host;
@@ -648,18 +676,46 @@ void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int to
     }
     if (!h.host && (hipHostMalloc((void **)&h.host, sizeof(int), hipHostMallocDefault) != hipSuccess ||
                     hipEventCreateWithFlags(&h.landed, hipEventDisableTiming) != hipSuccess)) {
-        (void)hipGetLastError();  // no hint, no two-phase passes: nothing else depends on it
+        (void)hipGetLastError();  // no hint, no two-launch passes: nothing else depends on it
         h.host = nullptr;
         return;
     }
+    if (hipMemcpyAsync(h.host, count_word, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+        hipEventRecord(h.landed, st) == hipSuccess)
+        h.pending = true, h.total = total, h.min_total = min_total;
+    else
+        (void)hipGetLastError();
+}
+static bool hint_wanted(long long total, long long min_total, hipStream_t st) {
+    return pass_form_override() < 0 && total >= min_total && !stream_is_capturing(st);
+}
+
+bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st) {
+    return pass_form_begin(batch, total_blocks, GI2D_BATCH_TWO_PHASE_MIN, st);
+}
+void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st) {
+    if (!hint_wanted(total_blocks, GI2D_BATCH_TWO_PHASE_MIN, st)) return;
     const int blocks = (total_blocks + 255) / 256;
     hipLaunchKernelGGL(batch_count_big_kernel, dim3((unsigned)(blocks < 64 ? blocks : 64)), dim3(256), 0, st,
                        (const BatchImage *)b.img, b.head, k_images);
-    if (hipMemcpyAsync(h.host, &head->big_seen, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
-        hipEventRecord(h.landed, st) == hipSuccess)
-        h.pending = true, h.total = total_blocks;
-    else
+    pass_form_end(batch, &b.head->big_seen, total_blocks, GI2D_BATCH_TWO_PHASE_MIN, st);
+}
+// A single image of more than GI2D_TWO_PHASE_TILES tiles, fitted by gi2d_train_steps: key = its workspace, the count
+// lives in a spare word next to the record-set counters.
+#define GI2D_WS_BIG_COUNT 16 /* word of FastWs::ver */
+bool single_pass_begin(const void *ws, long long tiles, hipStream_t st) {
+    return pass_form_begin(ws, tiles, GI2D_TWO_PHASE_TILES + 1, st);
+}
+void single_pass_end(const void *ws, const FastWs &w, long long tiles, hipStream_t st) {
+    if (!hint_wanted(tiles, GI2D_TWO_PHASE_TILES + 1, st)) return;
+    const int blocks = (int)((tiles + 255) / 256);
+    if (hipMemsetAsync(w.ver + GI2D_WS_BIG_COUNT, 0, sizeof(int32_t), st) != hipSuccess) {
         (void)hipGetLastError();
+        return;
+    }
+    hipLaunchKernelGGL(count_big_kernel, dim3((unsigned)(blocks < 64 ? blocks : 64)), dim3(256), 0, st, w.big_tile,
+                       (int)tiles, w.ver + GI2D_WS_BIG_COUNT);
+    pass_form_end(ws, w.ver + GI2D_WS_BIG_COUNT, tiles, GI2D_TWO_PHASE_TILES + 1, st);
 }
 }  // namespace gi2d
 
@@ -835,6 +891,18 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
                                          const float *background, const float *v_output, const float *target,
                                          float grad_scale, float *tile_sse, void *ws, size_t ws_bytes,
                                          int32_t *status, float *out_img, gi2d_stream_t st) {
+    return gi2d::fast_forward_backward_form(n, tiles_x, tiles_y, w_, h, background, v_output, target, grad_scale, tile_sse,
+                                            ws, ws_bytes, status, out_img, st, -1);
+}
+}  // extern "C"
+
+namespace gi2d {
+// form: 1 two launches, 0 one, -1 the rule of a call that knows nothing about the rows (two launches for every image of
+// more than GI2D_TWO_PHASE_TILES tiles: right for sparse rows -- a 2040x1356 image at 50 000 gaussians -- and 10 % slow
+// when some tile is fuller than the small form; gi2d_train_steps asks single_pass_begin instead)
+int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *background,
+                               const float *v_output, const float *target, float grad_scale, float *tile_sse, void *ws,
+                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form) {
     int rc = check_ws("fast rasterize forward+backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     const long long t = (long long)tiles_x * tiles_y;
@@ -852,7 +920,8 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
                                     v_output ? v_output : target, v_output ? 0.f : grad_scale,
                                     v_output ? nullptr : tile_sse);
     const dim3 grid((unsigned)t), block(256);
-    if (two_phase_tile_pass(t)) {
+    if (form < 0) form = pass_form_override() >= 0 ? pass_form_override() : 1;
+    if (two_phase_tile_pass(t) && form == 1) {
         KernelTimer *tm = next_timer();
         if (v_output) {
             launch_between(fast_fwdbwd_kernel<0, 1>, grid, block, (hipStream_t)st, tm ? tm->begin : nullptr, nullptr, a);
@@ -873,19 +942,17 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
                            status, background, out_img);
     return check_launch("fast rasterize forward+backward");
 }
+}  // namespace gi2d
 
+extern "C" {
 int gi2d_batch_tile_pass_form(const void *batch) {
-    const int forced = batch_pass_override();
+    const int forced = pass_form_override();
     if (forced >= 0) return forced;
     std::lock_guard<std::mutex> lock(g_hint_mu);
     const auto it = g_hints.find(batch);
     if (it == g_hints.end()) return 0;
-    BatchHint &h = it->second;
-    if (h.pending && hipEventQuery(h.landed) == hipSuccess) {
-        h.last = *h.host;
-        h.pending = false;
-    }
-    return h.last >= 0 && (long long)h.last * GI2D_BATCH_BIG_SHARE <= h.total ? 1 : 0;
+    hint_poll(it->second);
+    return hint_says_two_phase(it->second, it->second.total, it->second.min_total) ? 1 : 0;
 }
 
 int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast_image *images, void *batch,

@@ -1509,6 +1509,10 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         set_error("train steps: unknown optimizer, or Adan without its extra state (d_*, pg_*)");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
+    // a large image's tile passes run as two launches while the previous call on this workspace saw no row above the
+    // small form's capacity (gi2d_fast.hip: pass_form_begin)
+    const long long tiles = (long long)tx * ty;
+    const int form = single_pass_begin(s->workspace, tiles, st) ? 1 : 0;
     if (s->quant) {
         QuantTrain Q;
         rc = quant_of(s, Q);
@@ -1525,9 +1529,9 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         for (int it = 0; it < count; ++it) {
             const int step = first_step + it, qstep = q->first_step + it;
             train_launch_project_fill_quant(model, uq, Q, st);
-            rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height,
-                                                      nullptr, nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
-                                                      s->workspace_bytes, s->status, s->out_img, st_);
+            rc = fast_forward_backward_form(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr, nullptr,
+                                            s->gt, grad_scale, s->tile_sse, s->workspace, s->workspace_bytes, s->status,
+                                            s->out_img, st_, form);
             if (rc != GI2D_OK) return rc;
             AdamStep a[3], aq[3];
             for (int k = 0; k < 3; ++k) {
@@ -1546,6 +1550,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
                                    aq[1], aq[2], step);
             }
         }
+        single_pass_end(s->workspace, w, tiles, st);
         return check_launch("train steps (quantised)");
     }
     const UpdateArgs u = update_args_of(s, w, tx, ty);
@@ -1554,9 +1559,9 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
     train_launch_project_fill(s, w, P, tx, ty, st);
     for (int it = 0; it < count; ++it) {
         const int step = first_step + it;
-        rc = gi2d_fast_rasterize_forward_backward(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr,
-                                                  nullptr, s->gt, grad_scale, s->tile_sse, s->workspace,
-                                                  s->workspace_bytes, s->status, s->out_img, st_);
+        rc = fast_forward_backward_form(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr, nullptr,
+                                        s->gt, grad_scale, s->tile_sse, s->workspace, s->workspace_bytes, s->status,
+                                        s->out_img, st_, form);
         if (rc != GI2D_OK) return rc;
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s->beta3, eps, step, adan_opt);
@@ -1566,6 +1571,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         GI2D_DISPATCH_RU(s->kind, more, adan_opt);
 #undef GI2D_LAUNCH_RU
     }
+    single_pass_end(s->workspace, w, tiles, st);
     return check_launch("train steps");
 }
 

@@ -127,11 +127,14 @@ def fit_images_native(gts: Sequence[torch.Tensor], num_points: int, iterations: 
         sched_kw["chunk"] = None
         runs = []
         def fit_batch(part):
+            # (a batch of ONE image -- the three-image shard of an 8-GPU Kodak run is three of them -- takes the
+            # single-image calls: same results bit for bit, no table lookups)
+            runner = BatchFitter(part) if len(part) > 1 else part[0]
             if quantize:  # train_quantize.py's loop for the whole batch
-                for _ in BatchFitter(part).fit_quantize_schedule(iterations, warmup_iter, bits=bits, **sched_kw):
+                for _ in runner.fit_quantize_schedule(iterations, warmup_iter, bits=bits, **sched_kw):
                     pass
             else:
-                BatchFitter(part).fit(iterations, **sched_kw)
+                runner.fit(iterations, **sched_kw)
 
         if groups == 1:
             with torch.cuda.device(dev):

@@ -323,12 +323,15 @@ typedef struct gi2d_fast_image {
 size_t gi2d_batch_bytes(int num_images);
 /* The tile pass of a batch takes one of two forms, with the same results bit for bit: one launch of the general
  * workgroup (256 staged candidates per tile; six workgroups per CU), or two launches -- a small workgroup (128 staged
- * candidates, eight per CU) on every tile it can serve and the general one on the rest -- which is faster while next to
- * no tile is that full.  The library picks per call from what the PREVIOUS call on the same table reported (a count of
- * fuller tiles that travels to pinned memory behind that call's kernels: no call ever waits for it); the first call on
- * a table, and a call inside a stream capture, take the general form.  Returns what the next call on `batch` would take
- * given what has arrived so far: 1 two launches, 0 one.  Environment GI2D_BATCH_TILE_PASS = general | two-phase forces
- * either (tests, measurements). */
+ * candidates, eight per CU) on every tile it can serve and the general one on the rest -- which is 5 ... 10 % faster
+ * while NO tile is that full and slower otherwise (the second launch is as long as one tile's whole dependent chain as
+ * soon as it has one tile to serve).  The library picks per call from what the PREVIOUS call on the same table reported
+ * (the number of fuller tiles travels to pinned memory behind that call's kernels: no call ever waits for it); the
+ * first call on a table, a call inside a stream capture and a batch of fewer than 12288 tiles (eight 768x512 images) take
+ * the general form.  gi2d_train_steps does the same for a single image of more than 1536 tiles, keyed by its workspace.
+ * Returns what the next call on `batch` (a batch table, or such an image's workspace) would take given what has
+ * arrived so far: 1 two launches, 0 one.  Environment GI2D_BATCH_TILE_PASS = general | two-phase forces either (tests,
+ * measurements). */
 int gi2d_batch_tile_pass_form(const void *batch);
 int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast_image *images, void *batch,
                                                  size_t batch_bytes, gi2d_stream_t stream);

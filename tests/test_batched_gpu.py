@@ -337,41 +337,60 @@ def _placed_fitters(scenes):
     return out
 
 
+def _crowd(fitters, count=600):
+    """Pile the first `count` gaussians of every given fitter into the tile at pixel (40 .. 48, 40 .. 48)."""
+    for f in fitters:
+        rng = np.random.default_rng(77)
+        u = np.stack([(rng.uniform(40, 48, count) + 0.5) / (0.5 * f.w) - 1.0,
+                      (rng.uniform(40, 48, count) + 0.5) / (0.5 * f.h) - 1.0], 1)
+        f._xyz[:count] = torch.from_numpy(np.arctanh(u).astype(np.float32)).to(DEV)
+
+
 def test_batched_tile_pass_forms_give_the_same_bits_and_follow_the_reported_row_sizes():
-    """gi2d_batch_tile_pass_form (include/gi2d.h): the first call on a table runs the general form; its report -- tiles
-    with more than 128 candidates -- decides the next call's.  A batch with a handful of crowded tiles (600 gaussians in
-    one tile of 1536) takes the two-launch form, whose second launch then has real work; a batch whose every tile is
-    crowded stays with the general form.  Either way every image's state equals the single-image calls' bit for bit."""
+    """gi2d_batch_tile_pass_form (include/gi2d.h): the first call on a table runs the general form; its report -- the
+    number of tiles with more than 128 candidates -- decides the next call's.  Eight 768x512 images with short rows take
+    the two-launch form from the second call on.  Then 600 gaussians of one image move into one tile BETWEEN two calls:
+    the next call still runs as two launches (its answer is one call old) and its second launch has real work; the
+    call after that is back to one launch.  Every image's state equals the single-image calls' bit for bit throughout."""
     from gaussianimage_plus_amd import _lib
     from gaussianimage_plus_amd.trainer import BatchFitter
     lib = _lib.load()
-    sparse = [(384, 512, 2500, 600), (512, 384, 2500, 0)]
-    alone, together = _placed_fitters(sparse), _placed_fitters(sparse)
+    scenes = [(512, 768, 2500, 0)] * 4 + [(768, 512, 2200, 0)] * 4
+    alone, together = _placed_fitters(scenes), _placed_fitters(scenes)
     batch = BatchFitter(together)
     form = lambda b: int(lib.gi2d_batch_tile_pass_form(C.c_void_p(b.table.data_ptr())))
     assert form(batch) == 0  # nothing known about this table yet
-    forms = []
-    for count in (2, 3, 4):
-        for f in alone:
-            f.train(count)
-        batch.train(count)
-        torch.cuda.synchronize()
-        forms.append(form(batch))
-    assert forms == [1, 1, 1], forms  # i.e. the calls of 3 and 4 iterations ran as two launches
-    for i, (a, b) in enumerate(zip(alone, together)):
-        a.check_status(), b.check_status()
-        _assert_same(a, b, f"two-launch form, image {i}")
-    assert int(together[0].status[3]) >= 512, "the crowded tile is what the second launch is for"
 
-    crowded = [(64, 64, 3000, 0), (64, 80, 3500, 0)]
-    alone, together = _placed_fitters(crowded), _placed_fitters(crowded)
-    batch = BatchFitter(together)
-    for count in (2, 3):
+    def run(count):
         for f in alone:
             f.train(count)
         batch.train(count)
         torch.cuda.synchronize()
-        assert form(batch) == 0
-    for i, (a, b) in enumerate(zip(alone, together)):
-        a.check_status(), b.check_status()
-        _assert_same(a, b, f"general form, image {i}")
+        return form(batch)
+
+    def same(tag):
+        for i, (a, b) in enumerate(zip(alone, together)):
+            a.check_status(), b.check_status()
+            _assert_same(a, b, f"{tag}, image {i}")
+
+    assert [run(2), run(3)] == [1, 1]  # i.e. the call of 3 iterations ran as two launches
+    same("two launches, nothing for the second")
+    _crowd([alone[0], together[0]])
+    assert run(2) == 0  # ran as two launches (decided from the report before), reports a fuller tile
+    same("two launches, a crowded tile for the second")
+    assert int(together[0].status[3]) >= 512, "the crowded tile is what the second launch was for"
+    assert run(2) == 0
+    same("one launch")
+
+
+def test_small_batches_stay_with_one_launch():
+    """Fewer than eight residency rounds of tiles: the small form has no idle slots to fill, the form stays general."""
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    lib = _lib.load()
+    together = _placed_fitters([(384, 512, 2500, 0), (512, 384, 2500, 0)])
+    batch = BatchFitter(together)
+    for count in (2, 2):
+        batch.train(count)
+        torch.cuda.synchronize()
+        assert int(lib.gi2d_batch_tile_pass_form(C.c_void_p(batch.table.data_ptr()))) == 0

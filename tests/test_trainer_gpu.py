@@ -377,3 +377,46 @@ def test_one_fused_update_step_equals_the_torch_optimizer_on_the_same_gradient(o
                                         moved.flatten()[worst].item(), p.detach().flatten()[worst].item())
             for got, ref, what in ((getattr(fit, "m_" + nm), got_m[nm], "m"), (getattr(fit, "v_" + nm), got_v[nm], "v")):
                 assert torch.allclose(got, ref, rtol=1e-6, atol=1e-30), (step, nm, what)
+
+
+def test_large_image_fit_switches_to_two_launches_and_equals_a_single_call():
+    """A single image of more than one residency round of tiles (1040x1040: 4225) fitted by gi2d_train_steps: the first
+    call on its workspace runs the tile pass as one launch, reports no tile above the small form's capacity, and later
+    calls run it as two launches (include/gi2d.h: gi2d_batch_tile_pass_form, keyed by the workspace) -- the state equals
+    the same iterations issued as ONE call (all general form) bit for bit.  Once a tile is crowded the form goes back."""
+    import ctypes as C
+    from gaussianimage_plus_amd import _lib
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    lib = _lib.load()
+    h = w = 1040
+    n = 6000
+
+    def fitter():
+        rng = np.random.default_rng(4)
+        u = rng.uniform(-0.98, 0.98, (n, 2))
+        L = np.stack([rng.uniform(0.8, 1.6, n), rng.uniform(-0.3, 0.3, n), rng.uniform(0.8, 1.6, n)], 1)
+        init = {"xyz": torch.from_numpy(np.arctanh(u).astype(np.float32)), "chol": torch.from_numpy(L.astype(np.float32)),
+                "feat": torch.from_numpy(rng.uniform(0, 0.2, (n, 3)).astype(np.float32)),
+                "bound": torch.tensor([0.5, 0.0, 0.5])}
+        return NativeFitter(synthetic_image(h, w, 9).to(DEV), n, kind="cholesky", lr=1e-3, seed=5, init=init)
+
+    form = lambda f: int(lib.gi2d_batch_tile_pass_form(C.c_void_p(f.ws.data_ptr())))
+    a, b = fitter(), fitter()
+    assert form(a) == 0
+    a.train(2)
+    torch.cuda.synchronize()
+    assert form(a) == 1
+    a.train(3)  # two launches per tile pass
+    b.train(5)  # one call on a fresh workspace: one launch per tile pass
+    torch.cuda.synchronize()
+    a.check_status(), b.check_status()
+    for nm in ("_xyz", "_chol", "_feat", "m_xyz", "v_chol", "out_img", "tile_sse"):
+        assert torch.equal(getattr(a, nm), getattr(b, nm)), nm
+    # 600 gaussians into one tile: the next call (still two launches) reports it, the one after runs as one launch
+    rng = np.random.default_rng(77)
+    u = np.stack([(rng.uniform(40, 48, 600) + 0.5) / (0.5 * w) - 1.0, (rng.uniform(40, 48, 600) + 0.5) / (0.5 * h) - 1.0], 1)
+    a._xyz[:600] = torch.from_numpy(np.arctanh(u).astype(np.float32)).to(DEV)
+    a.train(2)
+    torch.cuda.synchronize()
+    assert form(a) == 0 and int(a.status[3]) >= 512

@@ -38,3 +38,11 @@ if g:
     print("idle time by (kernel before -> kernel after):")
     for (a, b), d in by.most_common(12):
         print(f"  {d / 1e9:.3f} s  {a}  ->  {b}")
+tot = collections.Counter()
+cnt = collections.Counter()
+for s, e, nm in rows:
+    tot[nm] += e - s
+    cnt[nm] += 1
+print("kernel time by name (sum of durations):")
+for nm, d in tot.most_common(8):
+    print(f"  {d / 1e9:.3f} s  {cnt[nm]:7d} x {d / cnt[nm] / 1e3:8.1f} us  {nm}")
