@@ -328,7 +328,21 @@ def dropin_autograd_rate(gt, n, iters=200, reps=5):
     launch.fit_image(gt, n, 300, eval_renders=1)  # warm-up: code objects, the caching allocator, the workspace pool
     runs = sorted(launch.fit_image(gt, n, iters, eval_renders=1)["train_s"] / iters * 1e6 for _ in range(reps))
     us = runs[len(runs) // 2]
+    # the same loop with one whole iteration captured in a HIP graph and replayed (launch.fit_image(graph=True)): what is
+    # left when PyTorch's per-op host work is out of the way -- longer fits, so that the three eager iterations and the
+    # capture in front weigh little
+    g_iters = 5 * iters
+    launch.fit_image(gt, n, 300, eval_renders=1, graph=True)
+    g_runs = sorted(launch.fit_image(gt, n, g_iters, eval_renders=1, graph=True)["train_s"] / g_iters * 1e6 for _ in range(3))
+    g_us = g_runs[len(g_runs) // 2]
     return {"us_per_iteration": us, "iters_per_s": 1e6 / us, "us_per_iteration_min_max": [runs[0], runs[-1]], "num_points": n, "iterations": iters, "repeats": reps,
+            "hip_graph": {"us_per_iteration": g_us, "iters_per_s": 1e6 / g_us, "us_per_iteration_min_max": [g_runs[0], g_runs[-1]],
+                          "iterations": g_iters, "repeats": 3,
+                          "what": "launch.fit_image(graph=True): three eager iterations, then render + mse_loss + backward + "
+                                  "Adam step captured once with torch.cuda.graph and replayed (Adam capturable + fused: "
+                                  "step count and learning rate on the device, same update rule); the wrappers record "
+                                  "their passes without the host-side status protocol, tile-row overflow is checked "
+                                  "between replays (every 256; gsplat/_raster_common.py::check_captured)"},
             "binding": table.BINDING, "status_check": "every forward" if _raster_common.SYNC_EVERY_FORWARD else
             "one call late (synchronous on a workspace's first use and above half the tile-row capacity)",
             "loop": "launch.fit_image: tanh, +bound, project_gaussians_2d, rasterize_gaussians_plus, clamp, mse_loss, "

@@ -70,6 +70,24 @@ def _settle(ws, what: str) -> None:
             "GI2D_WRAPPER_SYNC=1 to check every forward before its result is used.")
 
 
+def check_captured() -> None:
+    """For loops replayed from a captured graph: look (synchronously) at the status words of every pooled workspace a
+    captured forward ran on.  A tile row that overflowed in some replay since the last look (more than 1024 candidate
+    gaussians in one 16x16 tile) means images were rendered from truncated tile lists -- the sticky word remembers it --
+    and raises; the exact fallback of the eager path cannot run inside a graph, so such a scene needs the eager loop."""
+    for free in _pool.values():
+        for ws in free:
+            if getattr(ws, "captured", False):
+                sticky = int(ws.status[2].item())
+                if sticky:
+                    ws.captured = False
+                    ws.reset()
+                    raise RuntimeError(
+                        f"gsplat drop-in: a tile row overflowed (> {_C.fast_tile_capacity()} candidate gaussians in one "
+                        "tile) in a replay of a captured iteration; its images were rendered from truncated tile lists. "
+                        "Run this scene through the eager loop (which falls back to the capacity-free ops).")
+
+
 def _exact_forward(plus, xys, radii, conics, colors, opacity, img_height, img_width, tile_bounds, block, img_size,
                    background, radius_clip, isprint):
     """Capacity-free ops (any tile population): gi2d_bin_gaussians + gi2d_rasterize_sum[_plus]_forward."""
@@ -102,12 +120,19 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
 
     lease = _acquire(xys, num_points, tile_bounds)
     ws = lease.ws
-    _settle(ws, "the previous forward on this workspace")
+    # Inside a stream capture (torch.cuda.graph around a whole training iteration: launch.fit_image(graph=True)) nothing may
+    # wait and no event may be queried: the pass is recorded as it is, and the status words of every REPLAY are the
+    # caller's to look at -- check_captured() below, between replays.
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        _settle(ws, "the previous forward on this workspace")
     # "not a single intersection -> background image" (rasterize_sum_plus.py:110-118) is decided on the device
     out_img = _C.fast_forward(ws, xys, radii, conics, colors, opacity, img_height, img_width, radius_clip,
                               background=background)
     ctx.exact = None
-    if SYNC_EVERY_FORWARD or ws.must_check_now:
+    if capturing:
+        ws.captured = True
+    elif SYNC_EVERY_FORWARD or ws.must_check_now:
         _, overflow = ws.read_now()
         if overflow:
             ws.reset()  # the overflowing row lost entries: its workspace starts from empty lists next time
@@ -145,7 +170,8 @@ def backward_impl(ctx, plus: bool, v_out_img):
             ctx.img_height, ctx.img_width, gids, bins, xys, radii, conics, colors, opacity, final_idx, v_out_img,
             ctx.radius_clip, with_abs=not plus)
     else:
-        _settle(ctx.lease.ws, "this backward's forward")
+        if not torch.cuda.is_current_stream_capturing():
+            _settle(ctx.lease.ws, "this backward's forward")
         # without a single intersection the tile pass finds empty rows and the per-gaussian sums are zeros
         v_xy, v_conic, v_colors, v_opacity, v_abs = _C.fast_backward(
             ctx.lease.ws, xys, radii, v_out_img, ctx.img_height, ctx.img_width, ctx.radius_clip, with_abs=not plus)

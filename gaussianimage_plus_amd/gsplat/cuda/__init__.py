@@ -308,6 +308,7 @@ class FastWorkspace:
             else:
                 _lib.call("gi2d_fast_workspace_init", self.buf.data_ptr(), self.buf.numel(), self.n, self.tx, self.ty,
                           _stream(t))
+            self.status.zero_()  # incl. the sticky word: an overflow that has been dealt with is not reported again
         self.event, self.fullest = None, None
 
     def post(self):

@@ -235,9 +235,17 @@ def fit_image_native(gt_hwc: torch.Tensor, num_points: int, iterations: int, **k
 
 
 def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float = 1e-3, seed: int = 3047,
-              eval_renders: int = 10) -> Dict[str, float]:
+              eval_renders: int = 10, graph: bool = False) -> Dict[str, float]:
     """Cholesky model, L2 loss, Adam (models/gaussianimage_cholesky.py:57-58,80-82,302-317 with
-    opt_type="adam") through the autograd wrappers.  gt_hwc: float32 [H, W, 3] in [0, 1] on the target GPU."""
+    opt_type="adam") through the autograd wrappers.  gt_hwc: float32 [H, W, 3] in [0, 1] on the target GPU.
+
+    `graph`: the same loop, but one whole iteration -- render, loss, backward, optimizer step -- is captured in a HIP
+    graph (torch.cuda.graph) after three eager iterations and REPLAYED for the rest.  The eager loop is bound by the
+    host (PyTorch's dispatcher, autograd engine and optimizer issue ~35 small kernels per iteration); a replay is one
+    launch.  What changes: Adam runs with `capturable=True` (step count and learning rate live on the device; same
+    update rule), the wrappers record their passes without the host-side status protocol, and the tile-row overflow
+    check happens between replays (every 256, _raster_common.check_captured), where it can only raise -- the eager
+    loop's exact fallback cannot run inside a graph."""
     from .gsplat.project_gaussians_2d import project_gaussians_2d
     from .gsplat.rasterize_sum_plus import rasterize_gaussians_plus
 
@@ -252,7 +260,11 @@ def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float 
     low_pass = min(h * w / (9 * math.pi * num_points), 300)
     bound = torch.tensor([low_pass, 0.0, low_pass], device=dev).view(1, 3)
     background = torch.ones(3, device=dev)
-    opt = torch.optim.Adam([xyz, chol, feat], lr=lr)
+    if graph:
+        opt = torch.optim.Adam([xyz, chol, feat], lr=torch.tensor(float(lr), device=dev), capturable=True,
+                               fused=os.environ.get("GI2D_GRAPH_FUSED_ADAM", "1") == "1")
+    else:
+        opt = torch.optim.Adam([xyz, chol, feat], lr=lr)
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=20000, gamma=0.5)
 
     def render():
@@ -261,14 +273,37 @@ def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float 
                                        background=background)
         return torch.clamp(img, 0, 1)
 
-    torch.cuda.synchronize(dev)
-    t0 = time.time()
-    for _ in range(iterations):
+    def iteration():
         loss = torch.nn.functional.mse_loss(render(), gt_hwc)
         loss.backward()
         opt.step()
-        opt.zero_grad(set_to_none=True)
-        sched.step()
+
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    if graph and iterations > 3:
+        from .gsplat import _raster_common
+        side = torch.cuda.Stream(device=dev)  # (torch.cuda.graph wants the warm-up off the default stream)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                iteration()
+                opt.zero_grad(set_to_none=True)
+                sched.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        captured = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(captured):  # gradients are allocated here, in the graph's pool, and rewritten by every replay
+            iteration()
+        for it in range(3, iterations):
+            captured.replay()
+            sched.step()
+            if (it & 255) == 0:
+                _raster_common.check_captured()
+        _raster_common.check_captured()
+    else:
+        for _ in range(iterations):
+            iteration()
+            opt.zero_grad(set_to_none=True)
+            sched.step()
     torch.cuda.synchronize(dev)
     train_s = time.time() - t0
     with torch.no_grad():

@@ -43,6 +43,8 @@ def test_bench_line_has_the_contract_fields():
     assert d["roofline_valu"]["source"].startswith("none:")  # counters are stored for the default workload only
     dr = d["dropin_autograd_step"]
     assert dr["us_per_iteration"] > 0 and dr["binding"] in ("compiled", "ctypes") and dr["num_points"] == 3000
+    assert 0 < dr["hip_graph"]["us_per_iteration"] < dr["us_per_iteration"]  # one launch per iteration beats ~35
+    assert dr["hip_graph"]["iterations"] == 5 * dr["iterations"]
     im = d["images_per_s"]
     assert im["unit"] == "images/s" and im["images"] == 2 and im["iterations_per_image"] == 200 and im["value"] > 0
     assert abs(im["value"] - im["images"] / im["wall_s"]) <= 1e-9 * im["value"]
