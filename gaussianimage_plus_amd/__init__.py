@@ -13,7 +13,7 @@ import sys
 __version__ = "0.1.0"
 
 _SUBMODULES = ("cuda", "utils", "version", "project_gaussians_2d", "project_gaussians_2d_covariance",
-               "project_gaussians_2d_scale_rot", "rasterize_sum", "rasterize_sum_plus")
+               "project_gaussians_2d_scale_rot", "rasterize_sum", "rasterize_sum_plus", "_raster_common")
 
 
 def install_as_gsplat() -> None:
