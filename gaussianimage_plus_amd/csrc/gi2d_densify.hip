@@ -131,9 +131,11 @@ __global__ __launch_bounds__(256) void prune_copyback_kernel(RowArrays rows, con
 // train.py:86: errors = |render - gt| summed over the channels (render = clamp(out_img, 0, 1)); keys = the float bits
 // (non-negative floats order like their bit patterns).
 __global__ __launch_bounds__(256) void grow_error_kernel(int npix, const float *__restrict__ out_img,
-                                                         const float *__restrict__ gt, uint32_t *__restrict__ key) {
+                                                         const float *__restrict__ gt, uint32_t *__restrict__ key,
+                                                         int32_t *__restrict__ sel_state, int state_words) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < state_words) sel_state[p] = 0;  // the select's ticket, histogram and counts (grow_hist_kernel)
     if (p >= npix) return;
     float e = 0.f;
 #pragma unroll
@@ -144,87 +146,145 @@ __global__ __launch_bounds__(256) void grow_error_kernel(int npix, const float *
     key[p] = e == e ? __float_as_uint(e) : 0u;  // a NaN error never wins
 }
 
-// One workgroup of 1024 lanes.  k = growth budget from the LIVE count; radix select of the k-th largest key (four
-// 8-bit digits, LDS histograms); then the selected pixels in ascending index order: every key above the threshold and
-// the first `quota` keys equal to it.  info = {k, live n at entry}.
-__global__ __launch_bounds__(1024) void grow_select_kernel(int npix, const uint32_t *__restrict__ key,
-                                                           const int32_t *__restrict__ n_dev, int n_bound,
-                                                           int max_points, int budget_cap, int kmax,
-                                                           int32_t *__restrict__ sel, int32_t *__restrict__ info) {
+// The k = growth budget largest keys, as pixel indices in ascending order: a radix select of the k-th largest key (four
+// 8-bit digits), then every key above that threshold and the first `want` keys equal to it.  One workgroup reading every
+// key six times was 0.47 ms per growth step and image (nine steps per fit); now GI2D_SEL_WGS workgroups of 1024 lanes
+// each take a contiguous run of pixels, in six launches:
+//   grow_hist_kernel<24 / 16 / 8 / 0>  LDS histogram of the digit over the workgroup's run (keys that match the
+//                                      threshold's prefix so far), added to the pass's global histogram
+//   grow_count_kernel                  per (workgroup, wave): keys above / equal to the threshold in its run
+//   grow_write_kernel                  every workgroup scans those 1024 pairs itself and writes its run's share
+// Nobody combines the histograms in a step of its own: every workgroup of the NEXT launch reads the finished histogram
+// (256 words, one kernel boundary behind it) and picks the digit itself -- a suffix sum and a ballot, the same answer
+// everywhere; workgroup 0 also leaves the threshold so far in the state words for the launch after.  (A "last
+// workgroup in combines" ticket needs a release fence per workgroup, and on this 8-XCD part that is an L2 write-back:
+// 21 ... 25 us per pass against 5 for reading the keys.)
+// state words (`sel_state`, zeroed by grow_error_kernel): [0..3) and [4..7) two slots of (prefix, mask, want) -- the
+// threshold as resolved by the last launch, slots alternating; [8 + 256 p ..) histogram of pass p; [8 + 1024 ..) the
+// 2 x 16 x GI2D_SEL_WGS counts.
+#define GI2D_SEL_WGS 64
+#define GI2D_SEL_STATE_WORDS (8 + 4 * 256 + 2 * 16 * GI2D_SEL_WGS)
+__device__ __forceinline__ int grow_budget(const int32_t *__restrict__ n_dev, int n_bound, int max_points, int budget_cap,
+                                           int kmax, int npix, int &n) {
+    n = min(*n_dev, n_bound);
+    const int k = max(0, min(budget_cap, max_points - n));  // train.py:91-97
+    return min(min(k, kmax), npix);
+}
+// pixels [w0, w1) of wave `wave` of workgroup `b`: runs ascend with (b, wave), 64-aligned
+__device__ __forceinline__ void sel_run(int npix, int b, int wave, int &w0, int &w1) {
+    const int per_wave = (((npix + 16 * GI2D_SEL_WGS - 1) / (16 * GI2D_SEL_WGS)) + 63) & ~63;
+    w0 = min(npix, (b * 16 + wave) * per_wave);
+    w1 = min(npix, w0 + per_wave);
+}
+// The digit at `shift` of the threshold, from the finished histogram `gh` of the keys that match (prefix, mask): the
+// largest d >= 1 with (keys of digit >= d) >= want, else 0 -- walking the bins from the top until `want` keys are
+// covered -- as a suffix sum over the 256 bins by the first four waves (lane i holds bin 255 - i).  Whole workgroup
+// (>= 256 lanes); on return prefix / mask include the digit and want is the rank still wanted among the keys equal so far.
+__device__ __forceinline__ void resolve_digit(const int32_t *__restrict__ gh, int shift, unsigned &prefix, unsigned &mask,
+                                              int &want) {
+    __shared__ int suffix[257];
+    __shared__ int wtot[4], first_hit[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int incl = 0;
+    if (tid < 256) {
+        incl = wave_inclusive_scan(gh[255 - tid]);
+        if (lane == 63) wtot[wave] = incl;
+    }
+    if (tid == 0) suffix[256] = 0;
+    __syncthreads();
+    if (tid < 256) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        const int sfx = before + incl;  // keys whose digit is >= 255 - tid
+        suffix[255 - tid] = sfx;
+        const unsigned long long hit = __ballot(sfx >= want && tid < 255);
+        if (lane == 0) first_hit[wave] = hit ? wave * 64 + (__ffsll((long long)hit) - 1) : 256;
+    }
+    __syncthreads();
+    const int i = min(min(first_hit[0], first_hit[1]), min(first_hit[2], first_hit[3]));
+    const int d = i < 256 ? 255 - i : 0;
+    prefix |= (unsigned)d << shift;
+    mask |= 255u << shift;
+    want -= suffix[d + 1];
+    __syncthreads();  // the arrays above are reused by the next call
+}
+
+template <int SHIFT>
+__global__ __launch_bounds__(1024) void grow_hist_kernel(int npix, const uint32_t *__restrict__ key,
+                                                         const int32_t *__restrict__ n_dev, int n_bound, int max_points,
+                                                         int budget_cap, int kmax, int32_t *__restrict__ state,
+                                                         int32_t *__restrict__ info) {
     __shared__ int hist[256];
-    __shared__ unsigned s_prefix;
-    __shared__ int s_want;
-    const int tid = threadIdx.x;
-    const int n = min(*n_dev, n_bound);
-    int k = max(0, min(budget_cap, max_points - n));  // train.py:91-97
-    k = min(min(k, kmax), npix);
-    if (tid == 0) {
-        info[0] = k;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int n;
+    const int k = grow_budget(n_dev, n_bound, max_points, budget_cap, kmax, npix, n);
+    if (SHIFT == 24 && blockIdx.x == 0 && tid == 0) {
+        info[0] = k;  // info = {k, live n at entry}
         info[1] = n;
     }
     if (k == 0) return;
-    // k-th largest: walk the digits from the top, keeping the prefix of the threshold and how many are still wanted
+    // the threshold so far: its digits above SHIFT, and the rank (from the top) still wanted among the keys matching them
     unsigned prefix = 0, mask = 0;
-    int want = k;  // rank (1-based, from the top) of the threshold among the keys matching `prefix`
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        // one workgroup reads every key in every pass: eight loads per lane in flight at a time (a load per trip, each
-        // waited for before the next, made this kernel 0.7 ms of pure latency)
-        for (int base = 0; base < npix; base += 8 * 1024) {  // wave-uniform trip count (ballots below)
-            unsigned v8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = base + u * 1024 + tid;
-                v8[u] = p < npix ? key[p] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = base + u * 1024 + tid;
-                const unsigned v = v8[u];
-                const bool act = p < npix && (v & mask) == prefix;
-                const unsigned d = (v >> shift) & 255u;
-                if (shift == 24) {
-                    // the top byte of an error in [0, 3] takes a handful of values: one LDS atomic per distinct value
-                    // and wave instead of one per key (64 lanes on one address serialise)
-                    unsigned long long todo = __ballot(act);
-                    while (todo) {
-                        const int src = __ffsll((long long)todo) - 1;
-                        const unsigned d0 = (unsigned)__shfl((int)d, src, 64);
-                        const unsigned long long same = __ballot(act && d == d0);
-                        if ((tid & 63) == src) atomicAdd(&hist[d0], __popcll(same));
-                        todo &= ~same;
-                    }
-                } else if (act) {
-                    atomicAdd(&hist[d], 1);
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, d = 255;
-            for (; d > 0; --d) {
-                if (acc + hist[d] >= want) break;
-                acc += hist[d];
-            }
-            s_prefix = prefix | ((unsigned)d << shift);
-            s_want = want - acc;
-        }
-        __syncthreads();
-        prefix = s_prefix;
-        want = s_want;
-        mask |= 255u << shift;
-        __syncthreads();
+    int want = k;
+    if (SHIFT < 24) {
+        // two slots of (prefix, mask, want), read and written alternately: a launch never writes the slot its own
+        // workgroups -- which start at different times -- are still reading
+        const int32_t *in = state + (SHIFT == 8 ? 0 : 4);
+        int32_t *out = state + (SHIFT == 8 ? 4 : 0);
+        if (SHIFT < 16) prefix = (unsigned)in[0], mask = (unsigned)in[1], want = in[2];
+        resolve_digit(state + 8 + 256 * ((24 - SHIFT) / 8 - 1), SHIFT + 8, prefix, mask, want);
+        if (blockIdx.x == 0 && tid == 0) out[0] = (int32_t)prefix, out[1] = (int32_t)mask, out[2] = want;
     }
-    const unsigned thr = prefix;  // the k-th largest key; `want` of the keys equal to it are taken, lowest index first
-    // every WAVE owns a contiguous run of pixels and walks it 64 consecutive keys at a time (coalesced, eight loads per
-    // lane in flight): count, scan the sixteen wave totals, then write in index order -- a selected pixel's position is
-    // everything selected in front of it, which inside a 64-key group is a ballot and a popcount
-    __shared__ int w_above[16], w_equal[16];
-    const int wave = tid >> 6, lane = tid & 63;
-    const int per_wave = (((npix + 15) / 16) + 63) & ~63;
-    const int w0 = min(npix, wave * per_wave), w1 = min(npix, w0 + per_wave);
-    const unsigned long long lt = lanemask_lt();
+    int32_t *ghist = state + 8 + 256 * ((24 - SHIFT) / 8);
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    int w0, w1;
+    sel_run(npix, (int)blockIdx.x, wave, w0, w1);
+    for (int base = w0; base < w1; base += 64 * 8) {  // wave-uniform trip count (ballots below); eight loads in flight
+        unsigned v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = base + 64 * u + lane;
+            v8[u] = p < w1 ? key[p] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned v = v8[u];
+            const bool act = base + 64 * u + lane < w1 && (v & mask) == prefix;
+            const unsigned d = (v >> SHIFT) & 255u;
+            if (SHIFT == 24) {
+                // the top byte of an error in [0, 3] takes a handful of values: one LDS atomic per distinct value and
+                // wave instead of one per key (64 lanes on one address serialise)
+                unsigned long long todo = __ballot(act);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    const unsigned d0 = (unsigned)__shfl((int)d, src, 64);
+                    const unsigned long long same = __ballot(act && d == d0);
+                    if (lane == src) atomicAdd(&hist[d0], __popcll(same));
+                    todo &= ~same;
+                }
+            } else if (act) {
+                atomicAdd(&hist[d], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 256 && hist[tid]) atomicAdd(&ghist[tid], hist[tid]);
+}
+
+__global__ __launch_bounds__(1024) void grow_count_kernel(int npix, const uint32_t *__restrict__ key,
+                                                          const int32_t *__restrict__ info,
+                                                          int32_t *__restrict__ state) {
+    if (info[0] == 0) return;
+    unsigned prefix = (unsigned)state[0], mask = (unsigned)state[1];  // slot 0: left by grow_hist_kernel<0>
+    int want = state[2];
+    resolve_digit(state + 8 + 256 * 3, 0, prefix, mask, want);
+    if (blockIdx.x == 0 && threadIdx.x == 0)  // slot 1, for grow_write_kernel
+        state[4] = (int32_t)prefix, state[5] = (int32_t)mask, state[6] = want;
+    const unsigned thr = prefix;  // the k-th largest key
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int w0, w1;
+    sel_run(npix, (int)blockIdx.x, wave, w0, w1);
     int above = 0, equal = 0;  // wave-uniform
     for (int base = w0; base < w1; base += 64 * 8) {
         unsigned v8[8];
@@ -240,10 +300,36 @@ __global__ __launch_bounds__(1024) void grow_select_kernel(int npix, const uint3
             equal += __popcll(__ballot(in && v8[u] == thr));
         }
     }
-    if (lane == 0) w_above[wave] = above, w_equal[wave] = equal;
+    if (lane == 0) {
+        int32_t *cnt = state + 8 + 4 * 256 + 2 * ((int)blockIdx.x * 16 + wave);
+        cnt[0] = above;
+        cnt[1] = equal;
+    }
+}
+
+// The selected pixels in ascending index order: a selected pixel's position is everything selected in front of it -- the
+// runs before its wave's (a scan of the 16 x GI2D_SEL_WGS count pairs, done by every workgroup for itself) and, inside a
+// 64-key group, a ballot and a popcount.  `want` of the keys equal to the threshold are taken, lowest index first.
+__global__ __launch_bounds__(1024) void grow_write_kernel(int npix, const uint32_t *__restrict__ key,
+                                                          const int32_t *__restrict__ info,
+                                                          const int32_t *__restrict__ state, int32_t *__restrict__ sel) {
+    static_assert(16 * GI2D_SEL_WGS == 1024, "one count pair per lane");
+    __shared__ int wsum[17];
+    __shared__ int a_base[16], e_base[16];
+    if (info[0] == 0) return;
+    const unsigned thr = (unsigned)state[4];  // slot 1: left by grow_count_kernel
+    const int want = state[6];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int32_t *cnt = state + 8 + 4 * 256;
+    int total;
+    const int a_ex = block_exclusive_scan(cnt[2 * tid], wsum, total);
+    const int e_ex = block_exclusive_scan(cnt[2 * tid + 1], wsum, total);
+    if ((tid >> 4) == (int)blockIdx.x) a_base[tid & 15] = a_ex, e_base[tid & 15] = e_ex;
     __syncthreads();
-    int a_before = 0, e_before = 0;
-    for (int k = 0; k < wave; ++k) a_before += w_above[k], e_before += w_equal[k];
+    int a_before = a_base[wave], e_before = e_base[wave];
+    int w0, w1;
+    sel_run(npix, (int)blockIdx.x, wave, w0, w1);
+    const unsigned long long lt = lanemask_lt();
     for (int base = w0; base < w1; base += 64 * 8) {
         unsigned v8[8];
 #pragma unroll
@@ -377,12 +463,13 @@ size_t gi2d_densify_scratch_bytes(const gi2d_train_state *s, int max_points) {
     const RowArrays r = rows_of(s);
     const size_t npix = (size_t)s->img_height * (size_t)s->img_width;
     const size_t cap = (size_t)(max_points > s->num_points ? max_points : s->num_points);
-    // pos[cap] + counts[8] | keys[npix] + sel[cap] + ordered[cap] + info[8] | row scratch
-    return 256 * 8 + sizeof(int32_t) * (3 * cap + 16) + sizeof(uint32_t) * npix + sizeof(float) * cap * r.offset[r.count];
+    // pos[cap] + counts[8] | keys[npix] + sel[cap] + ordered[cap] + info[8] + select state | row scratch
+    return 256 * 9 + sizeof(int32_t) * (3 * cap + 16 + GI2D_SEL_STATE_WORDS) + sizeof(uint32_t) * npix +
+           sizeof(float) * cap * r.offset[r.count];
 }
 
 struct DensifyWs {
-    int32_t *pos, *counts, *sel, *ordered, *info;
+    int32_t *pos, *counts, *sel, *ordered, *info, *sel_state;
     uint32_t *key;
     float *rowbuf;
 };
@@ -393,6 +480,7 @@ static DensifyWs carve_densify(void *base, size_t cap, size_t npix) {
     DensifyWs w;
     w.counts = (int32_t *)(b + off), off += up(8 * sizeof(int32_t));
     w.info = (int32_t *)(b + off), off += up(8 * sizeof(int32_t));
+    w.sel_state = (int32_t *)(b + off), off += up(GI2D_SEL_STATE_WORDS * sizeof(int32_t));
     w.pos = (int32_t *)(b + off), off += up(cap * sizeof(int32_t));
     w.sel = (int32_t *)(b + off), off += up(cap * sizeof(int32_t));
     w.ordered = (int32_t *)(b + off), off += up(cap * sizeof(int32_t));
@@ -459,10 +547,23 @@ int gi2d_train_grow(const gi2d_train_state *s, int max_points, int budget_cap, c
     const size_t cap = (size_t)(max_points > s->num_points ? max_points : s->num_points);
     const DensifyWs w = carve_densify(scratch, cap, (size_t)npix);
     RowArrays moments = rows_of(s);  // every array of a new row starts from zero; parameters are then written over it
-    hipLaunchKernelGGL(grow_error_kernel, dim3((npix + 255) / 256), dim3(256), 0, st, npix, (const float *)s->out_img,
-                       s->gt, w.key);
-    hipLaunchKernelGGL(grow_select_kernel, dim3(1), dim3(1024), 0, st, npix, (const uint32_t *)w.key,
-                       (const int32_t *)s->num_points_dev, s->num_points, max_points, budget_cap, kmax, w.sel, w.info);
+    const int err_threads = npix > GI2D_SEL_STATE_WORDS ? npix : GI2D_SEL_STATE_WORDS;
+    hipLaunchKernelGGL(grow_error_kernel, dim3((err_threads + 255) / 256), dim3(256), 0, st, npix,
+                       (const float *)s->out_img, s->gt, w.key, w.sel_state, GI2D_SEL_STATE_WORDS);
+    const dim3 sg(GI2D_SEL_WGS), sb(1024);
+    const uint32_t *key = (const uint32_t *)w.key;
+    const int32_t *n_dev = (const int32_t *)s->num_points_dev;
+    hipLaunchKernelGGL(grow_hist_kernel<24>, sg, sb, 0, st, npix, key, n_dev, s->num_points, max_points, budget_cap, kmax,
+                       w.sel_state, w.info);
+    hipLaunchKernelGGL(grow_hist_kernel<16>, sg, sb, 0, st, npix, key, n_dev, s->num_points, max_points, budget_cap, kmax,
+                       w.sel_state, w.info);
+    hipLaunchKernelGGL(grow_hist_kernel<8>, sg, sb, 0, st, npix, key, n_dev, s->num_points, max_points, budget_cap, kmax,
+                       w.sel_state, w.info);
+    hipLaunchKernelGGL(grow_hist_kernel<0>, sg, sb, 0, st, npix, key, n_dev, s->num_points, max_points, budget_cap, kmax,
+                       w.sel_state, w.info);
+    hipLaunchKernelGGL(grow_count_kernel, sg, sb, 0, st, npix, key, (const int32_t *)w.info, w.sel_state);
+    hipLaunchKernelGGL(grow_write_kernel, sg, sb, 0, st, npix, key, (const int32_t *)w.info,
+                       (const int32_t *)w.sel_state, w.sel);
     hipLaunchKernelGGL(grow_rank_kernel, dim3((kmax + 255) / 256), dim3(256), 0, st, (const uint32_t *)w.key,
                        (const int32_t *)w.sel, (const int32_t *)w.info, w.ordered);
     hipLaunchKernelGGL(grow_append_kernel, dim3(1), dim3(1024), 0, st, moments, s->img_width, s->img_height,

@@ -605,7 +605,7 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
 struct PassHint {
     int *host = nullptr;  // pinned: where the report of the last call lands
     hipEvent_t landed = nullptr;
-    bool pending = false;
+    bool pending = false, discard = false;  // discard: the report in flight is about an earlier owner of the address
     long long total = 0, min_total = 0;  // tiles when that report was queued; smallest launch the form is used on
     int last = -1;        // tiles above GI2D_SMALL_CAP in the last pass of the last call that reported; -1: nothing known
 };
@@ -627,8 +627,8 @@ static bool stream_is_capturing(hipStream_t st) {
 }
 static void hint_poll(PassHint &h) {
     if (h.pending && hipEventQuery(h.landed) == hipSuccess) {
-        h.last = *h.host;
-        h.pending = false;
+        if (!h.discard) h.last = *h.host;
+        h.pending = h.discard = false;
     }
 }
 // smallest launch the form is used on: below it the small form's higher occupancy has nothing to fill (one 768x512 image
@@ -670,9 +670,8 @@ static void pass_form_end(const void *key, const int *count_word, long long tota
     }
     PassHint &h = g_hints[key];
     if (h.pending) {  // the previous report has not been looked at: is it there by now?
-        if (hipEventQuery(h.landed) != hipSuccess) return;  // still in flight: its buffer is not ours to overwrite yet
-        h.last = *h.host;
-        h.pending = false;
+        hint_poll(h);
+        if (h.pending) return;  // still in flight: its buffer is not ours to overwrite yet
     }
     if (!h.host && (hipHostMalloc((void **)&h.host, sizeof(int), hipHostMallocDefault) != hipSuccess ||
                     hipEventCreateWithFlags(&h.landed, hipEventDisableTiming) != hipSuccess)) {
@@ -722,6 +721,11 @@ void single_pass_end(const void *ws, const FastWs &w, long long tiles, hipStream
 namespace gi2d {
 // gi2d_fast_workspace_init without its argument checks; `only_if_moved`: see fast_ws_init_kernel
 int launch_workspace_init(void *ws, int n, int tiles_x, int tiles_y, const int32_t *only_if_moved, gi2d_stream_t st) {
+    if (!only_if_moved) {  // a workspace that starts over: what an earlier owner of this address reported is not about it
+        std::lock_guard<std::mutex> lock(g_hint_mu);
+        const auto it = g_hints.find(ws);
+        if (it != g_hints.end()) it->second.last = -1, it->second.discard = it->second.pending;
+    }
     FastWs w = carve_fast(ws, n, tiles_x * tiles_y);
     const int t = tiles_x * tiles_y;
     const int work = t > n ? t : n;
