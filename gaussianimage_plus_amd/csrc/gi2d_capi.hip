@@ -57,6 +57,9 @@ static std::string dev_switches() {
 #ifdef GI2D_FUSED_TRACE
     add("GI2D_FUSED_TRACE", "");
 #endif
+#ifdef GI2D_NO_QUANT_FINISH
+    add("GI2D_NO_QUANT_FINISH", "");
+#endif
 #ifdef GI2D_BATCH_LOG
     add("GI2D_BATCH_LOG", "");
 #endif

@@ -1541,13 +1541,17 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
             if (model == 2) {
                 hipLaunchKernelGGL(train_reduce_update_quant_kernel<2>, dim3(l.blocks), dim3(l.bs), 0, st, uq, Q, a[0],
                                    a[1], a[2], step);
+#ifndef GI2D_NO_QUANT_FINISH /* development aid (wrong results): what the closing launch costs an iteration */
                 hipLaunchKernelGGL(train_quant_finish_kernel<2>, dim3(1), dim3(256), 0, st, l.rows, uq, Q, a[1], aq[0],
                                    aq[1], aq[2], step);
+#endif
             } else {
                 hipLaunchKernelGGL(train_reduce_update_quant_kernel<1>, dim3(l.blocks), dim3(l.bs), 0, st, uq, Q, a[0],
                                    a[1], a[2], step);
+#ifndef GI2D_NO_QUANT_FINISH
                 hipLaunchKernelGGL(train_quant_finish_kernel<1>, dim3(1), dim3(256), 0, st, l.rows, uq, Q, a[1], aq[0],
                                    aq[1], aq[2], step);
+#endif
             }
         }
         single_pass_end(s->workspace, w, tiles, st);
