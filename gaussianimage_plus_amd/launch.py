@@ -392,6 +392,9 @@ def main(argv=None):
     ap.add_argument("--color_bit", type=int, default=6)
     ap.add_argument("--loop", choices=["native", "autograd"], default="native",
                     help="native: fused training iteration (gi2d_train_step); autograd: gsplat wrappers + torch Adam")
+    ap.add_argument("--graph", action="store_true",
+                    help="--loop autograd only: capture one whole iteration (render, loss, backward, Adam step) in a HIP "
+                         "graph after three eager iterations and replay it (fit_image(graph=True))")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -441,7 +444,7 @@ def main(argv=None):
         if args.loop == "native":
             r = fit_image_native(img.to(dev), args.num_points, args.iterations, **native_kw)
         else:
-            r = fit_image(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed)
+            r = fit_image(img.to(dev), args.num_points, args.iterations, lr=args.lr, seed=args.seed, graph=args.graph)
         report(i, img, r)
         return r
 

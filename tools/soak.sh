@@ -11,6 +11,7 @@ run --synthetic 4 --model cholesky --num_points 10000 --iterations 3000
 run --synthetic 4 --model cholesky --num_points 10000 --iterations 3000 --opt_type adam
 run --synthetic 2 --model covariance --num_points 20000 --max_num_points 60000 --iterations 3000 --grow_iter 300 --height 1356 --width 2040
 run --synthetic 3 --model covariance --num_points 3000 --iterations 300 --loop autograd
+run --synthetic 3 --model cholesky --num_points 3000 --iterations 600 --loop autograd --graph
 run --synthetic 5 --model covariance --num_points 5000 --max_num_points 50000 --iterations 4000 --grow_iter 400 --height 500 --width 333
 # several images per GPU: three batches on three streams (the default), one stream per image, quantised in batches
 run --synthetic 6 --model covariance --num_points 2500 --max_num_points 20000 --iterations 4000 --grow_iter 400 --images_per_gpu 6
