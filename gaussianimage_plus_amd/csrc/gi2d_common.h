@@ -106,7 +106,10 @@ __device__ __forceinline__ ConicS scale_conic(float a, float b, float c) {
     return s;
 }
 __device__ __forceinline__ float row_term_b(const ConicS &s, float dy) { return s.hb * dy; }
-__device__ __forceinline__ float row_term_c(const ConicS &s, float dy) { return s.hc * dy * dy; }
+// (the closing "+ 0": sigma' must come out as +0, not -0, for a pixel exactly on the centre of a negative conic -- the
+// reference's `sigma < 0.f` (forward.cu:539) is false for -0, so that pair lands -- and -0 + +0 = +0 in round-to-nearest,
+// while every non-zero product is unchanged; same instruction count: the multiply becomes a multiply-add)
+__device__ __forceinline__ float row_term_c(const ConicS &s, float dy) { return __builtin_fmaf(s.hc * dy, dy, 0.f); }
 __device__ __forceinline__ float pair_sigma(const ConicS &s, float dx, float bdy, float cdy2) {
     return __builtin_fmaf(dx, __builtin_fmaf(s.ha, dx, bdy), cdy2);
 }
@@ -117,25 +120,35 @@ __device__ __forceinline__ float pair_vis(float sigma_l2) { return __builtin_amd
 // non-negative floats "<=" is the order of their bit patterns while every negative float (sign bit set) compares
 // above all of them as an unsigned integer:
 //     lands  <=>  (unsigned)bits(sigma') < lim,      lim = bits(log2(255 * opac)) + 1      (one v_cmp instead of two)
-// lim = 0: never (255 * opac < 1, opac <= 0).  A gaussian with a NaN among its parameters keeps the reference's
-// behaviour -- every comparison with NaN is false, so nothing is skipped and alpha = fminf(1, NaN) = 1 -- with
-// lim = 0xffffffff.  `clamp`: min(1, .) can bind (opac > 1, or NaN): with 0 <= opac <= 1 a landing pair has
-// vis <= 1 (v_exp_f32 of a non-positive argument never exceeds 1: tools/ubench/exp_le_one.hip sweeps it), so
-// opac * vis <= 1 and the min is the identity -- loops over entries none of which needs it run without the two v_min.
+// lim = 0: never (255 * opac < 1, opac <= 0).  A gaussian with a NaN or an infinity among its parameters ("odd") keeps
+// the reference's two comparisons as they are written -- every comparison with NaN is false, so a NaN sigma is not
+// skipped and alpha = fminf(1, NaN) = 1, while sigma = +-inf (an infinite conic away from the centre) is skipped by one
+// test or the other -- with lim = 0xffffffff, which the CLAMP form of the pixel loops reads as "evaluate the
+// reference's expression" (pair_lands_odd; such an entry always sets `clamp`).  `clamp`: min(1, .) can bind (opac > 1,
+// or odd): with 0 <= opac <= 1 a landing pair has vis <= 1 (v_exp_f32 of a non-positive argument never exceeds 1:
+// tools/ubench/exp_le_one.hip sweeps it), so opac * vis <= 1 and the min is the identity -- loops over entries none of
+// which needs it run without the two v_min.
 struct AlphaRule {
     unsigned lim;
     bool clamp;
 };
+#define GI2D_LIM_ODD 0xffffffffu
 __device__ __forceinline__ AlphaRule alpha_rule(float gx, float gy, float a, float b, float c, float opac) {
     AlphaRule r;
+    // NaN, +-inf, inf - inf -- or six finite values whose sum overflows, which the exact comparisons serve just as well
     const float s = gx + gy + a + b + c + opac;
-    const bool has_nan = s != s;  // (also inf - inf: such a gaussian is evaluated everywhere, as one with a NaN is)
-    r.clamp = has_nan || !(opac <= 1.f);
+    const bool odd = !(__builtin_fabsf(s) <= 3.4028235e38f);
+    r.clamp = odd || !(opac <= 1.f);
     const float smax = __builtin_amdgcn_logf(opac * 255.f);  // v_log_f32 = log2
-    r.lim = has_nan ? 0xffffffffu : (smax >= 0.f ? (unsigned)__float_as_int(smax) + 1u : 0u);
+    r.lim = odd ? GI2D_LIM_ODD : (smax >= 0.f ? (unsigned)__float_as_int(smax) + 1u : 0u);
     return r;
 }
 __device__ __forceinline__ bool pair_lands(float sigma_l2, unsigned lim) { return (unsigned)__float_as_int(sigma_l2) < lim; }
+// the same for the loops that serve entries with `clamp` set: an odd entry is tested as forward.cu:539-541 writes it
+// (`alpha_unclamped` = opac * vis)
+__device__ __forceinline__ bool pair_lands_odd(float sigma_l2, float alpha_unclamped, unsigned lim) {
+    return lim == GI2D_LIM_ODD ? !(sigma_l2 < 0.f || fminf(1.f, alpha_unclamped) < (1.f / 255.f)) : pair_lands(sigma_l2, lim);
+}
 
 // Conservative pixel-space bounding box of {sigma <= ln(255*opac)} (the only place where a
 // pair can pass `alpha >= 1/255`, forward.cu:541), widened by a safety margin.  Returns false

@@ -238,12 +238,14 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
     } else {
         hr = head_row_for(a.lists, a.tile_order, slot, tile);
     }
+    // (ahead of the early return below: the launch's first workgroup records which record set this pass reads --
+    // RecSets::ver[0] -- whether or not its own tile is left to phase 2; a pipelined end-of-step kernel reads that word)
+    const float4 *recs = recs_for_tile_pass(a.rs, first && threadIdx.x == 0);
     if (PHASE == 1 || (PHASE == 0 && mark_big)) {
         const bool big = __builtin_amdgcn_readfirstlane(hr.hdr_count) > GI2D_SMALL_CAP;  // workgroup-uniform
         if (threadIdx.x == 0) a.big_tile[tile] = big ? 1 : 0;
         if (PHASE == 1 && big) return;
     }
-    const float4 *recs = recs_for_tile_pass(a.rs, first && threadIdx.x == 0);
     // (phase 2 loops over tiles: its loop keeps the lane's invariants alive, so the forward's trips are not unrolled there)
     fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
                           a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);

@@ -116,12 +116,14 @@ __device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px
         const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
         const v2f cb = {q4.x, q4.y};
         const v2f dx = gx - px2, dy = gy - py2;
-        const v2f bdy = hb * dy, cdy2 = hc * dy * dy;  // == row_term_b / row_term_c
+        const v2f zero2 = {0.f, 0.f};
+        const v2f bdy = hb * dy, cdy2 = __builtin_elementwise_fma(hc * dy, dy, zero2);  // == row_term_b / row_term_c
         const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
         const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
         const v2f tt = op * vis;
-        const bool ok0 = pair_lands(sig.x, (unsigned)__float_as_int(q4.z));  // forward.cu:539-541
-        const bool ok1 = pair_lands(sig.y, (unsigned)__float_as_int(q4.w));
+        // forward.cu:539-541
+        const bool ok0 = CLAMP ? pair_lands_odd(sig.x, tt.x, (unsigned)__float_as_int(q4.z)) : pair_lands(sig.x, (unsigned)__float_as_int(q4.z));
+        const bool ok1 = CLAMP ? pair_lands_odd(sig.y, tt.y, (unsigned)__float_as_int(q4.w)) : pair_lands(sig.y, (unsigned)__float_as_int(q4.w));
         v2f am = {ok0 ? tt.x : 0.f, ok1 ? tt.y : 0.f};
         if (CLAMP) am = (v2f){fminf(1.f, am.x), fminf(1.f, am.y)};
         a0 = __builtin_elementwise_fma(cr, am, a0);
@@ -513,8 +515,10 @@ __device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc
         const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
         const v2f t = in.opac2 * vis;
         // backward.cu:903 (idx <= final_idx) and :922-926 (sigma < 0 || alpha < 1/255: the forward's pair test)
-        const bool ok0 = in.in_a && fidx_admits<USE_FIDX>(in.idx, P1.z) && pair_lands(sig.x, in.lim);
-        const bool ok1 = in.in_b && fidx_admits<USE_FIDX>(in.idx, P1.w) && pair_lands(sig.y, in.lim);
+        const bool ok0 = in.in_a && fidx_admits<USE_FIDX>(in.idx, P1.z) &&
+                         (CLAMP ? pair_lands_odd(sig.x, t.x, in.lim) : pair_lands(sig.x, in.lim));
+        const bool ok1 = in.in_b && fidx_admits<USE_FIDX>(in.idx, P1.w) &&
+                         (CLAMP ? pair_lands_odd(sig.y, t.y, in.lim) : pair_lands(sig.y, in.lim));
         const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
         v2f am = tz;
         if (CLAMP) am = (v2f){fminf(1.f, tz.x), fminf(1.f, tz.y)};

@@ -353,7 +353,21 @@ Tensor fast_forward(Tensor &ws, Tensor &status, int num_points, int tiles_x, int
     GI2D_CHECK_I32(status);
     if (background) {
         GI2D_CHECK_F32(*background);
+        TORCH_CHECK(background->numel() >= 3 && background->device() == xys.device(), "background must hold 3 floats on the inputs' device");
     }
+    // the kernels trust num_points / tiles against the buffers: say so here, where a mismatch can still raise
+    GI2D_CHECK_INPUT(ws);
+    TORCH_CHECK(num_points >= 0 && tiles_x >= 0 && tiles_y >= 0, "negative size");
+    TORCH_CHECK(xys.dim() == 2 && xys.size(0) == num_points && xys.size(1) == 2, "xys must be [num_points, 2]");
+    TORCH_CHECK(radii.numel() == num_points, "radii must hold num_points entries");
+    TORCH_CHECK(conics.numel() == 3 * (int64_t)num_points, "conics must be [num_points, 3]");
+    TORCH_CHECK(colors.numel() == 3 * (int64_t)num_points, "colors must be [num_points, 3]");
+    TORCH_CHECK(opacities.numel() == num_points, "opacities must be [num_points, 1]");
+    TORCH_CHECK(status.numel() >= 4, "status must hold 4 words");
+    for (const Tensor *t : std::initializer_list<const Tensor *>{&radii, &conics, &colors, &opacities, &status, &ws})
+        TORCH_CHECK(t->device() == xys.device(), "every tensor of a fast_forward call must live on xys' device");
+    TORCH_CHECK((int64_t)tiles_x * 16 >= (int64_t)img_width && (int64_t)tiles_y * 16 >= (int64_t)img_height,
+                "tile grid does not cover the image");
     Tensor out_img = f32(xys, {(int64_t)img_height, (int64_t)img_width, 3});
     c10::hip::HIPGuardMasqueradingAsCUDA guard(xys.device());
     gi2d_stream_t st = stream_of(xys);
@@ -373,6 +387,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, c10::optional<Tensor>> fast_backward(
                                                                                 unsigned img_height,
                                                                                 unsigned img_width, bool with_abs) {
     GI2D_CHECK_F32(v_output);
+    GI2D_CHECK_INPUT(ws);
+    TORCH_CHECK(num_points >= 0 && tiles_x >= 0 && tiles_y >= 0, "negative size");
+    TORCH_CHECK(ws.device() == v_output.device(), "workspace and v_output must live on the same device");
+    TORCH_CHECK(v_output.numel() == (int64_t)img_height * img_width * 3, "v_output must be [H, W, 3]");
+    TORCH_CHECK((int64_t)tiles_x * 16 >= (int64_t)img_width && (int64_t)tiles_y * 16 >= (int64_t)img_height,
+                "tile grid does not cover the image");
     const int n = num_points;
     Tensor v_xy = f32(v_output, {n, 2}), v_conic = f32(v_output, {n, 3}), v_colors = f32(v_output, {n, 3});
     Tensor v_opacity = f32(v_output, {n, 1});

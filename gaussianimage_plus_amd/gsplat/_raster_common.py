@@ -13,10 +13,20 @@ remove).  A workspace is checked synchronously on its first use and whenever the
 pass was above half the row capacity; otherwise the 16 status bytes travel to pinned memory behind the kernels and are
 read when the host next touches the workspace (the backward, or the next forward): by then they have arrived, and the
 GPU never idles.  An overflow found that way -- a row going from <= 512 to > 1024 candidates between two consecutive
-calls -- raises (see _settle); GI2D_WRAPPER_SYNC=1 restores the synchronous check."""
+calls -- raises (see _settle); GI2D_WRAPPER_SYNC=1 restores the synchronous check.
+
+No forward stays unchecked: a workspace with a posted status sits in `_pending` until it is settled -- by its own next
+use, by ANY later forward / backward of the wrappers once its copy has landed (`_settle_landed`: an event query, no
+wait), by `settle_all()` (blocking; launch.fit_image calls it behind its last evaluation render), or by the
+interpreter-exit hook, which can only report.  And the "slowly moving rows" premise is only trusted within one run of
+calls: a workspace that was not used for more than IDLE_RECHECK_S seconds (the pool hands a workspace to whichever
+scene of its shape comes next -- train.py's next image, a checkpoint just loaded) is checked synchronously again."""
 from __future__ import annotations
 
+import atexit
 import os
+import sys
+import time
 
 import torch
 
@@ -26,8 +36,11 @@ BLOCK = 16
 # GI2D_WRAPPER_SYNC=1: wait for the status words of every forward before its image is handed on (the behaviour of
 # rounds 1-3: one GPU queue drain per iteration).  Default: see FastWorkspace.must_check_now / _settle.
 SYNC_EVERY_FORWARD = os.environ.get("GI2D_WRAPPER_SYNC", "0") == "1"
+IDLE_RECHECK_S = 0.05  # a workspace idle for longer may have changed hands: its next pass is checked at once
 _capacity = {}   # exact path: (device index, N, H, W) -> intersection capacity
 _pool = {}       # fast path: (device index, N, tiles_x, tiles_y) -> idle FastWorkspace objects
+_pending = []    # workspaces whose last forward posted its status words and has not been looked at yet
+_captured = []   # workspaces a captured forward ran on (check_captured), pooled or still leased
 
 
 def tile_bounds_of(img_height: int, img_width: int, block_h: int, block_w: int):
@@ -60,6 +73,8 @@ def _settle(ws, what: str) -> None:
     one call earlier) means an image has already been handed on that was rendered from a truncated tile list: the
     workspace is emptied, every later call on it is checked before its result is used -- and falls back to the
     capacity-free ops -- and the caller is told."""
+    if ws in _pending:
+        _pending.remove(ws)
     st = ws.settle()
     if st is not None and st[1]:
         ws.reset()
@@ -70,22 +85,52 @@ def _settle(ws, what: str) -> None:
             "GI2D_WRAPPER_SYNC=1 to check every forward before its result is used.")
 
 
+def _settle_landed(skip=None) -> None:
+    """Look at every posted status whose copy has already landed (no waiting): a forward that nothing on its own
+    workspace follows -- the last evaluation render of a loop -- is checked by whatever wrapper call comes next."""
+    for ws in list(_pending):
+        if ws is not skip and ws.event is not None and ws.event.query():
+            _settle(ws, "an earlier forward (its workspace was not used again)")
+
+
+def settle_all() -> None:
+    """Blocking: look at the status words of every forward that has not been checked yet (raises as _settle does).  For
+    callers whose last wrapper call is a forward: an evaluation render followed by nothing."""
+    for ws in list(_pending):
+        _settle(ws, "an earlier forward")
+
+
+def _report_at_exit() -> None:  # the last resort: nothing can be raised to anyone any more
+    try:
+        settle_all()
+    except RuntimeError as e:
+        print(f"ERROR at interpreter exit: {e}", file=sys.stderr)
+    except Exception:  # the device may already be gone
+        pass
+
+
+atexit.register(_report_at_exit)
+
+
 def check_captured() -> None:
-    """For loops replayed from a captured graph: look (synchronously) at the status words of every pooled workspace a
-    captured forward ran on.  A tile row that overflowed in some replay since the last look (more than 1024 candidate
-    gaussians in one 16x16 tile) means images were rendered from truncated tile lists -- the sticky word remembers it --
-    and raises; the exact fallback of the eager path cannot run inside a graph, so such a scene needs the eager loop."""
-    for free in _pool.values():
-        for ws in free:
-            if getattr(ws, "captured", False):
-                sticky = int(ws.status[2].item())
-                if sticky:
-                    ws.captured = False
-                    ws.reset()
-                    raise RuntimeError(
-                        f"gsplat drop-in: a tile row overflowed (> {_C.fast_tile_capacity()} candidate gaussians in one "
-                        "tile) in a replay of a captured iteration; its images were rendered from truncated tile lists. "
-                        "Run this scene through the eager loop (which falls back to the capacity-free ops).")
+    """For loops replayed from a captured graph: look (synchronously) at the status words of every workspace a captured
+    forward ran on -- pooled or still leased (a caller that keeps the captured loss or output alive, or uses
+    retain_graph, holds the lease): `_captured` is a registry of its own.  A tile row that overflowed in some replay
+    since the last look (more than 1024 candidate gaussians in one 16x16 tile) means images were rendered from
+    truncated tile lists -- the sticky word remembers it -- and raises; the exact fallback of the eager path cannot run
+    inside a graph, so such a scene needs the eager loop."""
+    for ws in list(_captured):
+        if not getattr(ws, "captured", False):
+            _captured.remove(ws)
+            continue
+        if int(ws.status[2].item()):
+            ws.captured = False
+            _captured.remove(ws)
+            ws.reset()
+            raise RuntimeError(
+                f"gsplat drop-in: a tile row overflowed (> {_C.fast_tile_capacity()} candidate gaussians in one "
+                "tile) in a replay of a captured iteration; its images were rendered from truncated tile lists. "
+                "Run this scene through the eager loop (which falls back to the capacity-free ops).")
 
 
 def _exact_forward(plus, xys, radii, conics, colors, opacity, img_height, img_width, tile_bounds, block, img_size,
@@ -126,12 +171,19 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
     capturing = torch.cuda.is_current_stream_capturing()
     if not capturing:
         _settle(ws, "the previous forward on this workspace")
+        _settle_landed(skip=ws)
+        now = time.monotonic()
+        if now - getattr(ws, "last_use", now) > IDLE_RECHECK_S:
+            ws.fullest = None  # may serve another scene now: checked before its image is handed on
+        ws.last_use = now
     # "not a single intersection -> background image" (rasterize_sum_plus.py:110-118) is decided on the device
     out_img = _C.fast_forward(ws, xys, radii, conics, colors, opacity, img_height, img_width, radius_clip,
                               background=background)
     ctx.exact = None
     if capturing:
         ws.captured = True
+        if ws not in _captured:
+            _captured.append(ws)
     elif SYNC_EVERY_FORWARD or ws.must_check_now:
         _, overflow = ws.read_now()
         if overflow:
@@ -144,7 +196,8 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
             ctx.exact = (gids, bins, final_idx)
             lease = None
     else:
-        ws.post()  # looked at when the host next needs this workspace (the backward, or the next forward)
+        ws.post()  # looked at when the host next needs this workspace (the backward, or the next forward) ...
+        _pending.append(ws)  # ... or by whichever wrapper call comes next once the copy has landed (_settle_landed)
     # rasterize_sum.py returns these; the plus wrapper drops them (final_T is never updated: forward.cu:558)
     final_Ts = None if plus else torch.ones(img_height, img_width, device=xys.device)
     cnt_gs_counts = None if plus else torch.zeros(img_height, img_width, dtype=torch.int32, device=xys.device)
@@ -172,6 +225,7 @@ def backward_impl(ctx, plus: bool, v_out_img):
     else:
         if not torch.cuda.is_current_stream_capturing():
             _settle(ctx.lease.ws, "this backward's forward")
+            _settle_landed(skip=ctx.lease.ws)
         # without a single intersection the tile pass finds empty rows and the per-gaussian sums are zeros
         v_xy, v_conic, v_colors, v_opacity, v_abs = _C.fast_backward(
             ctx.lease.ws, xys, radii, v_out_img, ctx.img_height, ctx.img_width, ctx.radius_clip, with_abs=not plus)

@@ -313,6 +313,8 @@ def fit_image(gt_hwc: torch.Tensor, num_points: int, iterations: int, lr: float 
         torch.cuda.synchronize(dev)
         eval_s = (time.time() - t0) / max(eval_renders, 1)
         mse = torch.nn.functional.mse_loss(img, gt_hwc).item()
+    from .gsplat import _raster_common as _rc
+    _rc.settle_all()  # the last render's status words (read one call late otherwise: no call follows)
     psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
     return {"psnr": psnr, "train_s": train_s, "eval_s": eval_s, "num_gaussians": num_points, "mse": mse}
 

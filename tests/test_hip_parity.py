@@ -538,6 +538,10 @@ def test_nan_parameters_and_odd_opacities_follow_the_reference_comparisons(C, or
     op[11, 0], op[12, 0], op[13, 0] = 0.0, -0.5, 1.0 / 300.0   # never land
     op[17, 0], op[18, 0] = 2.5, 40.0             # min(1, .) binds
     xys[21] = [np.nan, 20.0]                     # NaN centre: listed in no tile by the binning (radius box of NaN)
+    # infinite conic entries: sigma = +-inf away from the centre's pixel column (skipped by `alpha < 1/255` / `sigma < 0`),
+    # NaN on it (inf * 0: nothing is skipped, alpha = 1) -- the centre's x is an integer so that the column exists
+    xys[23], xys[26] = [30.0, 20.3], [17.0, 9.2]
+    conics[23, 0], conics[26, 0] = np.inf, -np.inf
     m, cum = oracle.compute_cumulative_intersects(_num_tiles_hit(xys, radii, tb))
     _, _, so, go, bins = oracle.bin_and_sort_gaussians(npts, m, xys, np.zeros(npts, np.float32), radii, cum, tb, 1.0)
     out_o, fT_o, fidx_o = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, xys, conics, col, op)
@@ -554,10 +558,79 @@ def test_nan_parameters_and_odd_opacities_follow_the_reference_comparisons(C, or
         ty, tx = divmod(t0, tb[0])
         px = got[16 * ty + 3, 16 * tx + 3]
         assert (px >= col[g] - 1e-5).all()
+    for g in (23, 26):  # ... and the infinite conics on their centre's column only (the oracle agrees: checked above)
+        row = int(xys[g, 1])
+        assert (out_o[row, int(xys[g, 0])] >= col[g] - 1e-5).all()
     # fused fast path: same image
     ws = C.FastWorkspace(npts, tb, t(xys))
     img = C.fast_forward(ws, t(xys), t(radii), t(conics), t(col), t(op), h, w, 1.0)
     assert torch.equal(img, out)
+
+
+def test_pixel_on_the_centre_of_a_negative_conic_lands_as_in_the_reference(C, oracle):
+    """forward.cu:539 skips a pair on `sigma < 0.f`.  A gaussian with conic (-a, -b, -c) whose centre sits exactly on an
+    integer pixel evaluates sigma = -0.0 THERE -- and -0 < 0 is false: the pair lands with alpha = min(1, opac) while
+    every other pixel of the gaussian's tiles sees sigma < 0.  The kernels test a pair with one unsigned compare of
+    sigma's bit pattern (gi2d_common.h::pair_lands), for which -0.0 = 0x80000000 would read as "negative": the row term
+    is therefore formed as fma(hc dy, dy, +0) (-0 + +0 = +0).  Forward pixel and gradients of every kernel form against
+    the oracle, which evaluates the reference's own expression."""
+    from gaussianimage_plus_amd import _lib
+    h, w, npts = 48, 64, 24
+    tb = oracle.tile_bounds(h, w)
+    rng = np.random.default_rng(31)
+    xys = (rng.random((npts, 2)) * np.array([w, h])).astype(np.float32)
+    s = rng.uniform(1.0, 3.0, (npts, 2)).astype(np.float32)
+    conics = np.stack([1 / s[:, 0] ** 2, rng.uniform(-0.05, 0.05, npts).astype(np.float32), 1 / s[:, 1] ** 2], 1).astype(np.float32)
+    radii = np.ceil(3 * s.max(1)).astype(np.int32)
+    col = rng.uniform(0.1, 1.0, (npts, 3)).astype(np.float32)
+    op = rng.uniform(0.3, 1.0, (npts, 1)).astype(np.float32)
+    # negative definite conics on integer pixels: inside a tile, on a tile corner, with opacity above 1 (clamp binds)
+    for g, (cx, cy, o) in {2: (21.0, 13.0, 0.8), 5: (32.0, 16.0, 0.5), 9: (40.0, 30.0, 3.0)}.items():
+        xys[g] = [cx, cy]
+        conics[g] = [-0.3, -0.05, -0.2]
+        op[g, 0] = o
+        radii[g] = 4
+    conics[14] = [-0.3, -0.05, -0.2]  # the same conic off the pixel grid: lands nowhere
+    m, cum = oracle.compute_cumulative_intersects(_num_tiles_hit(xys, radii, tb))
+    _, _, so, go, bins = oracle.bin_and_sort_gaussians(npts, m, xys, np.zeros(npts, np.float32), radii, cum, tb, 1.0)
+    out_o, fT_o, fidx_o = oracle.rasterize_sum_forward(tb, (16, 16, 1), (w, h, 1), go, bins, xys, conics, col, op)
+    v_out = (rng.normal(size=(h, w, 3)) * 1e-2).astype(np.float32)
+    g_o = oracle.rasterize_sum_backward(h, w, 16, 16, go, bins, xys, conics, col, op, None, fT_o, fidx_o, v_out)
+    # the oracle does land the three pairs: each adds colour * min(1, opacity) to its pixel, and only there
+    for g, alpha in ((2, 0.8), (5, 0.5), (9, 1.0)):
+        assert np.allclose(g_o[2][g], alpha * v_out[int(xys[g, 1]), int(xys[g, 0])], rtol=1e-6), "the oracle skipped the pair"
+    assert not g_o[2][14].any()
+
+    def same(tag, img, grads):
+        np.testing.assert_allclose(n(img), out_o, rtol=2e-5, atol=2e-6, err_msg=tag)
+        for name, got, want in zip(("v_xy", "v_conic", "v_rgb", "v_opacity"), grads, g_o):
+            np.testing.assert_allclose(n(got).reshape(want.shape), want, rtol=2e-5, atol=1e-7, err_msg=f"{tag} {name}")
+
+    bg = torch.zeros(3, device=DEV)
+    txys, tcon, tcol, top, trad, tv = t(xys), t(conics), t(col), t(op), t(radii), t(v_out)
+    # (1) the ops behind the reference's binding names
+    out, fT, fidx = C.rasterize_sum_plus_forward(tb, (16, 16, 1), (w, h, 1), t(go), t(bins), txys, tcon, tcol, top, bg, False)
+    res = C.rasterize_sum_plus_backward(h, w, 16, 16, t(go), t(bins), txys, tcon, tcol, top, bg, fT, fidx, tv, None)
+    same("plus", out, res[:4])
+    # (2) the two-kernel fast path of the autograd wrappers
+    ws = C.FastWorkspace(npts, tb, txys)
+    out_f = C.fast_forward(ws, txys, trad, tcon, tcol, top, h, w, 1.0)
+    same("fast", out_f, C.fast_backward(ws, txys, trad, tv, h, w, 1.0)[:4])
+    assert torch.equal(out_f, out)
+    # (3) the single-pass forward + backward kernel
+    ws1 = C.FastWorkspace(npts, tb, txys)
+    out1 = torch.empty(h, w, 3, device=DEV)
+    grads = [torch.empty(npts, k, device=DEV) for k in (2, 3, 3, 1)]
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("gi2d_fast_bin", npts, txys.data_ptr(), trad.data_ptr(), tcon.data_ptr(), tcol.data_ptr(), top.data_ptr(),
+              tb[0], tb[1], 1.0, ws1.buf.data_ptr(), ws1.buf.numel(), ws1.status.data_ptr(), st)
+    _lib.call("gi2d_fast_rasterize_forward_backward", npts, tb[0], tb[1], w, h, None, tv.data_ptr(), None, 0.0, None,
+              ws1.buf.data_ptr(), ws1.buf.numel(), ws1.status.data_ptr(), out1.data_ptr(), st)
+    _lib.call("gi2d_fast_rasterize_backward_reduce", npts, tb[0], tb[1], ws1.buf.data_ptr(), ws1.buf.numel(),
+              grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), None, st)
+    torch.cuda.synchronize()
+    same("single-pass", out1, grads)
+    assert torch.equal(out1, out)
 
 
 def _num_tiles_hit(xys, radii, tb):

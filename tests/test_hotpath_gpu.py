@@ -531,3 +531,44 @@ def test_two_phase_tile_pass_on_a_large_image_with_crowded_tiles_equals_the_exac
         for a, b in ((fused.out_img, exact.out_img), (fused.v_params, exact.v_params), (fused.v_mean2d, exact.v_mean2d),
                      (fused.v_rgb, exact.v_rgb), (fused.v_opac, exact.v_opac)):
             assert torch.equal(a, b), step
+
+
+@pytest.mark.parametrize("h,w,n_bg,corner", [(640, 1024, 9000, True), (544, 768, 33500, False)])
+def test_pipelined_steps_of_a_two_phase_tile_pass_whose_first_slot_is_a_crowded_tile(h, w, n_bg, corner):
+    """The record-set bookkeeping of a tile pass (RecSets: the launch's first workgroup leaves ver[0] = the set it read)
+    must not depend on WHICH tile that workgroup handles.  In the two-launch form of a large image the small form's
+    first workgroup returns early when the tile at slot 0 holds more than 128 candidates; the pipelined end-of-step
+    kernel (reduce + projection backward of step i next to projection + binning of step i + 1) then reads `ver[0]`.
+    Two ways to get a crowded tile to slot 0: tile 0 itself crowded on a grid too large for the tile ordering
+    (identity order above 2048 tiles), and the FULLEST tile of a 1537 ... 2048-tile grid with more than 32 768
+    gaussians, which the ordering workgroup deals to slot 0.  Pipelined steps over frozen inputs, fused against the
+    capacity-free ops, bit for bit."""
+    from gaussianimage_plus_amd.hotpath import HotPath
+    rng = np.random.default_rng(5)
+    xyz_b, L_b, col_b, op_b = synth_cholesky(n_bg, h, w, 12)
+    n_cl = 400
+    centre_px = np.array([7.5, 8.5] if corner else [0.63 * w, 0.41 * h], np.float32)
+    pix = centre_px + rng.normal(size=(n_cl, 2)).astype(np.float32) * 2.5
+    xyz_c = (pix / np.array([0.5 * w, 0.5 * h], np.float32) - 1.0).clip(-0.995, 0.995).astype(np.float32)
+    L_c = np.stack([rng.uniform(0.4, 1.0, n_cl), rng.uniform(-0.2, 0.2, n_cl), rng.uniform(0.4, 1.0, n_cl)], 1).astype(np.float32)
+    col_c = rng.uniform(0, 0.02, (n_cl, 3)).astype(np.float32)
+    xyz, L = np.concatenate([xyz_b, xyz_c]), np.concatenate([L_b, L_c])
+    n = n_bg + n_cl
+    col, op = np.concatenate([col_b, col_c]), np.ones((n, 1), np.float32)
+    fused = HotPath(n, h, w, device=DEV, mode="fused")
+    exact = HotPath(n, h, w, device=DEV, mode="exact")
+    assert fused.T > 1536 and (corner == (fused.T > 2048)) and (corner or n > 32768)
+    v = _v_out(h, w, 6)
+    for hp in (fused, exact):
+        hp.set_inputs(xyz, L, col, op)
+        hp.set_v_out(v)
+    for step in range(4):  # (the ordering workgroup deals the fullest tile to slot 0 from the second step on)
+        fused.step(pipelined=True)
+        exact.step()
+        fused.check_status()
+        for a, b in ((fused.out_img, exact.out_img), (fused.v_params, exact.v_params), (fused.v_mean2d, exact.v_mean2d),
+                     (fused.v_rgb, exact.v_rgb), (fused.v_opac, exact.v_opac)):
+            assert torch.equal(a, b), step
+    ids, tbins = fused.tile_lists()
+    pop = (tbins[:, 1] - tbins[:, 0]).cpu().numpy()
+    assert pop.max() > 128 and (pop[0] > 128 if corner else True), "the scene must put a crowded tile at slot 0"

@@ -208,13 +208,14 @@ def test_a_tile_row_beyond_its_capacity_falls_back_to_the_capacity_free_ops(gs, 
     assert float(g_col[256 + 50:].abs().max()) == 0.0  # ids beyond the cap received nothing
 
 
-def test_an_overflow_found_one_call_late_raises_and_the_retry_is_exact(gs, oracle):
+def test_an_overflow_found_one_call_late_raises_and_the_retry_is_exact(gs, oracle, monkeypatch):
     """The status words of a forward are read when the host next touches the workspace (no GPU queue drain per
     iteration).  A tile row that goes from at most half its capacity to beyond it between two consecutive calls on the
     same workspace is therefore found late: that must be loud, and the same call repeated must then be exact."""
     from gaussianimage_plus_amd.gsplat import _raster_common
     if _raster_common.SYNC_EVERY_FORWARD:
         pytest.skip("GI2D_WRAPPER_SYNC=1: every forward is checked before its image is used")
+    monkeypatch.setattr(_raster_common, "IDLE_RECHECK_S", 1e9)  # (the calls below are one run, however slow the host)
     npts, h, w = 1300, 48, 64
     rng = np.random.default_rng(2)
     calm = (rng.uniform(-0.9, 0.9, (npts, 2)).astype(np.float32),
@@ -229,6 +230,59 @@ def test_an_overflow_found_one_call_late_raises_and_the_retry_is_exact(gs, oracl
     d = [p.detach().cpu().numpy() for p in proj]
     _stage_check(oracle, h, w, d[0], d[1], d[2], d[3], d[4], crowded[2], crowded[3], img.detach().cpu().numpy(),
                  v.cpu().numpy(), {"colors": g_col.cpu().numpy()})
+
+
+def test_a_workspace_that_sat_idle_is_checked_at_once_again(gs, oracle, monkeypatch):
+    """The pool hands a workspace to whichever scene of its shape comes next (train.py's next image, a checkpoint just
+    loaded): "its rows were at most half full one call ago" says nothing about THAT scene.  A workspace that was not
+    used for longer than IDLE_RECHECK_S is checked before its image is handed on -- the crowded scene falls back to the
+    capacity-free ops instead of being found one call late."""
+    import time
+    from gaussianimage_plus_amd.gsplat import _raster_common
+    if _raster_common.SYNC_EVERY_FORWARD:
+        pytest.skip("GI2D_WRAPPER_SYNC=1: every forward is checked before its image is used")
+    npts, h, w = 1300, 48, 64
+    rng = np.random.default_rng(4)
+    calm = (rng.uniform(-0.9, 0.9, (npts, 2)).astype(np.float32),
+            np.stack([rng.uniform(0.3, 0.6, npts), np.zeros(npts), rng.uniform(0.3, 0.6, npts)], 1).astype(np.float32),
+            rng.uniform(0, 1, (npts, 3)).astype(np.float32), np.ones((npts, 1), np.float32))
+    monkeypatch.setattr(_raster_common, "IDLE_RECHECK_S", 1e9)
+    _render_and_grad(gs, oracle, *calm, h, w)
+    _render_and_grad(gs, oracle, *calm, h, w)   # the check trails by one call from here on
+    monkeypatch.setattr(_raster_common, "IDLE_RECHECK_S", 0.05)
+    time.sleep(0.2)
+    crowded = _crowded_scene(npts, h, w, 6)
+    img, g_col, proj, v = _render_and_grad(gs, oracle, *crowded, h, w)  # no raise: checked at once, exact fallback
+    d = [p.detach().cpu().numpy() for p in proj]
+    _stage_check(oracle, h, w, d[0], d[1], d[2], d[3], d[4], crowded[2], crowded[3], img.detach().cpu().numpy(),
+                 v.cpu().numpy(), {"colors": g_col.cpu().numpy()})
+
+
+def test_the_last_forward_of_a_loop_does_not_stay_unchecked(gs, oracle, monkeypatch):
+    """A no-grad render that nothing on its workspace follows (the evaluation render at the end of a fit) posts its
+    status words like any other forward; `settle_all()` -- launch.fit_image calls it, and an interpreter-exit hook
+    reports what is left -- looks at them.  Here that render overflows a tile row one call after a calm one."""
+    from gaussianimage_plus_amd.gsplat import _raster_common
+    if _raster_common.SYNC_EVERY_FORWARD:
+        pytest.skip("GI2D_WRAPPER_SYNC=1: every forward is checked before its image is used")
+    monkeypatch.setattr(_raster_common, "IDLE_RECHECK_S", 1e9)
+    npts, h, w = 1300, 48, 64
+    rng = np.random.default_rng(8)
+    calm = (rng.uniform(-0.9, 0.9, (npts, 2)).astype(np.float32),
+            np.stack([rng.uniform(0.3, 0.6, npts), np.zeros(npts), rng.uniform(0.3, 0.6, npts)], 1).astype(np.float32),
+            rng.uniform(0, 1, (npts, 3)).astype(np.float32), np.ones((npts, 1), np.float32))
+    _render_and_grad(gs, oracle, *calm, h, w)
+    _render_and_grad(gs, oracle, *calm, h, w)
+    _raster_common.settle_all()  # nothing to report
+    tb = oracle.tile_bounds(h, w)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    xyz, L, col, op = _crowded_scene(npts, h, w, 9)
+    with torch.no_grad():
+        xys, depths, radii, conics, nth = gs.project_gaussians_2d(t(xyz), t(L), h, w, tb)
+        gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, t(col), t(op), h, w, background=torch.ones(3, device=DEV))
+    with pytest.raises(RuntimeError, match="overflowed"):
+        _raster_common.settle_all()
+    _raster_common.settle_all()  # reported once
 
 
 def test_compiled_and_ctypes_op_tables_agree_bit_for_bit(oracle):
