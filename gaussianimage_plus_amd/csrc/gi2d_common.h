@@ -147,7 +147,12 @@ __device__ __forceinline__ bool pair_lands(float sigma_l2, unsigned lim) { retur
 // the same for the loops that serve entries with `clamp` set: an odd entry is tested as forward.cu:539-541 writes it
 // (`alpha_unclamped` = opac * vis)
 __device__ __forceinline__ bool pair_lands_odd(float sigma_l2, float alpha_unclamped, unsigned lim) {
-    return lim == GI2D_LIM_ODD ? !(sigma_l2 < 0.f || fminf(1.f, alpha_unclamped) < (1.f / 255.f)) : pair_lands(sigma_l2, lim);
+    // Integer flags behind an empty asm: written as booleans, the per-lane choice between the two tests comes out of
+    // the compiler as divergent branches inside the pixel loops; this way it is two v_cndmask.
+    unsigned as_written = (!(sigma_l2 < 0.f) & !(fminf(1.f, alpha_unclamped) < (1.f / 255.f))) ? 1u : 0u;
+    unsigned fast = pair_lands(sigma_l2, lim) ? 1u : 0u;
+    asm volatile("" : "+v"(as_written), "+v"(fast));
+    return (lim == GI2D_LIM_ODD ? as_written : fast) != 0u;
 }
 
 // Conservative pixel-space bounding box of {sigma <= ln(255*opac)} (the only place where a

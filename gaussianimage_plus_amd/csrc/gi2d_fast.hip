@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     if (tid == 0) fwd_stage_dummy(sm.f);
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
     const int L = tile_list_head<false>(
-        ids, grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
+        ids, grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int, const BinRec &br) { return br; },
+        [&](int rank, int g, const BinRec &br) {
             const GaussRec &r = br.r;
             // the backward kernel finds the entry's partial row by this code; a pool row past the pool's end (the
             // overflow status is raised here) becomes "no row"

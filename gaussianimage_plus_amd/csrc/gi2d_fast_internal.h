@@ -384,19 +384,22 @@ __device__ __forceinline__ float4 *partial_row(int slot, float4 *__restrict__ pa
 // What every tile kernel of the fast path does first (all 256 lanes of the tile's workgroup): read the tile's row,
 // test every entry against the box its gaussian is binned with NOW (its record), order the survivors by ascending id
 // (the stable key sort of the reference pipeline: bin_and_sort_gaussians with depth == 0), write the row / header /
-// tile_bins back where they changed, and hand every survivor to `emit(rank, g, record)` (rank = position in the
-// ascending list; the caller stages rank < 256).  Entries [0, sorted_len) are already ascending, so a survivor among
+// tile_bins back where they changed, and hand every survivor to the caller in two steps: `prep(g, record)` forms what
+// the caller stages of it (registers; ONCE per entry), `put(rank, g, staged)` stores it (rank = position in the ascending
+// list; the caller stages rank < 256).  Entries [0, sorted_len) are already ascending, so a survivor among
 // them only needs the number of survivors in front of it (a ballot scan) plus the number of smaller APPENDED ids; an
 // appended entry is ranked against everything.  With no append since the last pass -- the steady state of a fit --
 // there is no loop at all, and nothing is stored.  The row header and the first 256 ids are ONE round of loads (the ids
 // are read before the count is known; slots past the count hold stale ids that are ignored), the records the second.
 // `ids`: GI2D_FAST_C ints of LDS, `grp`: 32 ints of LDS; both are free again after the caller's next workgroup
 // barrier.  Returns the number of survivors.
-// OPTIMISTIC: a survivor of the ascending part is handed to `emit` at rank = its position BEFORE the workgroup
-// barrier -- right when its record arrives -- which is where it ends up whenever nothing was dropped or appended; only
-// otherwise (tile-uniform, known after the barrier) everything is emitted again at its true rank.  `emit` must then be idempotent LDS staging for rank < GI2D_TILE_LIST_CAP (entries past the cap are only
-// ever emitted once, at the end).  With OPTIMISTIC the staging is complete and visible to the whole workgroup on
-// return (the usual case costs ONE barrier in all); otherwise the caller's barrier after the call closes it.
+// OPTIMISTIC: a survivor of the ascending part is `put` at rank = its position BEFORE the workgroup barrier -- right
+// when its record arrives -- which is where it ends up whenever nothing was dropped or appended; only otherwise
+// (tile-uniform, known after the barrier) everything is `put` again at its true rank -- the stores only: what was
+// prepared is kept (on a scene whose gaussians move, most tiles take this way every step).  `put` must then be
+// idempotent LDS staging for rank < GI2D_TILE_LIST_CAP (entries past the cap are only ever put once, at the end).  With
+// OPTIMISTIC the staging is complete and visible to the whole workgroup on return (the usual case costs ONE barrier in
+// all); otherwise the caller's barrier after the call closes it.
 // The first round of loads of a tile's row (header + this lane's first id), separable from the rest so that a caller
 // whose tile index is itself the result of a load (the tile order of the single-pass kernel) can request the row of the
 // tile it EXPECTS -- the identity order of an evenly populated scene -- in the same round as that index, and only
@@ -418,16 +421,149 @@ __device__ __forceinline__ HeadRow head_row_for(const int32_t *__restrict__ list
     if (tile != slot) h = head_row_load(lists, tile);  // workgroup-uniform
     return h;
 }
-template <bool OPTIMISTIC, class Emit>
+// The general form of the head for a row of more than 64 candidates: EPT = list entries per lane.  A row of at most 256
+// candidates -- every tile of the bench scene, nearly every tile of a trained one -- is served by the EPT = 1
+// instantiation, whose per-lane state is scalars and which has none of the `u < rounds` bookkeeping of the four-entry
+// form (a third of the head's scalar instructions on such rows).
+template <bool OPTIMISTIC, int EPT, class Prep, class Put>
+__device__ __forceinline__ int tile_list_head_rows(int *ids, int *grp, int tile, int tx, int ty,
+                                                   const float4 *__restrict__ recs, int32_t *__restrict__ row,
+                                                   int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Prep prep,
+                                                   Put put, int id0, int hdr_count, int hdr_sorted, int count, int sorted) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int my_id[EPT];
+    my_id[0] = id0;
+    if (tid == 0 && hdr_count > GI2D_FAST_C) {  // more candidates than a row holds: the caller must fall back
+        atomicOr(&status[1], 1);
+        atomicOr(&status[2], 1);
+    }
+    // high-water mark for callers that read the status one call late (the autograd wrappers): as long as no row was
+    // more than half full, an overflow cannot be one slowly moving step away
+    if (tid == 0 && hdr_count > GI2D_FAST_C / 2) atomicMax(&status[3], hdr_count);
+    if (tid >= count) my_id[0] = -1;
+    GI2D_HEAD_TRACE(11);
+    // the first entry's record is kept in registers; entries past 256 (rare) fetch theirs again when they are staged
+    BinRec r0;
+    bool keep[EPT];
+    int pos[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) keep[u] = false, pos[u] = 0;
+    if constexpr (EPT > 1) {
+#pragma unroll
+        for (int u = 1; u < EPT; ++u) my_id[u] = -1;
+    }
+    const auto member = [&](int2 box) {
+        int mnx, mny, mxx, mxy;
+        unpack_box(box, mnx, mny, mxx, mxy);
+        return tx >= mnx && tx < mxx && ty >= mny && ty < mxy;  // the empty box 0/0 contains no tile
+    };
+    const int rounds = EPT == 1 ? 1 : (count + 255) >> 8;  // tile-uniform
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    decltype(prep(0, BinRec())) st0;  // what entry 0 stages, formed ONCE (a re-ranked entry only repeats the stores)
+    if ((wv_s << 6) >= count) {
+        // a wave whose 64 slots lie past the row's end (two of four at 72 candidates per tile) has no entry to load,
+        // test, count or stage: it reports empty groups and waits
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) grp[wv + 4 * u] = 0, grp[16 + wv + 4 * u] = 0;
+        }
+    } else {
+        if (my_id[0] >= 0) {
+            r0 = load_record(recs, my_id[0]);
+            keep[0] = member(r0.box);
+            if (keep[0]) st0 = prep(my_id[0], r0);
+        }
+        if constexpr (EPT > 1) {
+#pragma unroll
+            for (int u = 1; u < EPT; ++u) {
+                if (u < rounds) {
+                    const int e = tid + 256 * u;
+                    if (e < count) {
+                        my_id[u] = row[GI2D_FAST_HDR + e];
+                        const float4 *p = recs + 4 * (size_t)my_id[u];
+                        keep[u] = member(make_int2(__float_as_int(p[2].w), __float_as_int(p[3].x)));
+                    }
+                }
+            }
+        }
+        GI2D_HEAD_TRACE(12);
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            if (u < rounds) {
+                const int e = tid + 256 * u;
+                if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
+                const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
+                pos[u] = __popcll(kp & lanemask_lt());
+                if (lane == 0) {
+                    grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
+                    grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
+                }
+            } else if (lane == 0) {
+                grp[wv + 4 * u] = 0;
+                grp[16 + wv + 4 * u] = 0;
+            }
+        }
+    }
+    if (OPTIMISTIC && keep[0] && tid < sorted) put(tid, my_id[0], st0);  // tid < 256 = GI2D_TILE_LIST_CAP
+    __syncthreads();
+    GI2D_HEAD_TRACE(13);
+    // one wave-level scan gives every lane what it needs: lane i < 16 holds group i's ascending survivors, lanes
+    // 16..31 the appended ones
+    const int cnt = (lane < 32 && (lane & 15) < 4 * EPT) ? grp[lane] : 0;  // (the groups this form wrote)
+    const int incl = wave_inclusive_scan(cnt);
+    const int len = wave_read_lane(incl, 31);
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
+    int before[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) before[u] = wave_read_lane(incl - cnt, wv_u + 4 * u);
+    const bool clean = len == count && sorted == count;  // nothing dropped, nothing appended: every rank == position
+    if (tid == 0) {
+        // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
+        if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {
+            row[0] = len;
+            row[1] = len;
+        }
+        tile_bins[tile] = make_int2(list_base(tile), list_base(tile) + len);
+    }
+    if (OPTIMISTIC && clean) {
+        if constexpr (EPT > 1) {
+#pragma unroll
+            for (int u = 1; u < EPT; ++u)  // entries past the cap: put once, here (rank == position)
+                if (u < rounds && keep[u]) put(tid + 256 * u, my_id[u], prep(my_id[u], load_record(recs, my_id[u])));
+        }
+        return len;
+    }
+    // (the optimistic staging was complete at the barrier above: what follows overwrites it in program order)
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (u >= rounds || !keep[u]) continue;
+        const int e = tid + 256 * u, g = my_id[u];
+        // ids are unique within a row, so "smaller" needs no tie rule; dropped entries read as -1 = 0xffffffff
+        int rank, lo, hi;
+        if (e < sorted)
+            rank = before[u] + pos[u], lo = sorted, hi = count;
+        else
+            rank = 0, lo = 0, hi = count;
+        for (int q = lo; q < hi; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
+        const bool in_place = e < sorted && rank == e;  // an entry of the ascending part that nothing in front of it moved
+        if (!in_place) row[GI2D_FAST_HDR + rank] = g;
+        // ... and whose optimistic staging at rank = position (before the barrier) therefore already is the final one
+        if (!(OPTIMISTIC && u == 0 && in_place)) put(rank, g, u == 0 ? st0 : prep(g, load_record(recs, g)));
+    }
+    if (OPTIMISTIC) __syncthreads();  // OPTIMISTIC callers need no barrier of their own after the call
+    return len;
+}
+
+template <bool OPTIMISTIC, class Prep, class Put>
 __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty,
                                               const float4 *__restrict__ recs, int32_t *__restrict__ lists,
-                                              int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Emit emit,
+                                              int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Prep prep, Put put,
                                               const HeadRow *pre = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
     const HeadRow hr = pre ? *pre : head_row_load(lists, tile);
     const int hdr_count_v = hr.hdr_count, hdr_sorted_v = hr.hdr_sorted;
-    int my_id[GI2D_FAST_EPT];
+    int my_id[1];
     my_id[0] = hr.id0;
     // the header is the same for the whole workgroup: say so (vector loads leave it, and everything derived from it --
     // count, sorted length, rounds -- in vector registers; the single-pass tile kernel sits at its 80-register budget)
@@ -462,7 +598,7 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
                 const bool in_place = lane < sorted && rank == lane;
                 if (keep && !in_place) row[GI2D_FAST_HDR + rank] = g;
             }
-            if (keep) emit(rank, g, r0);
+            if (keep) put(rank, g, prep(g, r0));
             if (lane == 0) {
                 if (hdr_count != len || hdr_sorted != len) {
                     row[0] = len;
@@ -476,117 +612,11 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         return grp[0];
     }
 #endif
-    if (tid == 0 && hdr_count > GI2D_FAST_C) {  // more candidates than a row holds: the caller must fall back
-        atomicOr(&status[1], 1);
-        atomicOr(&status[2], 1);
-    }
-    // high-water mark for callers that read the status one call late (the autograd wrappers): as long as no row was
-    // more than half full, an overflow cannot be one slowly moving step away
-    if (tid == 0 && hdr_count > GI2D_FAST_C / 2) atomicMax(&status[3], hdr_count);
-    if (tid >= count) my_id[0] = -1;
-    GI2D_HEAD_TRACE(11);
-    // the first entry's record is kept in registers; entries past 256 (rare) fetch theirs again when they are staged
-    BinRec r0;
-    bool keep[GI2D_FAST_EPT];
-    int pos[GI2D_FAST_EPT];
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) keep[u] = false, pos[u] = 0;
-#pragma unroll
-    for (int u = 1; u < GI2D_FAST_EPT; ++u) my_id[u] = -1;
-    const auto member = [&](int2 box) {
-        int mnx, mny, mxx, mxy;
-        unpack_box(box, mnx, mny, mxx, mxy);
-        return tx >= mnx && tx < mxx && ty >= mny && ty < mxy;  // the empty box 0/0 contains no tile
-    };
-    const int rounds = (count + 255) >> 8;  // tile-uniform
-    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
-    if ((wv_s << 6) >= count) {
-        // a wave whose 64 slots lie past the row's end (two of four at 72 candidates per tile) has no entry to load,
-        // test, count or stage: it reports empty groups and waits
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < GI2D_FAST_EPT; ++u) grp[wv + 4 * u] = 0, grp[16 + wv + 4 * u] = 0;
-        }
-    } else {
-        if (my_id[0] >= 0) {
-            r0 = load_record(recs, my_id[0]);
-            keep[0] = member(r0.box);
-        }
-#pragma unroll
-        for (int u = 1; u < GI2D_FAST_EPT; ++u) {
-            if (u < rounds) {
-                const int e = tid + 256 * u;
-                if (e < count) {
-                    my_id[u] = row[GI2D_FAST_HDR + e];
-                    const float4 *p = recs + 4 * (size_t)my_id[u];
-                    keep[u] = member(make_int2(__float_as_int(p[2].w), __float_as_int(p[3].x)));
-                }
-            }
-        }
-        GI2D_HEAD_TRACE(12);
-#pragma unroll
-        for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-            if (u < rounds) {
-                const int e = tid + 256 * u;
-                if (e < count) ids[e] = keep[u] ? my_id[u] : -1;
-                const unsigned long long kp = __ballot(keep[u] && e < sorted), ka = __ballot(keep[u] && e >= sorted);
-                pos[u] = __popcll(kp & lanemask_lt());
-                if (lane == 0) {
-                    grp[wv + 4 * u] = __popcll(kp);       // survivors of the ascending part in entries [64 i, 64 i + 64)
-                    grp[16 + wv + 4 * u] = __popcll(ka);  // survivors of the appended part
-                }
-            } else if (lane == 0) {
-                grp[wv + 4 * u] = 0;
-                grp[16 + wv + 4 * u] = 0;
-            }
-        }
-    }
-    if (OPTIMISTIC && keep[0] && tid < sorted) emit(tid, my_id[0], r0);  // tid < 256 = GI2D_TILE_LIST_CAP
-    __syncthreads();
-    GI2D_HEAD_TRACE(13);
-    // one wave-level scan gives every lane what it needs: lane i < 16 holds group i's ascending survivors, lanes
-    // 16..31 the appended ones
-    const int cnt = lane < 32 ? grp[lane] : 0;
-    const int incl = wave_inclusive_scan(cnt);
-    const int len = wave_read_lane(incl, 31);
-    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
-    int before[GI2D_FAST_EPT];
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) before[u] = wave_read_lane(incl - cnt, wv_u + 4 * u);
-    const bool clean = len == count && sorted == count;  // nothing dropped, nothing appended: every rank == position
-    if (tid == 0) {
-        // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
-        if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {
-            row[0] = len;
-            row[1] = len;
-        }
-        tile_bins[tile] = make_int2(list_base(tile), list_base(tile) + len);
-    }
-    if (OPTIMISTIC && clean) {
-#pragma unroll
-        for (int u = 1; u < GI2D_FAST_EPT; ++u)  // entries past the cap: emitted once, here (rank == position)
-            if (u < rounds && keep[u]) emit(tid + 256 * u, my_id[u], load_record(recs, my_id[u]));
-        return len;
-    }
-    // (the optimistic staging was complete at the barrier above: what follows overwrites it in program order)
-#pragma unroll
-    for (int u = 0; u < GI2D_FAST_EPT; ++u) {
-        if (u >= rounds || !keep[u]) continue;
-        const int e = tid + 256 * u, g = my_id[u];
-        // ids are unique within a row, so "smaller" needs no tie rule; dropped entries read as -1 = 0xffffffff
-        int rank, lo, hi;
-        if (e < sorted)
-            rank = before[u] + pos[u], lo = sorted, hi = count;
-        else
-            rank = 0, lo = 0, hi = count;
-        for (int q = lo; q < hi; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
-        const bool in_place = e < sorted && rank == e;  // an entry of the ascending part that nothing in front of it moved
-        if (!in_place) row[GI2D_FAST_HDR + rank] = g;
-        // ... and whose optimistic staging at rank = position (before the barrier) therefore already is the final one
-        if (!(OPTIMISTIC && u == 0 && in_place)) emit(rank, g, u == 0 ? r0 : load_record(recs, g));
-    }
-    if (OPTIMISTIC) __syncthreads();  // OPTIMISTIC callers need no barrier of their own after the call
-    return len;
+    if (count <= 256)  // workgroup-uniform
+        return tile_list_head_rows<OPTIMISTIC, 1>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put, hr.id0,
+                                                  hdr_count, hdr_sorted, count, sorted);
+    return tile_list_head_rows<OPTIMISTIC, GI2D_FAST_EPT>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put,
+                                                          hr.id0, hdr_count, hdr_sorted, count, sorted);
 }
 
 // ------------------------------------------------------------------------------- tile order

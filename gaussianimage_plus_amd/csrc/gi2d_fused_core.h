@@ -153,19 +153,34 @@ __device__ __forceinline__ void fused_tile(
     }
     GI2D_TRACE_VALUE(1, (unsigned long long)blockIdx.x);  // the launch slot (single-image launches)
     const float tx0 = (float)(tx * GI2D_TILE), ty0 = (float)(ty * GI2D_TILE);
+    struct Staged {  // one entry as both phases consume it
+        float4 A, B;
+        float2 C;
+        unsigned cull;
+        int slot;
+    };
     const int L = tile_list_head<true>(
-        sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status, [&](int rank, int g, const BinRec &br) {
+        sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status,
+        [&](int g, const BinRec &br) {
             const GaussRec &r = br.r;
-            const int slot = partial_slot(g, br.box, tx, ty, br.pool);
+            Staged s;
+            s.slot = partial_slot(g, br.box, tx, ty, br.pool);
+            const ConicS cs = scale_conic(r.a, r.b, r.c);
+            s.A = make_float4(r.gx, r.gy, cs.ha, cs.hb);
+            s.B = make_float4(cs.hc, r.opac, r.cr, r.cg);
+            const AlphaRule ar = alpha_rule(r.gx, r.gy, r.a, r.b, r.c, r.opac);
+            s.C = make_float2(r.cb, __int_as_float((int)ar.lim));
+            s.cull = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h, ar.clamp);
+            return s;
+        },
+        [&](int rank, int, const Staged &s) {
             if (rank < CAP) {  // (the small form only sees rows of at most CAP candidates: always)
-                const ConicS cs = scale_conic(r.a, r.b, r.c);
-                sm.gA[rank] = make_float4(r.gx, r.gy, cs.ha, cs.hb);
-                sm.gB[rank] = make_float4(cs.hc, r.opac, r.cr, r.cg);
-                const AlphaRule ar = alpha_rule(r.gx, r.gy, r.a, r.b, r.c, r.opac);
-                sm.gC[rank] = make_float2(r.cb, __int_as_float((int)ar.lim));
-                sm.cullw[rank] = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h, ar.clamp);
-                sm.slot[rank] = slot;
-            } else if (float4 *row = partial_row(slot, partial_g, partial_big, pool_rows, status)) {
+                sm.gA[rank] = s.A;
+                sm.gB[rank] = s.B;
+                sm.gC[rank] = s.C;
+                sm.cullw[rank] = s.cull;
+                sm.slot[rank] = s.slot;
+            } else if (float4 *row = partial_row(s.slot, partial_g, partial_big, pool_rows, status)) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 row[0] = z;
@@ -216,10 +231,11 @@ __device__ __forceinline__ void fused_tile(
             float v[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float oc = fminf(fmaxf(o[c], 0.f), 1.f);  // torch.clamp(out_img, 0, 1)
+                const float oc = __builtin_amdgcn_fmed3f(o[c], 0.f, 1.f);  // torch.clamp(out_img, 0, 1): one v_med3_f32
+                                                                            // (a NaN pixel reads as 0 either way)
                 const float d = oc - gtv[c];
                 sse += d * d;
-                v[c] = (o[c] >= 0.f && o[c] <= 1.f) ? grad_scale * d : 0.f;  // clamp passes the gradient on [0, 1]
+                v[c] = (oc == o[c]) ? grad_scale * d : 0.f;  // clamp passes the gradient on [0, 1] (<=> it changed nothing)
             }
             v0 = v[0], v1 = v[1], v2 = v[2];
         }

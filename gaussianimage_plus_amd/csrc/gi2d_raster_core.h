@@ -496,8 +496,10 @@ __device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc
     const float4 *rec = in.rec;
     // pixel x coordinates exactly as the forward forms them: (float)j (small integers: stepping by 1.0 stays exact)
     float px = in.px0;
+    // (bottom-tested, every lane-varying update unconditional: the exit is then one compare and three scalar
+    // instructions per trip; with the test in the middle of the body the exec-mask bookkeeping was ten)
 #pragma unroll 1
-    for (;; rec += 2) {
+    do {
         const float4 P0 = rec[0];
         float4 P1;
         if (USE_FIDX) {
@@ -515,10 +517,10 @@ __device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc
         const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
         const v2f t = in.opac2 * vis;
         // backward.cu:903 (idx <= final_idx) and :922-926 (sigma < 0 || alpha < 1/255: the forward's pair test)
-        const bool ok0 = in.in_a && fidx_admits<USE_FIDX>(in.idx, P1.z) &&
-                         (CLAMP ? pair_lands_odd(sig.x, t.x, in.lim) : pair_lands(sig.x, in.lim));
-        const bool ok1 = in.in_b && fidx_admits<USE_FIDX>(in.idx, P1.w) &&
-                         (CLAMP ? pair_lands_odd(sig.y, t.y, in.lim) : pair_lands(sig.y, in.lim));
+        const bool l0 = CLAMP ? pair_lands_odd(sig.x, t.x, in.lim) : pair_lands(sig.x, in.lim);
+        const bool l1 = CLAMP ? pair_lands_odd(sig.y, t.y, in.lim) : pair_lands(sig.y, in.lim);
+        const bool ok0 = in.in_a & fidx_admits<USE_FIDX>(in.idx, P1.z) & l0;
+        const bool ok1 = in.in_b & fidx_admits<USE_FIDX>(in.idx, P1.w) & l1;
         const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
         v2f am = tz;
         if (CLAMP) am = (v2f){fminf(1.f, tz.x), fminf(1.f, tz.y)};
@@ -540,8 +542,8 @@ __device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc
             o.ax += __builtin_elementwise_abs(ux);
             o.ay += __builtin_elementwise_abs(uy);
         }
-        if (rec >= in.rec_end) break;
-    }
+        rec += 2;
+    } while (rec <= in.rec_end);
 }
 
 template <bool WITH_ABS, bool USE_FIDX = true, bool PRESCANNED = false, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
@@ -580,7 +582,23 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         if (tid < len) {
             sm.set_box(tid, cull);
             sm.span[tid] = (unsigned short)(slot0 | mine.n << 11);
-            for (int j = 0; j < mine.n; ++j) sm.item[slot0 + j] = (unsigned short)(tid | j << 8);
+        }
+        // the gaussian's item codes, without a divergent loop (its exec-mask bookkeeping was three times the stores): a
+        // lane past its count repeats its first store
+        const bool more = __ballot(mine.n > 4) != 0ull;  // wave-uniform
+        if (tid < len && mine.n > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int jj = j < mine.n ? j : 0;
+                sm.item[slot0 + jj] = (unsigned short)(tid | jj << 8);
+            }
+            if (more) {
+#pragma unroll
+                for (int j = 4; j < 8; ++j) {
+                    const int jj = j < mine.n ? j : 0;
+                    sm.item[slot0 + jj] = (unsigned short)(tid | jj << 8);
+                }
+            }
         }
         if (tid == 0) sm.n_items = bwd_field_sum(total);
     }
