@@ -644,12 +644,13 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
     // lane-serial chain of dependent loads would put this workgroup on the kernel's critical path)
     constexpr int PL = GI2D_ORDER_MAX_TILES / 64;
     int pop[PL];
+    // (unconditional loads at a clamped index, the bound applied afterwards: a conditional load each sits in a block of
+    // its own behind its own s_waitcnt vmcnt(0) -- thirty-two round trips one after the other)
+    int2 rr[PL];
 #pragma unroll
-    for (int q = 0; q < PL; ++q) {
-        const int t = tid + q * bs;
-        const int2 r = t < num_tiles ? tile_bins[t] : make_int2(0, 0);
-        pop[q] = min(max(r.y - r.x, 0), GI2D_ORDER_BINS - 1);
-    }
+    for (int q = 0; q < PL; ++q) rr[q] = tile_bins[min(tid + q * bs, num_tiles - 1)];
+#pragma unroll
+    for (int q = 0; q < PL; ++q) pop[q] = tid + q * bs < num_tiles ? min(max(rr[q].y - rr[q].x, 0), GI2D_ORDER_BINS - 1) : 0;
     // Worth it?  With populations as even as a uniform scene's (fullest tile < 1.75 x the mean; 1.49 at 50 000 uniform
     // gaussians) dealing them out buys the tile pass 0.1-0.2 us and this workgroup, the longest of the end-of-step
     // kernel, costs that kernel 1.1 us; on a trained scene (gaussians crowd where the detail is) the same ordering is

@@ -486,8 +486,9 @@ struct BwdItemIn {
     v2f dy, bdy, cdy2;         // the two rows of the pair
     v2f ha2, opac2, cr2, cg2, cb2;
     float4 raw;                // a, b, c as given (WITH_ABS)
-    unsigned lim;              // AlphaRule::lim
-    bool in_a, in_b;           // rows of the pair inside the box
+    unsigned lim_a, lim_b;     // AlphaRule::lim per row of the pair; 0 ("never lands") for a row outside the box: a lane
+                               // mask ANDed into the pair test every trip is a VALU -> SALU -> VALU round trip through
+                               // VCC on the loop's critical path (tools/ubench/valu_rate.hip: ~20 cycles a trip)
     int idx;                   // position in the sorted list (USE_FIDX)
     const float4 *rec, *rec_end;
 };
@@ -517,10 +518,10 @@ __device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc
         const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
         const v2f t = in.opac2 * vis;
         // backward.cu:903 (idx <= final_idx) and :922-926 (sigma < 0 || alpha < 1/255: the forward's pair test)
-        const bool l0 = CLAMP ? pair_lands_odd(sig.x, t.x, in.lim) : pair_lands(sig.x, in.lim);
-        const bool l1 = CLAMP ? pair_lands_odd(sig.y, t.y, in.lim) : pair_lands(sig.y, in.lim);
-        const bool ok0 = in.in_a & fidx_admits<USE_FIDX>(in.idx, P1.z) & l0;
-        const bool ok1 = in.in_b & fidx_admits<USE_FIDX>(in.idx, P1.w) & l1;
+        const bool l0 = CLAMP ? pair_lands_odd(sig.x, t.x, in.lim_a) : pair_lands(sig.x, in.lim_a);
+        const bool l1 = CLAMP ? pair_lands_odd(sig.y, t.y, in.lim_b) : pair_lands(sig.y, in.lim_b);
+        const bool ok0 = fidx_admits<USE_FIDX>(in.idx, P1.z) & l0;
+        const bool ok1 = fidx_admits<USE_FIDX>(in.idx, P1.w) & l1;
         const v2f tz = {ok0 ? t.x : 0.f, ok1 ? t.y : 0.f};
         v2f am = tz;
         if (CLAMP) am = (v2f){fminf(1.f, tz.x), fminf(1.f, tz.y)};
@@ -638,7 +639,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             const float4 A = sm.gA[k], B = sm.gB[k];
             const float2 C = sm.gC[k];
             BwdItemIn in;
-            in.in_a = 2 * p >= r0, in.in_b = 2 * p + 1 <= r1;  // a box may start on row B / end on row A of a pair
+            const bool in_a = 2 * p >= r0, in_b = 2 * p + 1 <= r1;  // a box may start on row B / end on row A of a pair
             in.gx = A.x;
             const float gy = A.y;
             ConicS s;
@@ -650,7 +651,8 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             in.cdy2 = (v2f){row_term_c(s, in.dy.x), row_term_c(s, in.dy.y)};
             in.ha2 = (v2f){s.ha, s.ha}, in.opac2 = (v2f){B.y, B.y};
             in.cr2 = (v2f){B.z, B.z}, in.cg2 = (v2f){B.w, B.w}, in.cb2 = (v2f){C.x, C.x};
-            in.lim = (unsigned)__float_as_int(C.y);
+            in.lim_a = in_a ? (unsigned)__float_as_int(C.y) : 0u;
+            in.lim_b = in_b ? (unsigned)__float_as_int(C.y) : 0u;
             in.idx = list_base + k;
             in.raw = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (WITH_ABS) in.raw = sm.gRaw[k];

@@ -242,11 +242,20 @@ __device__ __forceinline__ SseChunks sse_chunks(const BestSnap &best) {
 // one round of loads of chunk [lo, hi) starting at float4 t0
 __device__ __forceinline__ void sse_round(const float4 *__restrict__ sse4, int t0, int hi, float4 (&v)[GI2D_SSE_ROUND]) {
     const int lane = threadIdx.x & 63;
+    // Every load unconditional, at a clamped index (a lane past the end re-reads the chunk's last float4 and drops it):
+    // with `t < hi ? sse4[t] : 0` each load sat in a block of its own and the compiler closed every block with
+    // s_waitcnt vmcnt(0) -- the eight loads, and every other load of the kernel's first round, went one after the
+    // other: eight dependent round trips at the top of every wave of the update kernel.
+    if (hi <= t0) {  // (nothing to read: wave-uniform)
 #pragma unroll
-    for (int q = 0; q < GI2D_SSE_ROUND; ++q) {
-        const int t = t0 + lane + 64 * q;
-        v[q] = t < hi ? sse4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < GI2D_SSE_ROUND; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
     }
+#pragma unroll
+    for (int q = 0; q < GI2D_SSE_ROUND; ++q) v[q] = sse4[min(t0 + lane + 64 * q, hi - 1)];
+#pragma unroll
+    for (int q = 0; q < GI2D_SSE_ROUND; ++q)
+        if (t0 + lane + 64 * q >= hi) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ float sse_round_sum(const float4 (&v)[GI2D_SSE_ROUND]) {
     float part = 0.f;
@@ -386,7 +395,11 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     ProjGrad r;
     r.g11 = r.g12 = r.g22 = r.o0 = r.o1 = r.o2 = 0.f;
     r.v_mean = make_float2(0.f, 0.f);
-    if (radius > 0) {
+    // (opaque until here: left to itself the compiler turns `radius > 0` into a lane mask right behind the load -- behind
+    // an s_waitcnt vmcnt(0) in the middle of the first load round, with half of that round's loads not yet issued)
+    int radius_now = radius;
+    asm volatile("" : "+v"(radius_now));
+    if (radius_now > 0) {
         const float vc[3] = {acc[2], acc[3], acc[4]};
         r = project_bwd_one<KIND>(0, par, rot_of<KIND>(par), img_w, img_h, conic, make_float2(acc[0], acc[1]), vc);
     }
