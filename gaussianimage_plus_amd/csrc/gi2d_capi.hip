@@ -33,35 +33,8 @@ static std::string dev_switches() {
 #ifdef GI2D_STOP_AFTER
     add("GI2D_STOP_AFTER", GI2D_STR(GI2D_STOP_AFTER));
 #endif
-#ifdef GI2D_FWD_KNOCK
-    add("GI2D_FWD_KNOCK", GI2D_STR(GI2D_FWD_KNOCK));
-#endif
-#ifdef GI2D_BWD_KNOCK
-    add("GI2D_BWD_KNOCK", GI2D_STR(GI2D_BWD_KNOCK));
-#endif
-#ifdef GI2D_RU_KNOCK
-    add("GI2D_RU_KNOCK", GI2D_STR(GI2D_RU_KNOCK));
-#endif
-#ifdef GI2D_BWD_GAUSSIAN_ORDER
-    add("GI2D_BWD_GAUSSIAN_ORDER", "");
-#endif
-#ifdef GI2D_NO_TILE_ORDER
-    add("GI2D_NO_TILE_ORDER", "");
-#endif
-#ifdef GI2D_NO_XCD_MAP
-    add("GI2D_NO_XCD_MAP", "");
-#endif
-#ifdef GI2D_NO_SHORT_HEAD
-    add("GI2D_NO_SHORT_HEAD", "");
-#endif
 #ifdef GI2D_FUSED_TRACE
     add("GI2D_FUSED_TRACE", "");
-#endif
-#ifdef GI2D_NO_QUANT_FINISH
-    add("GI2D_NO_QUANT_FINISH", "");
-#endif
-#ifdef GI2D_BATCH_LOG
-    add("GI2D_BATCH_LOG", "");
 #endif
 #ifdef GI2D_DEV_VARIANT /* any other experiment: -DGI2D_DEV_VARIANT=name next to its own macros */
     add("GI2D_DEV_VARIANT", GI2D_STR(GI2D_DEV_VARIANT));

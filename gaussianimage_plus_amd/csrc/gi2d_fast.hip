@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void fast_fill_kernel(int n, const float2 *__r
                                                         int32_t *__restrict__ status) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     begin_binning(g, status);
-    float4 *recs = recs_for_binning(rs, g == 0);
+    const BinRecs recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     // forward.cu:161: culled gaussians are in no tile
     bin_one(g, xys[g], radii[g], true, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g], colors[3 * g],
@@ -65,7 +65,7 @@ __device__ __forceinline__ void project_fill_one(
     float *__restrict__ depths, int32_t *radii, float *conics, int32_t *__restrict__ num_tiles_hit,
     const BinTarget &bt) {
     begin_binning(g, bt.status);
-    float4 *recs = recs_for_binning(bt.recs, g == 0);
+    const BinRecs recs = recs_for_binning(bt.recs, g == 0);
     if (g >= n) return;
     // every input is requested before the first store below (the outputs may alias them as far as the compiler knows)
     const PrevBox old_box = bt.prev_box[g];
@@ -141,13 +141,15 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     // "No intersection at all" (image = background) is a global property no single tile can decide: every
     // non-empty tile raises status[0] with a plain store as its LAST memory operation (no barrier waits on
-    // it; a contended atomic here would serialise all workgroups), and the host entry may append a tiny
-    // fix-up kernel for that corner case.
+    // it; a contended atomic here would serialise all workgroups) ...
+    // ... which the binning step that filled the rows has noted (BinRecs: a gaussian in any tile at all), so the
+    // background image of that corner case is written here, not by a second launch
+    const bool nothing = background != nullptr && !tile_pass_has_members(rs);
     if (final_idx)
-        fwd_rasterize_staged<true>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, false, background,
+        fwd_rasterize_staged<true>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, nothing, background,
                                    final_Ts, final_idx, out_img);
     else
-        fwd_rasterize_staged<false>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, false, background,
+        fwd_rasterize_staged<false>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, nothing, background,
                                     final_Ts, final_idx, out_img);
     if (tid == 0 && L > 0) status[0] = 1;
 }
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
     // gaussian ids, which only change when rows were actually dropped -- one check in a few hundred on a Kodak fit
     if (only_if_moved && (only_if_moved[0] == only_if_moved[1] || only_if_moved[0] == 0)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 2) ver[i] = 0;
+    if (i < 3) ver[i] = 0;  // the two record-set counters and the any-member stamp (GI2D_VER_ANY)
     if (i == 0) lists[GI2D_POOL_CURSOR] = 0;  // the row pool is empty
     if (i < num_tiles) {
         lists[(size_t)i * GI2D_FAST_LROW] = 0;
@@ -254,9 +256,12 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
 
 // Phase 2 finds nothing to do on the scenes the two-phase form is for (large images: sparse rows), and ten thousand
 // workgroups that only look and return cost several us of dispatch: a phase-2 workgroup therefore looks at a STRIP of
-// GI2D_PHASE2_STRIP consecutive slots at once and handles the ones that were passed over one after the other (a barrier
-// between two tiles: they share its LDS).
-#define GI2D_PHASE2_STRIP 8
+// GI2D_PHASE2_STRIP slots at once (one per lane of a wave; strided over the launch) and handles the ones that were
+// passed over one after the other (a barrier between two tiles: they share its LDS).  64 instead of round 4's 8: the
+// launch that finds nothing is 170 workgroups at 2040x1356 instead of 1360.
+#ifndef GI2D_PHASE2_STRIP
+#define GI2D_PHASE2_STRIP 64
+#endif
 // a single image of more tiles than one residency round of the general form may run as two launches (see the launch code)
 #ifndef GI2D_TWO_PHASE_TILES
 #define GI2D_TWO_PHASE_TILES (256 * GI2D_FUSED_OCC) /* development aid: a huge value keeps every launch single-phase */
@@ -272,12 +277,14 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
     if (PHASE == 2) {
         // which slots of the strip were passed over: lane i looks at slot i (ONE round of two dependent loads for the
         // whole strip -- slot by slot it was sixteen), a ballot makes the answer scalar
+        // (the strip is STRIDED -- lane i looks at slot blockIdx + i * gridDim -- so that a run of neighbouring fuller
+        // tiles is dealt to as many workgroups as it has tiles instead of queueing up in one)
         const int tiles = a.tiles_x * a.tiles_y, lane = threadIdx.x & 63;
-        const int s0 = (int)blockIdx.x * GI2D_PHASE2_STRIP, mine = s0 + lane;
+        const int s0 = (int)blockIdx.x, stride = (int)gridDim.x, mine = s0 + lane * stride;
         const bool big = lane < GI2D_PHASE2_STRIP && mine < tiles && a.big_tile[a.tile_order[mine]] != 0;
         unsigned long long todo = __ballot(big);
         while (todo) {  // workgroup-uniform: every wave computed the same mask
-            const int slot = s0 + __builtin_ctzll(todo);
+            const int slot = s0 + __builtin_ctzll(todo) * stride;
             todo &= todo - 1;
             tile_pass_workgroup<MODE, PHASE>(a, slot, false);
             __syncthreads();  // the next tile stages into the same LDS
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_batche
     int k, local;
     if (PHASE == 2) {
         const int total = uniform_tiles > 0 ? k_images * uniform_tiles : tile_start[k_images], lane = threadIdx.x & 63;
-        const int s0 = (int)blockIdx.x * GI2D_PHASE2_STRIP, mine = s0 + lane;
+        const int s0 = (int)blockIdx.x, stride = (int)gridDim.x, mine = s0 + lane * stride;  // (strided: see above)
         bool big = false;
         if (lane < GI2D_PHASE2_STRIP && mine < total) {
             batched_slot_of_lane(mine, tile_start, k_images, uniform_tiles, xcd_map, k, local);
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_batche
         }
         unsigned long long todo = __ballot(big);
         while (todo) {
-            const int b = s0 + __builtin_ctzll(todo);
+            const int b = s0 + __builtin_ctzll(todo) * stride;
             todo &= todo - 1;
             batched_slot(b, tile_start, k_images, uniform_tiles, xcd_map, k, local);
             tile_pass_workgroup<MODE, PHASE>(imgs[k].t, local, false);
@@ -566,9 +573,7 @@ int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int to
                              bool two_phase, hipStream_t st) {
     if (total_blocks <= 0) return GI2D_OK;
     int xcd_map = 0;  // images placed on the XCDs whole (see the kernel): a multiple of 8
-#ifndef GI2D_NO_XCD_MAP /* development aid: what the XCD-aware mapping buys */
     if (uniform_tiles > 0) xcd_map = k_images & ~7;
-#endif
     const dim3 grid((unsigned)total_blocks), block(256);
     const BatchImage *imgs = (const BatchImage *)b.img;
     if (two_phase) {
@@ -649,10 +654,6 @@ static bool pass_form_begin(const void *key, long long total, long long min_tota
     std::lock_guard<std::mutex> lock(g_hint_mu);
     PassHint &h = g_hints[key];
     hint_poll(h);
-#ifdef GI2D_BATCH_LOG /* development aid: one line per call */
-    fprintf(stderr, "[gi2d tile-pass form %p] tiles %lld, above the small form's capacity at the last report: %d\n", key,
-            total, h.last);
-#endif
     return hint_says_two_phase(h, total, min_total);
 }
 // `count_word`: device word that holds the number of marked tiles once everything queued on `st` so far has run
@@ -888,9 +889,6 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
     hipLaunchKernelGGL(fast_fwd_kernel, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
                        (int)w_, (int)h, rec_sets(w, n), background, w.lists, (int2 *)w.tile_bins, w.packed,
                        w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
-    if (background)
-        hipLaunchKernelGGL(fast_background_kernel, dim3(256), dim3(256), 0, (hipStream_t)st, (int)w_, (int)h,
-                           status, background, out_img);
     return check_launch("fast rasterize forward");
 }
 
@@ -1082,9 +1080,6 @@ static int reduce_project_impl(int kind, int n, const float *p0, const float *p1
     }
     const int bs = per_gaussian_block(n), role_blocks = (n + bs - 1) / bs;
     np.tile_order = (next && n > 32768) ? w.tile_order : nullptr;
-#ifdef GI2D_NO_TILE_ORDER /* development aid: tools/order_cost.sh */
-    np.tile_order = nullptr;
-#endif
     const dim3 grid((next ? 2 : 1) * role_blocks + (np.tile_order ? 1 : 0)), block(bs);
 #define GI2D_LAUNCH_RP(K, F)                                                                                        \
     hipLaunchKernelGGL((fast_reduce_project_kernel<K, F>), grid, block, 0, (hipStream_t)st, n, role_blocks,          \

@@ -149,16 +149,8 @@ __device__ __forceinline__ void fill_trip_issue(FillPending &f, int base, int ti
         f.c[q] = (base + q < f.nt && !was) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
         if (++f.dj == f.w) f.dj = 0, ++f.di;
     }
-#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 32) /* development aid (wrong results): appends without a returning atomic */
-#pragma unroll
-    for (int q = 0; q < GI2D_FILL_BATCH; ++q) {
-        if (f.c[q] >= 0) __hip_atomic_fetch_or(&lists[f.c[q] + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f.p[q] = f.c[q] >= 0 ? GI2D_FAST_C - 1 : GI2D_FAST_C;
-    }
-#else
 #pragma unroll
     for (int q = 0; q < GI2D_FILL_BATCH; ++q) f.p[q] = f.c[q] >= 0 ? atomicAdd(&lists[f.c[q]], 1) : GI2D_FAST_C;
-#endif
 }
 __device__ __forceinline__ void fill_trip_store(const FillPending &f, int g, int32_t *__restrict__ lists) {
 #pragma unroll
@@ -235,11 +227,26 @@ struct RecSets {
     size_t stride;  // float4 per set
     int32_t *ver;
 };
-__device__ __forceinline__ float4 *recs_for_binning(const RecSets &rs, bool writer) {
+// What a binning kernel gets: the record set it writes, and the word in which it notes that SOME gaussian is in a tile
+// -- stamped with its own version, so nobody ever has to reset it: a forward that must render the background when there
+// is not a single intersection (rasterize_sum_plus.py:110-118) compares the word with the version it reads
+// (tile_pass_has_members) instead of waiting for a second launch behind the tile pass.
+#define GI2D_VER_ANY 2 /* word of RecSets::ver */
+struct BinRecs {
+    float4 *recs;
+    int32_t *any;
+    int stamp;
+};
+__device__ __forceinline__ BinRecs recs_for_binning(const RecSets &rs, bool writer) {
     const int c = rs.ver[0];
     if (writer) rs.ver[1] = c + 1;
-    return rs.base + ((c + 1) & 1) * rs.stride;
+    BinRecs b;
+    b.recs = rs.base + ((c + 1) & 1) * rs.stride;
+    b.any = rs.ver + GI2D_VER_ANY;
+    b.stamp = c + 1;
+    return b;
 }
+__device__ __forceinline__ bool tile_pass_has_members(const RecSets &rs) { return rs.ver[GI2D_VER_ANY] == rs.ver[1]; }
 __device__ __forceinline__ const float4 *recs_for_tile_pass(const RecSets &rs, bool writer) {
     const int b = rs.ver[1];
     if (writer) rs.ver[0] = b;
@@ -322,9 +329,14 @@ template <class Between>
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
                                         float radius_clip, PrevBox old_box, PrevBox *__restrict__ prev_box,
-                                        int32_t *__restrict__ lists, float4 *__restrict__ recs, Between between) {
+                                        int32_t *__restrict__ lists, const BinRecs &br, Between between) {
     int mnx, mny, mxx, mxy;
     const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
+    {  // one store per wave that holds a member (by its first such lane)
+        const unsigned long long mm = __ballot(member);
+        if (mm != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(mm)) *br.any = br.stamp;
+    }
+    float4 *recs = br.recs;
     FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
     write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
                  radius, f.pool);
@@ -334,7 +346,7 @@ __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_t
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
                                         float radius_clip, PrevBox old_box, PrevBox *__restrict__ prev_box,
-                                        int32_t *__restrict__ lists, float4 *__restrict__ recs) {
+                                        int32_t *__restrict__ lists, const BinRecs &recs) {
     bin_one(g, xy, radius, has_tiles, ka, kb, kc, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists,
             recs, [] {});
 }
@@ -342,14 +354,14 @@ template <class Between>
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
                                               int tiles_x, int tiles_y, float radius_clip, PrevBox old_box,
                                               PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists,
-                                              float4 *__restrict__ recs, Between between) {
+                                              const BinRecs &recs, Between between) {
     bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
             old_box, prev_box, lists, recs, between);
 }
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
                                               int tiles_x, int tiles_y, float radius_clip, PrevBox old_box,
                                               PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists,
-                                              float4 *__restrict__ recs) {
+                                              const BinRecs &recs) {
     bin_projected(g, o, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists, recs, [] {});
 }
 
@@ -570,7 +582,6 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
     const int hdr_count = __builtin_amdgcn_readfirstlane(hdr_count_v);
     const int hdr_sorted = __builtin_amdgcn_readfirstlane(hdr_sorted_v);
     const int count = min(max(hdr_count, 0), GI2D_FAST_C), sorted = min(max(hdr_sorted, 0), count);
-#ifndef GI2D_NO_SHORT_HEAD /* development aid: what the one-wave head of short rows buys */
     if (count <= 64) {
         // A row of at most 64 candidates -- every tile of a 2040x1356 image at 50 000 gaussians, every tile of a fit's
         // first 45 000 iterations (5 000 ... 14 000 large gaussians: ~24 per tile) -- is ONE wave's work: membership,
@@ -611,7 +622,6 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         __syncthreads();  // staging complete and visible (OPTIMISTIC or not: a caller's own barrier after this is harmless)
         return grp[0];
     }
-#endif
     if (count <= 256)  // workgroup-uniform
         return tile_list_head_rows<OPTIMISTIC, 1>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put, hr.id0,
                                                   hdr_count, hdr_sorted, count, sorted);
@@ -739,9 +749,6 @@ __device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_r
     }
     // a run that does not lie inside the pool was never written (partial_row): the overflow status is up
     unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F && pool >= 0 && pool + ntiles <= pool_rows);
-#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 64) /* development aid (wrong results): gaussians on > 32 tiles are not summed */
-    big = 0ull;
-#endif
     while (big) {  // a gaussian on > 32 tiles: the whole wave strides over its run of rows
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;

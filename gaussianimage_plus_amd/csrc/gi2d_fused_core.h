@@ -220,7 +220,7 @@ __device__ __forceinline__ void fused_tile(
         return;
     }
 #endif
-    fwd_store_pixels(mybuf, o0, o1, o2, tx, ty, img_w, img_h, out_img);
+    fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
 
     // ---- this pixel's gradient
     float v0 = p0, v1 = p1, v2 = p2, sse = 0.f;

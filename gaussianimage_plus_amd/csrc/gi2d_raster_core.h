@@ -194,11 +194,7 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
             if (NEED_FIDX) bdst[20] = __int_as_float(k);
         }
         __builtin_amdgcn_wave_barrier();
-#if defined(GI2D_FWD_KNOCK) && GI2D_FWD_KNOCK == 2 /* development aid (wrong results): one trip per chunk */
-        const int m = min(2, n_max - c0);
-#else
         const int m = min(GI2D_FWD_CHUNK, n_max - c0);
-#endif
         if (clamp_any)
             fwd_trips<NEED_FIDX, true, UNROLL>(mine, m, px2, py2, a0, a1, a2, last);
         else
@@ -211,36 +207,15 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
     last_k = last;
 }
 
-// A 16x16 tile's RGB leaves as 16-byte stores of whole 192-byte rows: transposed through `buf` (>= 192 floats of
-// this wave's LDS, idle by now).
-__device__ __forceinline__ void fwd_store_pixels(float *buf, float o0, float o1, float o2, int tx, int ty, int img_w,
-                                                 int img_h, float *__restrict__ out_img) {
+// A tile's RGB leaves as one 12-byte store per lane: the 16 lanes of a pixel row write 192 contiguous bytes = three
+// whole 64-byte lines in one instruction, which is as good for the memory system as 16-byte stores of rows transposed
+// through LDS (the form of rounds 1-3) and costs a third of its instructions.
+__device__ __forceinline__ void fwd_store_pixels(float o0, float o1, float o2, int tx, int ty, int img_w, int img_h,
+                                                 float *__restrict__ out_img) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
-#ifndef GI2D_FWD_STORE_TRANSPOSED /* development aid: the round-1..3 form, 16-byte stores of whole rows through LDS */
-#define GI2D_FWD_STORE_TRANSPOSED 0
-#endif
-    // One 12-byte store per lane: the 16 lanes of a pixel row write 192 contiguous bytes = three whole 64-byte lines
-    // in one instruction, which is as good for the memory system as the 16-byte stores of the transposed form and
-    // costs a third of its instructions (3 LDS writes, a read, two integer divisions).
-    const bool full_tile = GI2D_FWD_STORE_TRANSPOSED && (tx * GI2D_TILE + GI2D_TILE <= img_w) && ((img_w & 3) == 0);
-    if (full_tile) {
-        const int r = lane >> 4;
-        buf[r * 48 + lx * 3 + 0] = o0;
-        buf[r * 48 + lx * 3 + 1] = o1;
-        buf[r * 48 + lx * 3 + 2] = o2;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 48) {
-            const int rr = lane / 12, q = lane % 12;
-            const int ii = ty * GI2D_TILE + wv * 4 + rr;
-            if (ii < img_h) {
-                const float4 v = reinterpret_cast<const float4 *>(buf)[rr * 12 + q];
-                float4 *dst = reinterpret_cast<float4 *>(out_img + ((size_t)ii * img_w + tx * GI2D_TILE) * 3);
-                dst[q] = v;
-            }
-        }
-    } else if (i < img_h && j < img_w) {
+    if (i < img_h && j < img_w) {
         const size_t pix = (size_t)i * img_w + j;
         out_img[3 * pix + 0] = o0;
         out_img[3 * pix + 1] = o1;
@@ -314,7 +289,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
         if (final_Ts) final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
         if (NEED_FIDX) final_idx[pix] = cur_idx;
     }
-    fwd_store_pixels(mybuf, o0, o1, o2, tx, ty, img_w, img_h, out_img);
+    fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
 }
 
 // ========================================================================================== backward
@@ -621,21 +596,13 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
         const int round1 = min(n_items, round0 + GI2D_BWD_ITEMS);
         const int it = round0 + tid;
         float res[PSTR];
-#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 3 /* development aid (wrong results): no item is run */
-        if (it < 0) {
-#else
         if (it < round1) {
-#endif
             const int code = sm.item[it], k = code & 255;
             const unsigned xr = sm.box_of(k);  // r0 | r1 << 4 | c0 << 8 | c1 << 12 | clamp << 16
             const int r0 = (int)(xr & 15u), r1 = (int)((xr >> 4) & 15u);
             const int p = (r0 >> 1) + (code >> 8);               // items of k: its row pairs in order
             const int c_lo = (int)((xr >> 8) & 15u);
-#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 1 /* development aid (wrong results): one trip per item */
-            const int c_hi = c_lo;
-#else
             const int c_hi = (int)((xr >> 12) & 15u);
-#endif
             const float4 A = sm.gA[k], B = sm.gB[k];
             const float2 C = sm.gC[k];
             BwdItemIn in;
@@ -714,11 +681,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
             __syncthreads();
             if (owner) {
                 const int e0 = max(lo, round0 + h0), e1 = min(hi, round0 + h0 + PROWS);
-#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 2 /* development aid (wrong results): hand-off rows are not summed */
-                for (int e = e0; e < min(e1, e0 + 1); ++e) {
-#else
                 for (int e = e0; e < e1; ++e) {
-#endif
                     const float *in = &sm.part[(e - round0 - h0) * PSTR];
 #pragma unroll
                     for (int q = 0; q < PSTR; ++q) acc[q] += in[q];
@@ -750,11 +713,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                 acc[8] += d2.x;
                 if (PSTR > 9) acc[PSTR - 2] += d2.y, acc[PSTR - 1] += d2.z;
             }
-#if defined(GI2D_BWD_KNOCK) && GI2D_BWD_KNOCK == 4 /* development aid (wrong results): gradient rows are not stored */
-            if (acc[0] == 12345.678f) store_partial_row<PSTR>(dst, acc);
-#else
             store_partial_row<PSTR>(dst, acc);
-#endif
         }
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);

@@ -83,7 +83,7 @@ __device__ __forceinline__ void train_project_fill_body(int g, const UpdateArgs 
     const TrainParams &P = u.P;
     const int n = live_n(P, u.n);
     begin_binning(g, u.next.status);
-    float4 *recs = recs_for_binning(u.next.recs, g == 0);
+    const BinRecs recs = recs_for_binning(u.next.recs, g == 0);
     if (g >= n) return;
     const PrevBox old_box = u.next.prev_box[g];  // with the other inputs, ahead of the stores
     const Row3 col = load_row3(P.feat, g);
@@ -335,13 +335,11 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
 #pragma clang fp contract(off)
     const int tiles_x = u.tiles_x, tiles_y = u.tiles_y;
     if (order_block) {
-#ifndef GI2D_NO_TILE_ORDER /* development aid: tools/variant_sweep.sh */
         // Tile populations drift slowly along a fit: the order is renewed every 16th step, and then unconditionally --
         // what the dealing balances is the SUM of the six tiles a CU holds (371 .. 516 gaussians around a mean of 436
         // on the uniform bench scene when tiles are taken in index order: the slowest CU finishes the tile pass 1.8 us
         // after the median one), which is uneven long before a single tile stands out.
         if ((step & 15) == 1) compute_tile_order(u.tile_bins, tiles_x * tiles_y, u.next.tile_order, true);
-#endif
         return;
     }
     const TrainParams &P = u.P;
@@ -373,18 +371,10 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     const int n = live_n(P, u.n);
     const PrevBox pbox = g < n ? box_ld : no_box();
     const int2 box = make_int2(pbox.x, pbox.y);
-#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 1) /* development aid (wrong results): no best-model decision */
-    const bool snapshot = false;
-#else
     const SseLoads sse_first = best_sse_loads(best);
     const bool snapshot = best_decision(best, sse_first, n, g);
-#endif
     float acc[11];
-#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 2) /* development aid (wrong results): no gradient gather */
-    for (int q = 0; q < 11; ++q) acc[q] = 1e-9f * (float)(box.x + q);
-#else
     reduce_one(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big, acc);
-#endif
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -453,18 +443,14 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
             if (best.bound) store_row3(best.bound, g, bound3[0], bound3[1], bound3[2]);
         }
     };
-#if defined(GI2D_RU_KNOCK) && (GI2D_RU_KNOCK & 4) /* development aid (wrong results): the next iteration is not prepared */
-    if (FILL_NEXT && new_xy.x == 12345.678f) {
-#else
     if (FILL_NEXT) {
-#endif
         // same code path as train_project_fill_kernel, on the values just computed
         // (The record-set lookup stays HERE.  Hoisted to the top of the kernel together with begin_binning -- either
         // one alone is fine -- the build keeps one more SGPR alive across the whole kernel, spills SGPRs to VGPR lanes,
         // and a stretch of iterations stops being equal to the same iterations issued one by one: measured,
         // deterministic, and worth nothing in time.)
         begin_binning(g, next.status);
-        float4 *recs = recs_for_binning(next.recs, g == 0);
+        const BinRecs recs = recs_for_binning(next.recs, g == 0);
         // From the rows just computed, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
         // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
@@ -579,7 +565,7 @@ __device__ __forceinline__ void project_fill_quant_body(int block, const UpdateA
     const RecSets &rs = u.next.recs;
     const int g = block * blockDim.x + threadIdx.x;
     begin_binning(g, status);
-    float4 *recs = recs_for_binning(rs, g == 0);
+    const BinRecs recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     const PrevBox old_box = prev_box[g];  // with the other inputs, ahead of the stores
     const float opac = P.opacity[g];
@@ -975,7 +961,7 @@ __device__ __forceinline__ void project_fill_quant_rs_body(int block, const Upda
     const RecSets &rs = u.next.recs;
     const int g = block * blockDim.x + threadIdx.x;
     begin_binning(g, status);
-    float4 *recs = recs_for_binning(rs, g == 0);
+    const BinRecs recs = recs_for_binning(rs, g == 0);
     if (g >= n) return;
     const PrevBox old_box = prev_box[g];  // with the other inputs, ahead of the stores
     const float opac = P.opacity[g];
@@ -1554,17 +1540,13 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
             if (model == 2) {
                 hipLaunchKernelGGL(train_reduce_update_quant_kernel<2>, dim3(l.blocks), dim3(l.bs), 0, st, uq, Q, a[0],
                                    a[1], a[2], step);
-#ifndef GI2D_NO_QUANT_FINISH /* development aid (wrong results): what the closing launch costs an iteration */
                 hipLaunchKernelGGL(train_quant_finish_kernel<2>, dim3(1), dim3(256), 0, st, l.rows, uq, Q, a[1], aq[0],
                                    aq[1], aq[2], step);
-#endif
             } else {
                 hipLaunchKernelGGL(train_reduce_update_quant_kernel<1>, dim3(l.blocks), dim3(l.bs), 0, st, uq, Q, a[0],
                                    a[1], a[2], step);
-#ifndef GI2D_NO_QUANT_FINISH
                 hipLaunchKernelGGL(train_quant_finish_kernel<1>, dim3(1), dim3(256), 0, st, l.rows, uq, Q, a[1], aq[0],
                                    aq[1], aq[2], step);
-#endif
             }
         }
         single_pass_end(s->workspace, w, tiles, st);

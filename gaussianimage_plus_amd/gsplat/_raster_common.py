@@ -202,6 +202,7 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
     final_Ts = None if plus else torch.ones(img_height, img_width, device=xys.device)
     cnt_gs_counts = None if plus else torch.zeros(img_height, img_width, dtype=torch.int32, device=xys.device)
 
+    ctx.set_materialize_grads(False)  # the unused outputs' gradients as None, not as zero-filled tensors
     ctx.img_width, ctx.img_height = img_width, img_height
     ctx.BLOCK_H, ctx.BLOCK_W = BLOCK_H, BLOCK_W
     ctx.radius_clip = float(radius_clip)
@@ -212,6 +213,8 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
 
 def backward_impl(ctx, plus: bool, v_out_img):
     xys, radii, conics, colors, opacity = ctx.saved_tensors
+    if v_out_img is None:  # (set_materialize_grads(False): the image took no part in the loss)
+        v_out_img = torch.zeros(ctx.img_height, ctx.img_width, 3, device=xys.device)
     v_out_img = v_out_img.contiguous()
     if ctx.exact is not None:
         gids, bins, final_idx = ctx.exact

@@ -39,6 +39,9 @@ class _ProjectGaussians2d(Function):
     @staticmethod
     def forward(ctx, means2d, L_elements, img_height, img_width, tile_bounds, clip_thresh=0.01,
                 radius_clip=2.0, isprint=False):
+        # gradients of outputs nobody used (depths: always) arrive as None instead of freshly zero-filled tensors -- one
+        # fill kernel per such output and backward, ~4 us each in a replayed graph
+        ctx.set_materialize_grads(False)
         num_points = means2d.shape[-2]
         xys, depths, radii, conics, num_tiles_hit = _C.project_gaussians_2d_forward(
             num_points, 3.0, means2d, L_elements, img_height, img_width, tile_bounds, clip_thresh,

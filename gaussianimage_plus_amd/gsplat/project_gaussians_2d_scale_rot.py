@@ -37,6 +37,9 @@ class _ProjectGaussians2dScaleRot(Function):
     @staticmethod
     def forward(ctx, means2d, scales2d, rotation, img_height, img_width, tile_bounds, clip_thresh=0.01,
                 radius_clip=2.0, isprint=False):
+        # gradients of outputs nobody used (depths: always) arrive as None instead of freshly zero-filled tensors -- one
+        # fill kernel per such output and backward, ~4 us each in a replayed graph
+        ctx.set_materialize_grads(False)
         num_points = means2d.shape[-2]
         if num_points < 1 or means2d.shape[-1] != 2:  # project_gaussians_2d_scale_rot.py:84-85
             raise ValueError(f"Invalid shape for means2d: {means2d.shape}")

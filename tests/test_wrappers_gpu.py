@@ -114,6 +114,15 @@ def test_zero_intersections_gives_background_and_zero_grads(gs):
     assert torch.equal(img, bg.expand(h, w, 3))
     img.sum().backward()
     assert float(col.grad.abs().max()) == 0.0
+    # "not a single intersection" is noted by the binning step (a word stamped with its version: nothing ever resets
+    # it) and acted on by the forward's own tile pass -- so the same pooled workspace must get it right in any order:
+    # a scene with intersections, none again, and a scene again
+    c_ok = torch.tensor([[9.0, 0.0, 9.0]], device=DEV).repeat(npts, 1)
+    for cov, empty in ((c_ok, False), (c_t.detach(), True), (c_t.detach(), True), (c_ok, False), (c_t.detach(), True)):
+        with torch.no_grad():
+            xys, depths, radii, conics, nth = gs.project_gaussians_2d_covariance(m_t.detach(), cov, h, w, tb)
+            img = gs.rasterize_gaussians_plus(xys, depths, radii, conics, nth, col.detach() + 0.5, op, h, w, background=bg)
+        assert torch.equal(img, bg.expand(h, w, 3)) == empty, empty
 
 
 def test_wrapper_errors(gs):

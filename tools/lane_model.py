@@ -110,6 +110,11 @@ def main():
     out = {"scene": f"N={n} {w}x{h} seed {seed} (tests/helpers.py::synth_cholesky)", "num_intersects": m,
            "entries_reaching_their_tile": reaching, "backward_items_per_tile": items_total / len(tiles),
            "useful_lane_frac_fwd": f_useful / f_issued, "useful_lane_frac_bwd": b_useful / b_issued,
+           # absolute counts (DESIGN.md "what a 16x16-tile design caps at"): pixel x gaussian evaluations inside a box,
+           # and the lane-evaluations the kernels' scheduling issues for them (backward: two pixel rows per lane-trip)
+           "useful_pair_evals_fwd": int(f_useful), "issued_lane_evals_fwd": int(f_issued),
+           "useful_pair_evals_bwd": int(b_useful), "issued_lane_evals_bwd": int(b_issued),
+           "fwd_wave_trips": f_issued // 128, "bwd_wave_trips": b_issued // 128,
            "lane_model": "tools/lane_model.py: the kernels' list / item scheduling replayed in numpy; useful = pixel "
                          "evaluations inside a gaussian's alpha >= 1/255 box, issued = 64 lanes per wave-trip"}
     print(json.dumps(out))
