@@ -500,7 +500,7 @@ def images_per_s(args, rank, world, dev, red_dev, barrier):
 
 def pmc_traffic(kernel, n, h, w, images_per_launch=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/traffic.json, built by
-    tools/make_profiles3.py: 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md; one section per
+    tools/make_profiles_rounds.py: 2*FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md; one section per
     profiled workload) and where the figure comes from.  Hardware counters cannot be read from inside the timed
     process, so this is a STORED value of the same command under rocprofv3, labelled as such; null when no counters were
     collected for this workload."""
@@ -552,7 +552,7 @@ def valu_roofline(kernel, n, h, w, kernel_us, images_per_launch=None):
     """The VALU side of the tile pass (what DESIGN.md 3.4 argues it is bound by, next to the mandated HBM figure):
     wave-instructions per image and the time the SIMDs spend issuing them -- SQ_ACTIVE_INST_VALU quad-cycles x 4 /
     1024 SIMDs / shader clock -- against the kernel's duration measured live in this run.  The counters are STORED
-    values of the same command under `rocprofv3 --pmc` (profiles/traffic.json, tools/profile_round4.sh); the useful-lane
+    values of the same command under `rocprofv3 --pmc` (profiles/traffic.json, tools/profile_rounds.sh); the useful-lane
     fractions come from tools/lane_model.py (the kernels' own scheduling rules replayed on the scene in numpy)."""
     try:
         t, wl, v = _stored_kernel(kernel, n, h, w, images_per_launch)

@@ -1,5 +1,5 @@
 """bench.py's `batched` block alone, for K images per launch (development aid; run under rocprofv3 by
-tools/profile_round4.sh so that the stored counters of profiles/traffic.json belong to the scenes -- and the tile-pass form --
+tools/profile_rounds.sh so that the stored counters of profiles/traffic.json belong to the scenes -- and the tile-pass form --
 bench.py reports).  usage: batched_bench_scene.py [K]"""
 import json
 import os

@@ -10,7 +10,7 @@ gaussian's alpha >= 1/255 box -- the kernels' own scheduling rules (csrc/gi2d_ra
             useful = box pixels.
 
 usage: python tools/lane_model.py [N H W seed]     (the bench scene: 50000 512 768 3047; prints one JSON object that
-       tools/make_profiles4.py stores next to the VALU counters in profiles/traffic.json)"""
+       tools/make_profiles_rounds.py stores next to the VALU counters in profiles/traffic.json)"""
 import json
 import math
 import os

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/rp (tools/profile_round.sh) into the tracked evidence under profiles/:
+"""Turn gpurun_out/rp (tools/profile_round12.sh) into the tracked evidence under profiles/:
     <round>_bench_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the default bench.py run
     <round>_bench_under_rocprof.json  the JSON line bench.py printed in that run
     <round>_bench_plain.json          the JSON line of a plain run (no profiler) in the same gpurun call
     <round>_pmc_summary.txt           mean counter value per kernel, one line per kernel and --pmc pass
     traffic.json                      HBM bytes per launch per kernel (read by bench.py for roofline.traffic)
-usage: python tools/make_profiles.py round2"""
+usage: python tools/make_profiles12.py round2"""
 import collections
 import csv
 import glob

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/rp<N> (tools/profile_round4.sh; N = the ROUND environment variable, default 4) into the tracked
+"""Turn gpurun_out/rp<N> (tools/profile_rounds.sh; N = the ROUND environment variable, default 5) into the tracked
 evidence under profiles/:
     round3_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the workload (head, c4_2k, batched,
                                          c5_rs_quant, trained_fit)
@@ -12,7 +12,7 @@ evidence under profiles/:
                                          lane model of the bench scene (tools/lane_model.py)
     round4_dropin_profile_after.txt      the drop-in autograd loop under cProfile
     round4_kodak_fit_50k_run.txt         the images/s leg alone (24 Kodak images x 50 000 iterations)
-usage: python tools/make_profiles4.py"""
+usage: python tools/make_profiles_rounds.py"""
 import collections
 import csv
 import glob
@@ -21,12 +21,12 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "4")
+ROUND = os.environ.get("ROUND", "5")
 SRC = os.path.join(ROOT, "gpurun_out", "rp" + ROUND)
 DST = os.path.join(ROOT, "profiles")
 TAG = "round" + ROUND
 NAMES = {"head": "bench", "c4": "c4_2k", "batched": "batched", "c5": "c5_rs_quant", "fit": "trained_fit",
-         "frozen": "frozen_scene", "trained": "trained_scene"}
+         "frozen": "frozen_scene", "trained": "trained_scene", "batched4": "batched_k4", "batched8": "batched_k8"}
 
 
 def short(name):
@@ -92,8 +92,8 @@ for work, name in NAMES.items():
                 open(os.path.join(DST, f"{TAG}_bench_under_rocprof.json"), "w").write(js[-1])
             else:
                 open(os.path.join(DST, f"{TAG}_c4_2k_under_rocprof.json"), "w").write(js[-1])
-    elif work == "batched":
-        cfg = {"num_points": 50000, "height": 512, "width": 768, "images_per_launch": 24}
+    elif work in ("batched", "batched4", "batched8"):
+        cfg = {"num_points": 50000, "height": 512, "width": 768, "images_per_launch": int(work[7:] or 24)}
     elif work == "frozen":
         cfg = {"num_points": 50000, "height": 512, "width": 768, "frozen": True}
     wl = {"workload": name, "config": cfg, "kernels": kernels}
@@ -109,12 +109,17 @@ open(os.path.join(DST, f"{TAG}_pmc_summary.txt"), "w").write("\n".join(lines) + 
 plain = [l for l in open(os.path.join(SRC, "bench_plain.json")) if l.startswith("{")]
 if plain:
     open(os.path.join(DST, f"{TAG}_bench_plain.json"), "w").write(plain[-1])
+for src, dst in (("c4_plain.json", f"{TAG}_c4_2k_plain.json"), ("bench_driverlike.json", f"{TAG}_bench_steps20_plain.json")):
+    if os.path.exists(os.path.join(SRC, src)):
+        js = [l for l in open(os.path.join(SRC, src)) if l.startswith("{")]
+        if js:
+            open(os.path.join(DST, dst), "w").write(js[-1])
 bp = os.path.join(SRC, "batched_plain.out")
 if os.path.exists(bp):
     open(os.path.join(DST, f"{TAG}_batched_plain.txt"), "w").write(
         "".join(l for l in open(bp) if l.startswith("K=") or l.startswith("single")))
 for src, dst in (("dropin_profile.txt", f"{TAG}_dropin_profile_after.txt"), ("kodak50k.out", f"{TAG}_kodak_fit_50k_run.txt"),
-                 ("trained_fit.out", f"{TAG}_trained_scene_fit.txt")):
+                 ("trained_fit.out", f"{TAG}_trained_scene_fit.txt"), ("kodak_shards.out", f"{TAG}_kodak_shards.txt")):
     if os.path.exists(os.path.join(SRC, src)):
         keep = [l for l in open(os.path.join(SRC, src)) if "amdgpu.ids" not in l]
         open(os.path.join(DST, dst), "w").write("".join(keep))
@@ -123,6 +128,6 @@ for work in ("c5", "fit"):
     if os.path.exists(f):
         keep = [l for l in open(f) if ("us/iter" in l or "images/s" in l or l.startswith("best"))]
         open(os.path.join(DST, f"{TAG}_{NAMES[work]}_run.txt"), "w").write("".join(keep))
-json.dump({"source": f"profiles/{TAG}_pmc_summary.txt (tools/profile_round4.sh, separate --pmc passes)",
+json.dump({"source": f"profiles/{TAG}_pmc_summary.txt (tools/profile_rounds.sh, separate --pmc passes)",
            "workloads": workloads}, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print("\n".join(lines))

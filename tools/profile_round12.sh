@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence kept under profiles/: kernel-trace stats of the default bench.py run and four
 # separate --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ groups).  Run on the GPU box:
-#   gpurun -- 'bash tools/profile_round.sh'      then      python tools/make_profiles.py round2
+#   gpurun -- 'bash tools/profile_round12.sh'      then      python tools/make_profiles12.py round2
 set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/rp

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence kept under profiles/round<N>_* (ROUND, default 4; round 3's files were made by the
+# Collect the rocprofv3 evidence kept under profiles/round<N>_* (ROUND, default 5; rounds 3 and 4 were made by the
 # same script): for each workload the kernel-trace stats and separate --pmc passes (FETCH_SIZE / WRITE_SIZE / two SQ
 # groups; never combined with other trace domains).
-#   gpurun --timeout 1200 -- 'bash tools/profile_round4.sh'      then      python tools/make_profiles4.py
+#   gpurun --timeout 1200 -- 'bash tools/profile_rounds.sh'      then      python tools/make_profiles_rounds.py
 # workloads: head    bench.py's timed loop (Cholesky, N=50 000, 768x512, training iterations)
 #            c4      the same at 2040x1356 (BASELINE config 4)
 #            batched 24 images per launch (bench.py's `batched` block: tools/batched_bench_scene.py; timings without the
@@ -14,7 +14,7 @@
 #            dropin  the drop-in autograd loop under cProfile (tools/profile_autograd_loop.py)
 set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-4}
+ROUND=${ROUND:-5}
 OUT=$REPO/gpurun_out/rp$ROUND
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -48,6 +48,10 @@ python3 $REPO/tools/batch_time.py 50000 512 768 cholesky 4 8 24 > $OUT/batched_p
 for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc batched $1 "$2" $REPO/tools/batched_bench_scene.py 24; done
 pmc batched sq1 "$SQ1" $REPO/tools/batched_bench_scene.py 24
 pmc batched sq2 "$SQ2" $REPO/tools/batched_bench_scene.py 24
+for K in 4 8; do
+  mkdir -p $OUT/batched$K
+  for p in "fetch FETCH_SIZE" "write WRITE_SIZE"; do set -- $p; pmc batched$K $1 "$2" $REPO/tools/batched_bench_scene.py $K; done
+done
 echo "batched done"
 stats c5 $REPO/tools/quant_time.py 30000 400 scale_rot
 pmc c5 sq1 "$SQ1" $REPO/tools/quant_time.py 30000 100 scale_rot
@@ -65,4 +69,9 @@ python3 $REPO/tools/kodak_fit.py 24 50000 3 > $OUT/kodak50k.out 2>&1 || true
 (cd $REPO && python3 tools/lane_model.py > $OUT/lane_model.json 2> /dev/null) || true
 echo "dropin + kodak done"
 cd $REPO && python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+python3 bench.py $C4 > $OUT/c4_plain.json 2> /dev/null          # (no profiler: the c4 figures DESIGN.md quotes)
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --images 0 --no-batched --no-static --no-dropin > $OUT/bench_driverlike.json 2> /dev/null
+python3 tools/kodak_fit.py 3 50000 3 > $OUT/kodak_shards.out 2>&1 || true
+python3 tools/kodak_fit.py 6 50000 3 >> $OUT/kodak_shards.out 2>&1 || true
+python3 tools/kodak_fit.py 12 50000 3 >> $OUT/kodak_shards.out 2>&1 || true
 tail -n 1 $OUT/bench_plain.json | cut -c1-400
