@@ -43,6 +43,7 @@ struct NextFill {
     int32_t *num_tiles_hit, *lists, *status, *tile_order;
     PrevBox *prev_box;
     RecSets recs;
+    float4 *inbox;  // the tiles' inboxes (FastWs::inbox_recs)
 };
 
 struct AdamStep {
@@ -68,6 +69,7 @@ struct TilePassArgs {
     float *tile_sse;
     const int32_t *tile_order;
     int32_t *big_tile;  // two-phase tile pass: which tiles the small form left to the general one (FastWs::big_tile)
+    float4 *inbox;      // the tiles' inboxes (FastWs::inbox_recs)
 };
 
 // One image's arguments of the per-gaussian fitting kernels (project+fill, reduce+update).
@@ -95,6 +97,7 @@ static inline TilePassArgs tile_pass_args(const FastWs &w, int n, int tiles_x, i
     a.tiles_x = tiles_x, a.tiles_y = tiles_y, a.img_w = img_w, a.img_h = img_h;
     a.rs = rec_sets(w, n);
     a.lists = w.lists;
+    a.inbox = w.inbox_recs;
     a.tile_bins = (int2 *)w.tile_bins;
     a.partial_g = w.partial_g;
     a.partial_big = w.partial_big;

@@ -36,6 +36,9 @@ static std::string dev_switches() {
 #ifdef GI2D_FUSED_TRACE
     add("GI2D_FUSED_TRACE", "");
 #endif
+#ifdef GI2D_INBOX_STATS
+    add("GI2D_INBOX_STATS", "");
+#endif
 #ifdef GI2D_DEV_VARIANT /* any other experiment: -DGI2D_DEV_VARIANT=name next to its own macros */
     add("GI2D_DEV_VARIANT", GI2D_STR(GI2D_DEV_VARIANT));
 #endif

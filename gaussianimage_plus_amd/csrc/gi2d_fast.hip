@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
                 row[1] = z;
                 row[2] = z;
             }
-        });
+        }, Inbox{nullptr}, head_row_load(lists, tile, false));
     __syncthreads();
     const int len = L > GI2D_TILE_LIST_CAP ? GI2D_TILE_LIST_CAP : L;
     // "No intersection at all" (image = background) is a global property no single tile can decide: every
@@ -211,13 +211,16 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
     // gaussian ids, which only change when rows were actually dropped -- one check in a few hundred on a Kodak fit
     if (only_if_moved && (only_if_moved[0] == only_if_moved[1] || only_if_moved[0] == 0)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3) ver[i] = 0;  // the two record-set counters and the any-member stamp (GI2D_VER_ANY)
+    if (i < GI2D_VER_WORDS) ver[i] = 0;  // the two record-set counters and the any-member stamp (GI2D_VER_ANY)
     if (i == 0) lists[GI2D_POOL_CURSOR] = 0;  // the row pool is empty
     if (i < num_tiles) {
         lists[(size_t)i * GI2D_FAST_LROW] = 0;
         lists[(size_t)i * GI2D_FAST_LROW + 1] = 0;
         tile_order[i] = i;
     }
+    // ... and every tile's inbox: 64 bitmap words behind its ids
+    for (long long k = i; k < (long long)num_tiles * GI2D_INBOX_WORDS; k += (long long)gridDim.x * blockDim.x)
+        inbox_bits_of(lists, (int)(k / GI2D_INBOX_WORDS))[k % GI2D_INBOX_WORDS] = 0;
     if (i < n) prev_box[i] = no_box();
 }
 
@@ -229,7 +232,9 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 // PHASE 2: ... and handled by the general form in a second launch whose other workgroups return at once.
 // The per-tile code is the same template (fused_tile<MODE, CAP>), so a tile's results do not depend on the phase.
 // `mark_big` (batched launches): the general form marks the rows above GI2D_SMALL_CAP too -- batch_pass_end counts them.
-template <int MODE, int PHASE>
+// INBOX: the head takes entrants out of the tile's inbox (gi2d_fast_internal.h::Inbox) -- the one launch of one image,
+// which is what follows the one kernel that puts any in; every other form is built without that code.
+template <int MODE, int PHASE, bool INBOX = false>
 __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int slot, bool first, bool mark_big = false) {
     constexpr int CAP = PHASE == 1 ? GI2D_SMALL_CAP : GI2D_TILE_LIST_CAP;
     __shared__ FusedLdsT<CAP> sm;
@@ -237,21 +242,23 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
     HeadRow hr;
     if (PHASE == 2) {  // (the caller has looked at big_tile: only tiles the small form passed over arrive here)
         tile = __builtin_amdgcn_readfirstlane(a.tile_order[slot]);
-        hr = head_row_load(a.lists, tile);
+        hr = head_row_load(a.lists, tile, INBOX);
     } else {
-        hr = head_row_for(a.lists, a.tile_order, slot, tile);
+        hr = head_row_for(a.lists, a.tile_order, slot, tile, INBOX);
     }
     // (ahead of the early return below: the launch's first workgroup records which record set this pass reads --
     // RecSets::ver[0] -- whether or not its own tile is left to phase 2; a pipelined end-of-step kernel reads that word)
     const float4 *recs = recs_for_tile_pass(a.rs, first && threadIdx.x == 0);
+    Inbox ib;
+    ib.recs = a.inbox;
     if (PHASE == 1 || (PHASE == 0 && mark_big)) {
         const bool big = __builtin_amdgcn_readfirstlane(hr.hdr_count) > GI2D_SMALL_CAP;  // workgroup-uniform
         if (threadIdx.x == 0) a.big_tile[tile] = big ? 1 : 0;
         if (PHASE == 1 && big) return;
     }
     // (phase 2 loops over tiles: its loop keeps the lane's invariants alive, so the forward's trips are not unrolled there)
-    fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
-                          a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr);
+    fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL, INBOX>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
+                          a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr, ib);
 }
 
 // Phase 2 finds nothing to do on the scenes the two-phase form is for (large images: sparse rows), and ten thousand
@@ -266,6 +273,7 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
 #ifndef GI2D_TWO_PHASE_TILES
 #define GI2D_TWO_PHASE_TILES (256 * GI2D_FUSED_OCC) /* development aid: a huge value keeps every launch single-phase */
 #endif
+static_assert(GI2D_INBOX_MAX_TILES <= GI2D_TWO_PHASE_TILES, "the inboxes are for launches that run the general form throughout");
 // workgroups per CU the register allocator leaves room for, by phase: the loop of phase 2 keeps the lane's invariants
 // alive across tiles (80 registers and a few dwords of scratch at six per CU -- and a kernel with ANY scratch pays
 // ~200 us per dispatch here while the runtime re-arms the queue's scratch: measured) -- so it is built for four (five still left one of the four kernels with 12 bytes of it)
@@ -291,8 +299,8 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
         }
     } else {
         // (a large image in the general form marks its fuller tiles too: single_pass_end counts them)
-        tile_pass_workgroup<MODE, PHASE>(a, (int)blockIdx.x, blockIdx.x == 0,
-                                         a.tiles_x * a.tiles_y > GI2D_TWO_PHASE_TILES);
+        tile_pass_workgroup<MODE, PHASE, PHASE == 0>(a, (int)blockIdx.x, blockIdx.x == 0,
+                                                     a.tiles_x * a.tiles_y > GI2D_TWO_PHASE_TILES);
     }
 }
 

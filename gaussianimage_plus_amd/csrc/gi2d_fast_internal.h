@@ -24,7 +24,12 @@ namespace gi2d {
 // gaussian ids are renumbered (pruning / compaction) or after an overflow.
 #define GI2D_FAST_C 1024                             /* list slots per tile */
 #define GI2D_FAST_HDR 16                             /* header words in front of a row's ids */
-#define GI2D_FAST_LROW (GI2D_FAST_C + GI2D_FAST_HDR) /* words per row */
+#define GI2D_INBOX_WORDS 64                          /* bitmap of the tile's inbox behind its ids (below) */
+#define GI2D_INBOX_SLOTS (32 * GI2D_INBOX_WORDS)     /* 8 neighbour directions x 256 ranks */
+#ifndef GI2D_INBOX_MAX_TILES
+#define GI2D_INBOX_MAX_TILES 1536                    /* images of more tiles do without (Inbox below) */
+#endif
+#define GI2D_FAST_LROW (GI2D_FAST_C + GI2D_FAST_HDR + GI2D_INBOX_WORDS) /* words per row */
 #define GI2D_FAST_EPT (GI2D_FAST_C / 256)            /* list entries per lane of the 256-lane tile workgroup */
 #define GI2D_FAST_S 32                               /* gaussian-major partial rows per gaussian: a gaussian on <= 32
                                                         tiles finds its rows by position in its box.  16 left every
@@ -60,6 +65,68 @@ typedef int4 PrevBox;
 #define GI2D_STATUS_POOL 4
 __host__ __device__ __forceinline__ PrevBox no_box() { return make_int4(0, 0, -1, 0); }
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+// THE INBOX OF A TILE -- how a gaussian enters a tile without waiting for an atomic's answer.  The update kernel of a
+// fit ends with the binning step of the next iteration, and a gaussian that has ENTERED a tile used to reserve its slot
+// in the tile's row with a returning atomic: a device-scope round trip at the very end of every lane's dependency
+// chain, 3 us of a 10 us kernel, paid by the whole launch because some lane of nearly every wave needs it.  A slot
+// that needs no answer is one nobody else can want: a gaussian entering tile t is, one pass earlier, at a known rank
+// r < 256 in the staged list of some NEIGHBOUR s of t that it is in (the tile pass hands every staged entry its rank in
+// the spare word of the gradient row it writes anyway) -- slot (t, direction of s, r) is its alone.  It stores its
+// 64-byte record there and sets the slot's bit in the tile's 2048-bit bitmap with a NON-returning atomicOr; the tile's
+// workgroup -- the only writer of its row during a pass -- reads the bitmap with its row, the marked records with its
+// entries' records, appends what it finds and clears the bits (tile_list_head).  Entrants with no staged neighbour
+// (a new scene, a gaussian from afar, rank beyond the 256-entry cap) and boxes of more than eight tiles keep the
+// returning atomic; binning kernels that do not know ranks (everything but the update kernel of a fit) likewise.
+// Only where it pays: the update kernel of ONE image of at most GI2D_INBOX_MAX_TILES tiles -- the launches whose tile
+// pass is the general form throughout.  A batch hides the round trip behind its other images' workgroups, and a larger
+// image's tile pass runs the small form first (gi2d_fast.hip), which has no registers to spare for entrants.
+// WHO MAY FIND AN INBOX NON-EMPTY: only the tile pass that gi2d_train_steps issues right behind such an update kernel,
+// in the same call -- the update kernel only bins when another iteration follows in its call (FILL_NEXT), so every call
+// returns with all inboxes empty, and no other kernel ever writes to one.  That pass (fast_fwdbwd_kernel<MODE, 0>) is
+// the only kernel built with the code that takes entrants in; nobody else loads a bitmap word.  The ranks are good for
+// the same reason: the update kernel runs right behind the tile pass whose gradient rows it reduces.
+struct Inbox {
+    float4 *recs;  // [T][GI2D_INBOX_SLOTS][4]: a record as write_record leaves it, its last word the gaussian's id
+};
+__device__ __forceinline__ int32_t *inbox_bits_of(int32_t *lists, int tile) {
+    return lists + (size_t)tile * GI2D_FAST_LROW + GI2D_FAST_HDR + GI2D_FAST_C;
+}
+// What an entering gaussian knows of its old tiles (the update kernel of a fit): the ranks it was staged at in the
+// (<= 8) tiles of its old box.
+struct InboxSrc {
+    // rank + 1 as the tile pass left it in the gradient row of tile i of the old box (0: none); kept as loaded -- only the
+    // few lanes whose box changes ever look at one.  (Eight named words, not an array: the compiler turns a select over
+    // an array's elements into an indexed load, i.e. puts the array -- and the struct around it -- into scratch memory.)
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7;
+    bool on;  // lanes that may use the inboxes at all
+    __device__ __forceinline__ void clear() { t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = 0u; }
+    __device__ __forceinline__ void set(int q, unsigned v) {
+        switch (q) {
+            case 0: t0 = v; break;
+            case 1: t1 = v; break;
+            case 2: t2 = v; break;
+            case 3: t3 = v; break;
+            case 4: t4 = v; break;
+            case 5: t5 = v; break;
+            case 6: t6 = v; break;
+            default: t7 = v; break;
+        }
+    }
+    __device__ __forceinline__ unsigned get(int k) const {
+        unsigned a0 = t0, a1 = t1, a2 = t2, a3 = t3, a4 = t4, a5 = t5, a6 = t6, a7 = t7;
+        // (values, not loads: a select between loads of one object becomes a load at a selected address)
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        unsigned v = a0;
+        v = k == 1 ? a1 : v;
+        v = k == 2 ? a2 : v;
+        v = k == 3 ? a3 : v;
+        v = k == 4 ? a4 : v;
+        v = k == 5 ? a5 : v;
+        v = k == 6 ? a6 : v;
+        v = k == 7 ? a7 : v;
+        return v;
+    }
+};
 // Workgroup size of the one-lane-per-gaussian kernels (project+fill, reduce+project backward, optimizer update):
 // single waves spread a small population over many CUs and shorten the dependent load chains
 // (N=2500: project+fill 10.9 -> 5.5 us, reduce 7.4 -> 4.7 us; neutral to slightly worse beyond ~30k gaussians).
@@ -68,7 +135,9 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 #endif
 static inline int per_gaussian_block(int n) { return n <= 32768 ? 64 : GI2D_PG_BIG; }
 struct FastWs {
-    int32_t *lists;        // [T * LROW]         persistent tile lists (see above)
+    int32_t *lists;        // [T * LROW]         persistent tile lists (see above), each row with its inbox bitmap
+    float4 *inbox_recs;    // [T * 2048 * 4]     the tiles' inboxes (Inbox): sparsely used address space, 128 KB per tile
+                           //                    (images of at most GI2D_INBOX_MAX_TILES tiles; none otherwise)
     int32_t *gids_sorted;  // == lists: tile_bins hold absolute word positions into it
     int32_t *tile_bins;    // [T * 2]            [row base + HDR, row base + HDR + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
@@ -91,6 +160,11 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     char *b = (char *)base;
     size_t off = 0;
     const size_t t = (size_t)(num_tiles > 0 ? num_tiles : 1), nn = (size_t)(n > 0 ? n : 1);
+    // the inboxes' records FIRST: 192 MiB of sparsely used address space in the middle of the arrays every kernel works
+    // on cost the batched kernels 1.5 % (measured: the same arrays, further apart), and behind them its place would
+    // depend on the gaussian count
+    w.inbox_recs = (float4 *)(b + off);
+    if (t <= GI2D_INBOX_MAX_TILES) off += align_up(t * GI2D_INBOX_SLOTS * 4 * sizeof(float4));
     w.lists = (int32_t *)(b + off);
     w.gids_sorted = w.lists;
     off += align_up(t * GI2D_FAST_LROW * sizeof(int32_t));
@@ -138,28 +212,120 @@ struct FillPending {
     int c[GI2D_FILL_BATCH], p[GI2D_FILL_BATCH];
     int nt, w, mnx, mny, omnx, omxx, omny, omxy, di, dj;  // nt == 0: nothing to append
     int pool;                                             // first pool row of the gaussian's run (-1: none)
+    bool live;                                            // the last trip issued atomics (c / p are set)
 };
-__device__ __forceinline__ void fill_trip_issue(FillPending &f, int base, int tiles_x, int32_t *__restrict__ lists) {
+// What a binning step that may use the inboxes hands to fill_diff_begin: where they are, what the gaussian knows of its
+// old tiles, and its record (the words write_record stores; the pool word is filled in once the run is known).
+#ifdef GI2D_INBOX_STATS /* development aid (tools/inbox_stats.py): counters in the padding of tile row 0's header */
+#define GI2D_INBOX_STAT(word) atomicAdd(&lists[word], 1)
+#else
+#define GI2D_INBOX_STAT(word) \
+    do {                      \
+    } while (0)
+#endif
+struct InboxFill {
+    Inbox ib;
+    InboxSrc src;
+    float4 q[4];
+};
+// Tile (ti, tj) has been entered by a gaussian whose old box is f.o*: through the inbox if the nearest tile of the old
+// box is a neighbour that handed a rank on (true), through the row's header otherwise.
+__device__ __forceinline__ bool inbox_enter(const FillPending &f, const InboxFill &in, int ti, int tj, int tiles_x,
+                                            int32_t *__restrict__ lists) {
+    const int sj = min(max(tj, f.omnx), f.omxx - 1), si = min(max(ti, f.omny), f.omxy - 1);
+    const int ddx = sj - tj, ddy = si - ti;  // not both zero: the tile is outside the old box
+    if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) {
+        GI2D_INBOX_STAT(11);
+        return false;
+    }
+    const int k = (si - f.omny) * (f.omxx - f.omnx) + (sj - f.omnx);  // < 8: the caller only comes with such boxes
+    const int r = (int)in.src.get(k) - 1;
+    if ((unsigned)r >= (unsigned)GI2D_TILE_LIST_CAP) {
+        GI2D_INBOX_STAT(12);
+        return false;
+    }
+    GI2D_INBOX_STAT(9);
+    int d = (ddy + 1) * 3 + (ddx + 1);
+    d -= d > 4 ? 1 : 0;
+    const int slot = d * GI2D_TILE_LIST_CAP + r, tile = ti * tiles_x + tj;
+    float4 *dst = in.ib.recs + 4 * ((size_t)tile * GI2D_INBOX_SLOTS + slot);
+    dst[0] = in.q[0], dst[1] = in.q[1], dst[2] = in.q[2], dst[3] = in.q[3];
+    atomicOr(reinterpret_cast<unsigned *>(inbox_bits_of(lists, tile)) + (slot >> 5), 1u << (slot & 31));  // no answer needed
+    return true;
+}
+template <bool INBOX>
+__device__ __forceinline__ void fill_trip_issue(FillPending &f, int base, int tiles_x, int32_t *__restrict__ lists,
+                                                const InboxFill *in = nullptr) {
+    // the entered tiles that take the gaussian through their inbox (a ROLLED loop over the trip's tiles: one copy of the
+    // record's stores, no indexing of register arrays; a lane has one or two entered tiles, rarely more)
+    unsigned handled = 0u;
+    if constexpr (INBOX) {
+#ifdef GI2D_INBOX_STATS
+        if (base == 0) {
+            GI2D_INBOX_STAT(13);                       // lanes whose box changed
+            if (!in->src.on) GI2D_INBOX_STAT(14);      // ... that may not use the inboxes
+            if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) GI2D_INBOX_STAT(15);  // waves
+        }
+#endif
+        bool left = false;  // an entered tile that is left to the header's atomic
+        int di = f.di, dj = f.dj;
+        const int trips = min(GI2D_FILL_BATCH, f.nt - base);
+        for (int q = 0; q < trips; ++q) {
+            const int ti = f.mny + di, tj = f.mnx + dj;
+            const bool was = tj >= f.omnx && tj < f.omxx && ti >= f.omny && ti < f.omxy;
+            if (!was) {
+                if (in->src.on && inbox_enter(f, *in, ti, tj, tiles_x, lists))
+                    handled |= 1u << q;
+                else
+                    left = true;
+            }
+            if (++dj == f.w) dj = 0, ++di;
+        }
+        if (__ballot(left) == 0ull) {
+            // nothing for the headers (the steady state of a fit): the trip's sixteen-fold address arithmetic, its
+            // atomics and the stores behind them are not even looked at
+            f.di = di, f.dj = dj;
+            f.live = false;
+            if (f.nt - base <= GI2D_FILL_BATCH) f.nt = 0;  // the box's last trip: fill_diff_end has nothing to do
+            return;
+        }
+    }
     // GI2D_FILL_BATCH tiles per trip: the returning atomics of a trip are issued back to back, then the stores, so a
     // lane pays one round trip per trip instead of one per tile
 #pragma unroll
     for (int q = 0; q < GI2D_FILL_BATCH; ++q) {
         const int ti = f.mny + f.di, tj = f.mnx + f.dj;
         const bool was = tj >= f.omnx && tj < f.omxx && ti >= f.omny && ti < f.omxy;  // still listed from before
-        f.c[q] = (base + q < f.nt && !was) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
+        f.c[q] = (base + q < f.nt && !was && !((handled >> q) & 1u)) ? (ti * tiles_x + tj) * GI2D_FAST_LROW : -1;
         if (++f.dj == f.w) f.dj = 0, ++f.di;
     }
+#ifdef GI2D_INBOX_STATS
+    if constexpr (INBOX) {
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < GI2D_FILL_BATCH; ++q)
+            if (f.c[q] >= 0) {
+                any = true;
+                GI2D_INBOX_STAT(10);  // entered tiles that took the header's atomic
+            }
+        const unsigned long long wm = __ballot(any);
+        if (wm != 0ull && (threadIdx.x & 63) == __builtin_ctzll(wm)) GI2D_INBOX_STAT(7);  // waves that wait for one
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < GI2D_FILL_BATCH; ++q) f.p[q] = f.c[q] >= 0 ? atomicAdd(&lists[f.c[q]], 1) : GI2D_FAST_C;
+    f.live = true;
 }
 __device__ __forceinline__ void fill_trip_store(const FillPending &f, int g, int32_t *__restrict__ lists) {
+    if (!f.live) return;  // (the trip issued nothing: c / p are not even set)
 #pragma unroll
     for (int q = 0; q < GI2D_FILL_BATCH; ++q)
         if (f.p[q] < GI2D_FAST_C) lists[f.c[q] + GI2D_FAST_HDR + f.p[q]] = g;  // a fuller row is flagged by the tile pass
 }
+template <bool INBOX = false>
 __device__ __forceinline__ FillPending fill_diff_begin(int g, bool member, int mnx, int mny, int mxx, int mxy,
                                                        int tiles_x, PrevBox old, PrevBox *__restrict__ prev_box,
-                                                       int32_t *__restrict__ lists) {
+                                                       int32_t *__restrict__ lists, InboxFill *in = nullptr) {
     FillPending f;
     f.nt = 0;
     f.pool = old.z;
@@ -183,14 +349,17 @@ __device__ __forceinline__ FillPending fill_diff_begin(int g, bool member, int m
     f.mnx = mnx, f.mny = mny;
     f.w = mxx - mnx, f.nt = f.w * (mxy - mny);
     f.di = f.dj = 0;
-    fill_trip_issue(f, 0, tiles_x, lists);
+    if constexpr (INBOX) in->q[3].z = __int_as_float(f.pool);
+    fill_trip_issue<INBOX>(f, 0, tiles_x, lists, in);
     return f;
 }
-__device__ __forceinline__ void fill_diff_end(int g, FillPending &f, int tiles_x, int32_t *__restrict__ lists) {
+template <bool INBOX = false>
+__device__ __forceinline__ void fill_diff_end(int g, FillPending &f, int tiles_x, int32_t *__restrict__ lists,
+                                              const InboxFill *in = nullptr) {
     if (f.nt == 0) return;
     fill_trip_store(f, g, lists);
     for (int base = GI2D_FILL_BATCH; base < f.nt; base += GI2D_FILL_BATCH) {
-        fill_trip_issue(f, base, tiles_x, lists);
+        fill_trip_issue<INBOX>(f, base, tiles_x, lists, in);
         fill_trip_store(f, g, lists);
     }
 }
@@ -232,6 +401,7 @@ struct RecSets {
 // is not a single intersection (rasterize_sum_plus.py:110-118) compares the word with the version it reads
 // (tile_pass_has_members) instead of waiting for a second launch behind the tile pass.
 #define GI2D_VER_ANY 2 /* word of RecSets::ver */
+#define GI2D_VER_WORDS 3
 struct BinRecs {
     float4 *recs;
     int32_t *any;
@@ -283,20 +453,29 @@ __device__ __forceinline__ void begin_binning(int g, int32_t *__restrict__ statu
 // The record a binning step leaves per gaussian -- everything a tile pass needs of it, gathered with four 16-byte loads
 // of ONE line instead of nine dwords from five arrays (each of the ~72 entries of a tile used to cost 5-6 line requests,
 // all 1536 tiles asking at once):
-//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, radius, pool, -)
+//   (gx, gy, a, b) (c, opacity, r, g) (b, hx, hy, box.x) (box.y, radius, pool, id)
 // a, b, c: conic; (hx, hy): half extents of the alpha >= 1/255 box (gi2d_common.h::cull_extent), computed here once per
 // gaussian instead of once per (tile, gaussian); box: the tile box it is binned with (0/0: in no tile), which is what
 // the tile pass tests membership against and derives the partial-row slot from; pool: first row of its run in the row
 // pool (PrevBox).
-__device__ __forceinline__ void write_record(float4 *__restrict__ recs, int g, float2 xy, float a, float b, float c,
-                                             float opac, float cr, float cg, float cb, int2 box, int radius, int pool) {
+__device__ __forceinline__ void make_record(float4 (&q)[4], int g, float2 xy, float a, float b, float c, float opac,
+                                            float cr, float cg, float cb, int2 box, int radius, int pool) {
     float hx, hy;
     cull_extent(xy.x, xy.y, a, b, c, opac, hx, hy);
+    q[0] = make_float4(xy.x, xy.y, a, b);
+    q[1] = make_float4(c, opac, cr, cg);
+    q[2] = make_float4(cb, hx, hy, __int_as_float(box.x));
+    q[3] = make_float4(__int_as_float(box.y), __int_as_float(radius), __int_as_float(pool), __int_as_float(g));
+}
+__device__ __forceinline__ void store_record(float4 *__restrict__ recs, int g, const float4 (&q)[4]) {
     float4 *r = recs + 4 * (size_t)g;
-    r[0] = make_float4(xy.x, xy.y, a, b);
-    r[1] = make_float4(c, opac, cr, cg);
-    r[2] = make_float4(cb, hx, hy, __int_as_float(box.x));
-    r[3] = make_float4(__int_as_float(box.y), __int_as_float(radius), __int_as_float(pool), 0.f);
+    r[0] = q[0], r[1] = q[1], r[2] = q[2], r[3] = q[3];
+}
+__device__ __forceinline__ void write_record(float4 *__restrict__ recs, int g, float2 xy, float a, float b, float c,
+                                             float opac, float cr, float cg, float cb, int2 box, int radius, int pool) {
+    float4 q[4];
+    make_record(q, g, xy, a, b, c, opac, cr, cg, cb, box, radius, pool);
+    store_record(recs, g, q);
 }
 struct BinRec {
     GaussRec r;
@@ -304,19 +483,27 @@ struct BinRec {
     int2 box;
     int pool;
 };
-__device__ __forceinline__ BinRec load_record(const float4 *__restrict__ recs, int g) {
-    const float4 *p = recs + 4 * (size_t)g;
-    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-    const float4 q3 = p[3];
-    const float by = q3.x;
+__device__ __forceinline__ BinRec record_of(const float4 q0, const float4 q1, const float4 q2, const float4 q3, int g) {
     BinRec o;
     o.r.gx = q0.x, o.r.gy = q0.y, o.r.a = q0.z, o.r.b = q0.w;
     o.r.c = q1.x, o.r.opac = q1.y, o.r.cr = q1.z, o.r.cg = q1.w;
     o.r.cb = q2.x, o.r.slot = -1, o.r.gid = g, o.r.pad = 0;
     o.hx = q2.y, o.hy = q2.z;
-    o.box = make_int2(__float_as_int(q2.w), __float_as_int(by));
+    o.box = make_int2(__float_as_int(q2.w), __float_as_int(q3.x));
     o.pool = __float_as_int(q3.z);
     return o;
+}
+__device__ __forceinline__ BinRec load_record(const float4 *__restrict__ recs, int g) {
+    const float4 *p = recs + 4 * (size_t)g;
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const float4 q3 = p[3];
+    return record_of(q0, q1, q2, q3, g);
+}
+// a record waiting in an inbox slot: the same words, the gaussian's id in the last one
+__device__ __forceinline__ BinRec load_inbox_record(const float4 *__restrict__ p) {
+    const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const float4 q3 = p[3];
+    return record_of(q0, q1, q2, q3, __float_as_int(q3.w));
 }
 __device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mxx, int &mxy) {
     mnx = box.x & 0xffff, mxx = (int)((unsigned)box.x >> 16), mny = box.y & 0xffff, mxy = (int)((unsigned)box.y >> 16);
@@ -325,11 +512,14 @@ __device__ __forceinline__ void unpack_box(int2 box, int &mnx, int &mny, int &mx
 // appends to the rows of tiles it has entered, and its record.
 // `between`: the caller's own stores, issued after the binning step's atomics and before the stores that wait for them
 // (fill_diff_begin / _end above).
-template <class Between>
+// INBOX (the update kernel of a fit): `in` = the inboxes and what the gaussian knows of its old tiles (InboxFill; its
+// record words are filled in here).
+template <bool INBOX = false, class Between>
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
                                         float radius_clip, PrevBox old_box, PrevBox *__restrict__ prev_box,
-                                        int32_t *__restrict__ lists, const BinRecs &br, Between between) {
+                                        int32_t *__restrict__ lists, const BinRecs &br, Between between,
+                                        InboxFill *in = nullptr) {
     int mnx, mny, mxx, mxy;
     const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
     {  // one store per wave that holds a member (by its first such lane)
@@ -337,11 +527,21 @@ __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_t
         if (mm != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(mm)) *br.any = br.stamp;
     }
     float4 *recs = br.recs;
-    FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
-    write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0),
-                 radius, f.pool);
-    between();
-    fill_diff_end(g, f, tiles_x, lists);
+    const int2 box = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
+    if constexpr (INBOX) {
+        // the record first (registers): an entered tile's inbox gets a copy
+        make_record(in->q, g, xy, ka, kb, kc, opac, cr, cg, cb, box, radius, old_box.z);
+        FillPending f = fill_diff_begin<true>(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists, in);
+        in->q[3].z = __int_as_float(f.pool);
+        store_record(recs, g, in->q);
+        between();
+        fill_diff_end<true>(g, f, tiles_x, lists, in);
+    } else {
+        FillPending f = fill_diff_begin(g, member, mnx, mny, mxx, mxy, tiles_x, old_box, prev_box, lists);
+        write_record(recs, g, xy, ka, kb, kc, opac, cr, cg, cb, box, radius, f.pool);
+        between();
+        fill_diff_end(g, f, tiles_x, lists);
+    }
 }
 __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_tiles, float ka, float kb, float kc,
                                         float opac, float cr, float cg, float cb, int tiles_x, int tiles_y,
@@ -350,13 +550,13 @@ __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_t
     bin_one(g, xy, radius, has_tiles, ka, kb, kc, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip, old_box, prev_box, lists,
             recs, [] {});
 }
-template <class Between>
+template <bool INBOX = false, class Between>
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
                                               int tiles_x, int tiles_y, float radius_clip, PrevBox old_box,
                                               PrevBox *__restrict__ prev_box, int32_t *__restrict__ lists,
-                                              const BinRecs &recs, Between between) {
-    bin_one(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
-            old_box, prev_box, lists, recs, between);
+                                              const BinRecs &recs, Between between, InboxFill *in = nullptr) {
+    bin_one<INBOX>(g, o.xy, o.radius, o.tiles_hit > 0, o.k0, o.k1, o.k2, opac, cr, cg, cb, tiles_x, tiles_y, radius_clip,
+                   old_box, prev_box, lists, recs, between, in);
 }
 __device__ __forceinline__ void bin_projected(int g, const ProjOut &o, float opac, float cr, float cg, float cb,
                                               int tiles_x, int tiles_y, float radius_clip, PrevBox old_box,
@@ -418,40 +618,72 @@ __device__ __forceinline__ float4 *partial_row(int slot, float4 *__restrict__ pa
 // re-request on a miss (head_row_for): one dependent memory round trip less at the top of every tile.
 struct HeadRow {
     int hdr_count, hdr_sorted, id0;
+    unsigned inbox_w;  // word (lane) of the tile's inbox bitmap: every wave holds all 64 words
 };
-__device__ __forceinline__ HeadRow head_row_load(const int32_t *__restrict__ lists, int tile) {
+// `inbox`: the pass takes entrants out of the tiles' inboxes (compile-time at every call site).
+__device__ __forceinline__ HeadRow head_row_load(const int32_t *__restrict__ lists, int tile, bool inbox) {
     const int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
     HeadRow h;
     h.hdr_count = row[0], h.hdr_sorted = row[1], h.id0 = row[GI2D_FAST_HDR + threadIdx.x];
+    h.inbox_w = 0u;
+    if (inbox) h.inbox_w = (unsigned)row[GI2D_FAST_HDR + GI2D_FAST_C + (threadIdx.x & 63)];
     return h;
 }
 // `order[slot]` is the tile this workgroup handles; the row of tile `slot` is requested alongside.
 __device__ __forceinline__ HeadRow head_row_for(const int32_t *__restrict__ lists, const int32_t *__restrict__ order,
-                                                int slot, int &tile) {
-    HeadRow h = head_row_load(lists, slot);
+                                                int slot, int &tile, bool inbox) {
+    HeadRow h = head_row_load(lists, slot, inbox);
     tile = __builtin_amdgcn_readfirstlane(order[slot]);
-    if (tile != slot) h = head_row_load(lists, tile);  // workgroup-uniform
+    if (tile != slot) h = head_row_load(lists, tile, inbox);  // workgroup-uniform
     return h;
 }
 // The general form of the head for a row of more than 64 candidates: EPT = list entries per lane.  A row of at most 256
 // candidates -- every tile of the bench scene, nearly every tile of a trained one -- is served by the EPT = 1
 // instantiation, whose per-lane state is scalars and which has none of the `u < rounds` bookkeeping of the four-entry
 // form (a third of the head's scalar instructions on such rows).
-template <bool OPTIMISTIC, int EPT, class Prep, class Put>
+template <bool OPTIMISTIC, int EPT, bool INBOX, class Prep, class Put>
 __device__ __forceinline__ int tile_list_head_rows(int *ids, int *grp, int tile, int tx, int ty,
                                                    const float4 *__restrict__ recs, int32_t *__restrict__ row,
                                                    int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Prep prep,
-                                                   Put put, int id0, int hdr_count, int hdr_sorted, int count, int sorted) {
+                                                   Put put, int id0, int hdr_count, int hdr_sorted, int count, int sorted,
+                                                   unsigned inbox_w, const float4 *__restrict__ inbox) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int my_id[EPT];
     my_id[0] = id0;
-    if (tid == 0 && hdr_count > GI2D_FAST_C) {  // more candidates than a row holds: the caller must fall back
-        atomicOr(&status[1], 1);
+    // ---- the tile's inbox (Inbox): lane tid looks at byte tid of the bitmap, i.e. at slots 8 tid .. 8 tid + 7.  The
+    // FIRST entrant of a byte is staged like a row entry -- its record (the inbox's copy) arrives in the same round as
+    // the row entries' records; further ones of the same byte (two gaussians of neighbouring ranks entering from the
+    // same side: rare) only leave their ids and fetch their records when they are ranked.  `inbox` = this tile's slots.
+    int k_in = 0, ent_id = -1, ent_at = 0;
+    unsigned ent_more = 0u;
+    decltype(prep(0, BinRec())) st_in;
+    const bool any_in = INBOX && __ballot(inbox_w != 0u) != 0ull;  // workgroup-uniform
+    if (any_in) {
+        const int pc = __popc(inbox_w), incl_w = wave_inclusive_scan(pc);
+        k_in = wave_read_lane(incl_w, 63);
+        const unsigned wd = (unsigned)__shfl((int)inbox_w, tid >> 2, 64);
+        const int sh = 8 * (tid & 3);
+        const unsigned byte = (wd >> sh) & 0xffu;
+        ent_at = count + __shfl(incl_w - pc, tid >> 2, 64) + __popc(wd & ((1u << sh) - 1u));
+        if (byte != 0u) {
+            const BinRec rin = load_inbox_record(inbox + 4 * (size_t)(tid * 8 + __ffs((int)byte) - 1));
+            ent_id = rin.r.gid;
+            st_in = prep(ent_id, rin);
+            if (ent_at < GI2D_FAST_C) ids[ent_at] = ent_id;
+            ent_more = byte & (byte - 1u);
+            int at = ent_at + 1;
+            for (unsigned m = ent_more; m; m &= m - 1u, ++at)
+                if (at < GI2D_FAST_C) ids[at] = __float_as_int(inbox[4 * (size_t)(tid * 8 + __ffs((int)m) - 1) + 3].w);
+        }
+    }
+    const int count_all = min(count + k_in, GI2D_FAST_C);  // candidates in `ids` once the barrier is passed
+    if (tid == 0 && (hdr_count > GI2D_FAST_C || count + k_in > GI2D_FAST_C)) {  // more candidates than a row holds:
+        atomicOr(&status[1], 1);                                                  // the caller must fall back
         atomicOr(&status[2], 1);
     }
     // high-water mark for callers that read the status one call late (the autograd wrappers): as long as no row was
     // more than half full, an overflow cannot be one slowly moving step away
-    if (tid == 0 && hdr_count > GI2D_FAST_C / 2) atomicMax(&status[3], hdr_count);
+    if (tid == 0 && hdr_count + k_in > GI2D_FAST_C / 2) atomicMax(&status[3], hdr_count + k_in);
     if (tid >= count) my_id[0] = -1;
     GI2D_HEAD_TRACE(11);
     // the first entry's record is kept in registers; entries past 256 (rare) fetch theirs again when they are staged
@@ -518,17 +750,19 @@ __device__ __forceinline__ int tile_list_head_rows(int *ids, int *grp, int tile,
     }
     if (OPTIMISTIC && keep[0] && tid < sorted) put(tid, my_id[0], st0);  // tid < 256 = GI2D_TILE_LIST_CAP
     __syncthreads();
+    // the inbox is taken: every wave has read the bitmap (before the barrier), wave 0 clears it
+    if (any_in && wv == 0 && inbox_w != 0u) row[GI2D_FAST_HDR + GI2D_FAST_C + lane] = 0;
     GI2D_HEAD_TRACE(13);
     // one wave-level scan gives every lane what it needs: lane i < 16 holds group i's ascending survivors, lanes
     // 16..31 the appended ones
     const int cnt = (lane < 32 && (lane & 15) < 4 * EPT) ? grp[lane] : 0;  // (the groups this form wrote)
     const int incl = wave_inclusive_scan(cnt);
-    const int len = wave_read_lane(incl, 31);
+    const int len = wave_read_lane(incl, 31) + (count_all - count);  // (entrants are members: their tile took them in)
     const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     int before[EPT];
 #pragma unroll
     for (int u = 0; u < EPT; ++u) before[u] = wave_read_lane(incl - cnt, wv_u + 4 * u);
-    const bool clean = len == count && sorted == count;  // nothing dropped, nothing appended: every rank == position
+    const bool clean = len == count && sorted == count && !any_in;  // nothing dropped, nothing appended: rank == position
     if (tid == 0) {
         // an overflowed row keeps its count: it has lost entries, so every pass flags it until the workspace is emptied
         if (hdr_count <= GI2D_FAST_C && (hdr_count != len || hdr_sorted != len)) {
@@ -553,27 +787,45 @@ __device__ __forceinline__ int tile_list_head_rows(int *ids, int *grp, int tile,
         // ids are unique within a row, so "smaller" needs no tie rule; dropped entries read as -1 = 0xffffffff
         int rank, lo, hi;
         if (e < sorted)
-            rank = before[u] + pos[u], lo = sorted, hi = count;
+            rank = before[u] + pos[u], lo = sorted, hi = count_all;
         else
-            rank = 0, lo = 0, hi = count;
+            rank = 0, lo = 0, hi = count_all;
         for (int q = lo; q < hi; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
         const bool in_place = e < sorted && rank == e;  // an entry of the ascending part that nothing in front of it moved
         if (!in_place) row[GI2D_FAST_HDR + rank] = g;
         // ... and whose optimistic staging at rank = position (before the barrier) therefore already is the final one
         if (!(OPTIMISTIC && u == 0 && in_place)) put(rank, g, u == 0 ? st0 : prep(g, load_record(recs, g)));
     }
+    if (ent_id >= 0 && ent_at < GI2D_FAST_C) {  // the entrants: ranked against everything
+        int rank = 0;
+        for (int q = 0; q < count_all; ++q) rank += ((unsigned)ids[q] < (unsigned)ent_id) ? 1 : 0;
+        row[GI2D_FAST_HDR + rank] = ent_id;
+        put(rank, ent_id, st_in);
+        int at = ent_at + 1;
+        for (unsigned m = ent_more; m; m &= m - 1u, ++at) {
+            if (at >= GI2D_FAST_C) break;
+            const int g = ids[at];
+            rank = 0;
+            for (int q = 0; q < count_all; ++q) rank += ((unsigned)ids[q] < (unsigned)g) ? 1 : 0;
+            row[GI2D_FAST_HDR + rank] = g;
+            put(rank, g, prep(g, load_record(recs, g)));  // (the records are as the inbox's copies: no binning since)
+        }
+    }
     if (OPTIMISTIC) __syncthreads();  // OPTIMISTIC callers need no barrier of their own after the call
     return len;
 }
 
-template <bool OPTIMISTIC, class Prep, class Put>
+// INBOX: the head takes the entrants out of the tile's inbox (Inbox) -- the tile pass that follows the one kernel that
+// puts any in; every other caller is built without that code (and without the bitmap's load).
+template <bool OPTIMISTIC, bool INBOX = false, class Prep, class Put>
 __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int tx, int ty,
                                               const float4 *__restrict__ recs, int32_t *__restrict__ lists,
                                               int2 *__restrict__ tile_bins, int32_t *__restrict__ status, Prep prep, Put put,
-                                              const HeadRow *pre = nullptr) {
+                                              const Inbox &ib, const HeadRow hr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *row = lists + (size_t)tile * GI2D_FAST_LROW;
-    const HeadRow hr = pre ? *pre : head_row_load(lists, tile);
+    const bool any_in = INBOX && __ballot(hr.inbox_w != 0u) != 0ull;  // entrants in the tile's inbox (workgroup-uniform)
+    const float4 *inbox = ib.recs + 4 * ((size_t)tile * GI2D_INBOX_SLOTS);
     const int hdr_count_v = hr.hdr_count, hdr_sorted_v = hr.hdr_sorted;
     int my_id[1];
     my_id[0] = hr.id0;
@@ -582,7 +834,7 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
     const int hdr_count = __builtin_amdgcn_readfirstlane(hdr_count_v);
     const int hdr_sorted = __builtin_amdgcn_readfirstlane(hdr_sorted_v);
     const int count = min(max(hdr_count, 0), GI2D_FAST_C), sorted = min(max(hdr_sorted, 0), count);
-    if (count <= 64) {
+    if (count <= 64 && !any_in) {
         // A row of at most 64 candidates -- every tile of a 2040x1356 image at 50 000 gaussians, every tile of a fit's
         // first 45 000 iterations (5 000 ... 14 000 large gaussians: ~24 per tile) -- is ONE wave's work: membership,
         // ranks (ballot / compare loop over the wave's own LDS copy), row write-back and staging need nothing from the
@@ -623,10 +875,10 @@ __device__ __forceinline__ int tile_list_head(int *ids, int *grp, int tile, int 
         return grp[0];
     }
     if (count <= 256)  // workgroup-uniform
-        return tile_list_head_rows<OPTIMISTIC, 1>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put, hr.id0,
-                                                  hdr_count, hdr_sorted, count, sorted);
-    return tile_list_head_rows<OPTIMISTIC, GI2D_FAST_EPT>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put,
-                                                          hr.id0, hdr_count, hdr_sorted, count, sorted);
+        return tile_list_head_rows<OPTIMISTIC, 1, INBOX>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put, hr.id0,
+                                                  hdr_count, hdr_sorted, count, sorted, hr.inbox_w, inbox);
+    return tile_list_head_rows<OPTIMISTIC, GI2D_FAST_EPT, INBOX>(ids, grp, tile, tx, ty, recs, row, tile_bins, status, prep, put,
+                                                          hr.id0, hdr_count, hdr_sorted, count, sorted, hr.inbox_w, inbox);
 }
 
 // ------------------------------------------------------------------------------- tile order
@@ -720,9 +972,14 @@ __device__ __forceinline__ void compute_tile_order(const int2 *__restrict__ tile
 // tile id up to GI2D_BIG_TILES_F tiles; beyond, lane l of the wave adds the box's tiles l, l + 64, ... and the 64 sums meet
 // in a fixed butterfly.
 static_assert(GI2D_FAST_S == GI2D_BIG_TILES_F, "gaussian-major rows up to the size where the order of the sum changes");
+static_assert(GI2D_REDUCE_BATCH >= 8 && GI2D_TILE_LIST_CAP == 256, "reduce_one reads the ranks of a box of <= 8 tiles in its first trip, eight bits each");
+// `src` (optional): the ranks the tile pass left in the spare word of the rows (store_partial_row), for a box of at most
+// eight tiles -- what the gaussian needs to enter a neighbouring tile through its inbox (InboxSrc).
 __device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_rows, const float4 *__restrict__ partial_g,
-                                           const float4 *__restrict__ partial_big, float (&acc)[11]) {
+                                           const float4 *__restrict__ partial_big, float (&acc)[11],
+                                           InboxSrc *src = nullptr) {
     const int lane = threadIdx.x & 63;
+    if (src) src->clear();
 #pragma unroll
     for (int q = 0; q < 11; ++q) acc[q] = 0.f;
     int mnx, mny, mxx, mxy;
@@ -745,6 +1002,11 @@ __device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_r
 #pragma unroll
             for (int q = 0; q < GI2D_REDUCE_BATCH; ++q)
                 if (k0 + q < ntiles) add_partial_row(acc, r[q][0], r[q][1], r[q][2]);
+            if (src && k0 == 0) {  // (the first eight tiles' tags; whoever uses them looks at boxes of <= 8 tiles only)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < ntiles) src->set(q, (unsigned)__float_as_int(r[q][2].w));
+            }
         }
     }
     // a run that does not lie inside the pool was never written (partial_row): the overflow status is up

@@ -120,13 +120,14 @@ static_assert(offsetof(FusedLdsSmall, slot) >= offsetof(FusedLdsSmall, part) &&
 // MODE 1: `vsrc` is the target image gt[H,W,3]; the pixel gradient is that of mean((clamp(out,0,1) - gt)^2):
 //         grad_scale * (clamp(out) - gt) where the clamp passes gradient (models/gaussianimage_cholesky.py:307-310
 //         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
-template <int MODE, int CAP = GI2D_TILE_LIST_CAP, int FWD_UNROLL = GI2D_FWD_UNROLL>
+// INBOX: see tile_list_head.
+template <int MODE, int CAP = GI2D_TILE_LIST_CAP, int FWD_UNROLL = GI2D_FWD_UNROLL, bool INBOX = false>
 __device__ __forceinline__ void fused_tile(
     FusedLdsT<CAP> &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
     int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
     float4 *__restrict__ partial_g, float4 *__restrict__ partial_big, int32_t *__restrict__ status,
     float *__restrict__ out_img, const float *__restrict__ vsrc, float grad_scale, float *__restrict__ tile_sse,
-    const HeadRow &head_row) {
+    const HeadRow head_row, const Inbox &ib) {
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int pool_rows = tiles_x * tiles_y * GI2D_TILE_LIST_CAP;  // rows of `partial_big`, the row pool (PrevBox)
     static_assert(CAP <= GI2D_TILE_LIST_CAP, "at most the reference's 256 entries of a tile are rasterized");
@@ -159,7 +160,7 @@ __device__ __forceinline__ void fused_tile(
         unsigned cull;
         int slot;
     };
-    const int L = tile_list_head<true>(
+    const int L = tile_list_head<true, INBOX>(
         sm.ids, sm.grp, tile, tx, ty, recs, lists, tile_bins, status,
         [&](int g, const BinRec &br) {
             const GaussRec &r = br.r;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void fused_tile(
                 row[1] = z;
                 row[2] = z;
             }
-        }, &head_row);
+        }, ib, head_row);
     GI2D_TRACE(2);
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 1 /* development aid: instruction / time budget of the phases */
     if (L >= 0) return;

@@ -323,7 +323,7 @@ static_assert(GI2D_BWD_ITEMS == 256, "an item's row in the hand-off buffer is it
 #endif
 
 template <int PSTR>
-__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR]);
+__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR], int tag);
 
 // Pixel gradients in LDS: one 32-byte record per (row pair p, column c) at pix[2 * (16 p + c)]:
 //   (vox_A, vox_B, voy_A, voy_B) (voz_A, voz_B, fidx_A, fidx_B)        A = row 2p, B = row 2p + 1
@@ -713,17 +713,24 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                 acc[8] += d2.x;
                 if (PSTR > 9) acc[PSTR - 2] += d2.y, acc[PSTR - 1] += d2.z;
             }
-            store_partial_row<PSTR>(dst, acc);
+#ifdef GI2D_DEV_NO_TAG
+            store_partial_row<PSTR>(dst, acc, 0);
+#else
+            store_partial_row<PSTR>(dst, acc, tid + 1);
+#endif
         }
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);
 }
 
+// `tag`: the entry's rank in its tile's staged list, plus one -- the spare word of the row hands it to the gaussian's
+// lane of the update kernel, which needs it to enter a neighbouring tile through that tile's inbox
+// (gi2d_fast_internal.h::Inbox); rows written as zeros elsewhere carry 0 = no rank.
 template <int PSTR>
-__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR]) {
+__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR], int tag) {
     dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    dst[2] = make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, 0.f);
+    dst[2] = make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, __int_as_float(tag));
 }
 
 __device__ __forceinline__ void add_partial_row(float acc[11], const float4 &p0, const float4 &p1, const float4 &p2);

@@ -328,7 +328,8 @@ __device__ __forceinline__ bool best_decision(const BestSnap &best, const SseLoa
 // Gradient reduce + projection backward + activation backward + optimizer update (+ next iteration's activation,
 // projection and binning step) of one image's gaussians: workgroup `block` of the image's launch share, or its extra
 // workgroup (`order_block`) that computes the next iteration's tile order (gi2d_fast_internal.h).
-template <int KIND, bool FILL_NEXT, bool ADAN>
+// INBOX: entered tiles take the gaussian through their inbox where that is possible (the single-image kernel).
+template <int KIND, bool FILL_NEXT, bool ADAN, bool INBOX = false>
 __device__ __forceinline__ void train_reduce_update_body(int block, bool order_block, const UpdateArgs &u,
                                                          const AdamStep &a_xyz, const AdamStep &a_chol,
                                                          const AdamStep &a_feat, int step) {
@@ -374,7 +375,11 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     const SseLoads sse_first = best_sse_loads(best);
     const bool snapshot = best_decision(best, sse_first, n, g);
     float acc[11];
-    reduce_one(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big, acc);
+    // (FILL_NEXT: with the sums come the ranks the tile pass staged this gaussian at -- what it needs to enter a
+    // neighbouring tile through that tile's inbox instead of waiting for an atomic's answer: gi2d_fast_internal.h::Inbox)
+    InboxFill inbox;
+    reduce_one(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big, acc,
+               FILL_NEXT && INBOX ? &inbox.src : nullptr);
     if (g >= n) return;
     float2 mean;
     float par[3];
@@ -451,6 +456,12 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         // deterministic, and worth nothing in time.)
         begin_binning(g, next.status);
         const BinRecs recs = recs_for_binning(next.recs, g == 0);
+        if constexpr (INBOX) {
+            inbox.ib.recs = next.inbox;
+            // (not on a large image; boxes of at most eight tiles: the ranks reduce_one kept)
+            const int old_w = (int)((unsigned)pbox.x >> 16) - (pbox.x & 0xffff), old_h = (int)((unsigned)pbox.y >> 16) - (pbox.y & 0xffff);
+            inbox.src.on = tiles_x * tiles_y <= GI2D_INBOX_MAX_TILES && old_w > 0 && old_h > 0 && old_w * old_h <= 8;
+        }
         // From the rows just computed, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
         // activation / projection arithmetic in THIS kernel only, and a stretch of iterations issued as one call
@@ -465,24 +476,27 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box).
         // Order of the tail: the binning step's returning atomics (gaussians that entered a tile), then every other
         // store of the lane, then the list stores that need the atomics' results.
-        bin_projected(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, pbox,
-                      next.prev_box, next.lists, recs, [&] {
-                          xys[g] = o.xy;
-                          radii[g] = o.radius;
-                          store_row3(conics, g, o.k0, o.k1, o.k2);
-                          next.num_tiles_hit[g] = o.tiles_hit;
-                          store_rest();
-                      });
+        bin_projected<INBOX>(g, o, opac_next, new_feat.a, new_feat.b, new_feat.c, tiles_x, tiles_y, radius_clip, pbox,
+                            next.prev_box, next.lists, recs, [&] {
+                                xys[g] = o.xy;
+                                radii[g] = o.radius;
+                                store_row3(conics, g, o.k0, o.k1, o.k2);
+                                next.num_tiles_hit[g] = o.tiles_hit;
+                                store_rest();
+                            }, &inbox);
     } else {
         store_rest();
     }
 }
 
+#ifndef GI2D_INBOX_SINGLE
+#define GI2D_INBOX_SINGLE 1 /* development aid: 0 = the header's returning atomics everywhere */
+#endif
 template <int KIND, bool FILL_NEXT, bool ADAN>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(UpdateArgs u, AdamStep a_xyz, AdamStep a_chol,
                                                                   AdamStep a_feat, int step) {
-    train_reduce_update_body<KIND, FILL_NEXT, ADAN>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz, a_chol,
-                                                    a_feat, step);
+    train_reduce_update_body<KIND, FILL_NEXT, ADAN, FILL_NEXT && GI2D_INBOX_SINGLE>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz,
+                                                               a_chol, a_feat, step);
 }
 // K images in one launch (gi2d_batch.h): image k owns workgroups [pg_start[k], pg_start[k + 1]), the last of them its
 // tile-ordering workgroup.  All images are at the same optimizer step with the same learning rates.
@@ -1344,6 +1358,7 @@ static UpdateArgs update_args_of(const gi2d_train_state *s, const FastWs &w, int
     u.next.clip_coe = s->clip_coe;
     u.next.num_tiles_hit = s->num_tiles_hit;
     u.next.lists = w.lists;
+    u.next.inbox = w.inbox_recs;
     u.next.prev_box = w.prev_box;
     u.next.recs = rec_sets(w, n);
     u.next.status = s->status;

@@ -73,6 +73,45 @@ def test_batched_iterations_equal_single_image_calls(kind, optimizer, sizes):
         assert int(a.best_info[1]) > 0  # a snapshot was taken: the decision logic ran
 
 
+def test_a_fit_that_changes_between_single_image_and_batched_calls_equals_the_fit_alone():
+    """The update kernel of ONE image lets a gaussian enter a tile through the tile's inbox (csrc/gi2d_fast_internal.h::
+    Inbox), and only the tile pass issued right behind it, in the same call, is built to take entrants out of one; the
+    kernels of a batch append through the row headers.  The two must leave the same rows -- 2 iterations alone, 3 in a
+    batch, 4 alone == 9 alone, bit for bit (lr 0.01: gaussians enter tiles on every step) -- and every call must return
+    with all inboxes empty (its last update kernel does not bin: whoever comes next finds nothing waiting)."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    sizes = [(256, 384, 15000), (384, 256, 14000)]
+    alone, mixed = _fitters("cholesky", "adam", sizes), _fitters("cholesky", "adam", sizes)
+    for f in alone:
+        f.train(9)
+    for f in mixed:
+        f.train(2)
+        assert _inbox_bits(f) == 0
+    BatchFitter(mixed).train(3)
+    for f in mixed:
+        assert _inbox_bits(f) == 0
+        f.train(4)
+        assert _inbox_bits(f) == 0
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(alone, mixed)):
+        a.check_status(), b.check_status()
+        _assert_same(a, b, f"alone / batched / alone, image {i}")
+
+
+def _inbox_bits(fit) -> int:
+    """Entrants waiting in the inboxes of a fitter's workspace: the set bits of the 64 bitmap words behind each tile
+    row's 16 header words and 1024 ids (csrc/gi2d_fast_internal.h: GI2D_FAST_HDR, GI2D_FAST_C, GI2D_INBOX_WORDS)."""
+    gp, bp = C.c_void_p(), C.c_void_p()
+    from gaussianimage_plus_amd import _lib
+    _lib.call("gi2d_fast_workspace_views", fit.ws.data_ptr(), fit.ws.numel(), fit.cap, fit.tx, fit.ty, C.byref(gp),
+              C.byref(bp))
+    torch.cuda.synchronize()
+    off, tiles, lrow = gp.value - fit.ws.data_ptr(), fit.tx * fit.ty, 16 + 1024 + 64
+    rows = fit.ws[off:off + 4 * tiles * lrow].view(torch.int32).view(tiles, lrow)
+    words = rows[:, 16 + 1024:].cpu().numpy().view(np.uint32)
+    return int(np.unpackbits(words.view(np.uint8)).sum())
+
+
 @pytest.mark.parametrize("k", [8, 11])
 def test_xcd_mapped_batch_equals_single_image_calls(k):
     """Eight or more images with the same tile count: image i's tiles go to the workgroups b with b % 8 == i % 8 (one

@@ -483,7 +483,7 @@ def test_slowly_growing_gaussians_do_not_leak_the_row_pool():
         fused.check_status()
         nth = fused.nth[:n_big]
         peak_live = max(peak_live, int(nth[nth > 32].sum()))
-    cursor = int(fused.ws[:64].view(torch.int32)[8].item())   # GI2D_POOL_CURSOR: rows handed out since the last init
+    cursor = int(fused.tile_lists()[0][8].item())   # GI2D_POOL_CURSOR (a word of tile row 0's header): rows handed out since the last init
     pool_rows = fused.T * 256
     assert int((fused.nth[:n_big] > 32).sum()) >= 20 and peak_live > 3000, "the scene must exercise the pool"
     print(f"row pool: {cursor} rows handed out over {steps} steps for {peak_live} live rows (pool {pool_rows})")
