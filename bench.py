@@ -202,7 +202,7 @@ def run_rank(args):
         # pass in two launches -- the small form, then the general one on the tiles it passed over (csrc/gi2d_fast.hip):
         # the events bracket both, the stored counters are summed over both
         # (which of the two the timed calls took: gi2d_batch_tile_pass_form on the fitter's workspace -- two launches
-        # while no row is fuller than the small form's 128 candidates)
+        # while at most one row in sixteen is fuller than the small form's 128 candidates)
         two = bool(_lib.load().gi2d_batch_tile_pass_form(fit.ws.data_ptr()))
         kernel = "gi2d::fast_fwdbwd_kernel<1, 1> + gi2d::fast_fwdbwd_kernel<1, 2>" if two else \
             "gi2d::fast_fwdbwd_kernel<1, 0>"

@@ -356,7 +356,7 @@ __device__ __forceinline__ void batched_slot_of_lane(int b, const int *__restric
 // PHASE as in fast_fwdbwd_kernel.  Measured at K = 8 / 24 of 768x512 images: the small form is 5 ... 8 % faster per
 // tile it serves, but a scene whose fuller tiles sit above GI2D_SMALL_CAP (9 % of the tiles of tools/batch_time.py's
 // scenes, half of a trained Kodak scene's) hands those to a second launch at lower occupancy (net -6 % at K = 24), so
-// the two-phase form is used on a batch only while no row of it is that full -- batch_pass_begin.
+// the two-phase form is used on a batch only while few rows of it are that full (GI2D_TWO_PHASE_BIG_DIV) -- batch_pass_begin.
 template <int MODE, int PHASE>
 __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_batched_kernel(
     const BatchImage *__restrict__ imgs, const BatchHead *__restrict__ head, int k_images, int uniform_tiles,
@@ -652,8 +652,14 @@ static void hint_poll(PassHint &h) {
 #define GI2D_BATCH_TWO_PHASE_MIN (8 * GI2D_TWO_PHASE_TILES) /* measured: eight 768x512 images -6 %; one image per
                                                                launch on three streams +40 % in time (a Kodak shard
                                                                of three images 1.10 -> 0.78 images/s) */
+// Two launches while at most one tile in GI2D_TWO_PHASE_BIG_DIV was too full for the small form in the last pass that
+// reported.  Measured on the Kodak leg (24 images, 50 000 iterations, three batches of eight): 1.376 / 1.396 images/s
+// with "none at all" (round 4's rule), 1.408-1.413 with 1/64, 1/16 and 1/6 alike -- a fit spends a stretch of its
+// schedule with a handful of crowded tiles per image; tools/batch_time.py's scenes (9 % of the tiles too full) lose 6 %
+// in two launches, hence not more than 1/16.
+#define GI2D_TWO_PHASE_BIG_DIV 16
 static bool hint_says_two_phase(const PassHint &h, long long total, long long min_total) {
-    return h.last == 0 && total >= min_total;
+    return h.last >= 0 && (long long)h.last * GI2D_TWO_PHASE_BIG_DIV <= total && total >= min_total;
 }
 static bool pass_form_begin(const void *key, long long total, long long min_total, hipStream_t st) {
     const int forced = pass_form_override();

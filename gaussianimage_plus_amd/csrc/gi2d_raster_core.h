@@ -713,11 +713,7 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                 acc[8] += d2.x;
                 if (PSTR > 9) acc[PSTR - 2] += d2.y, acc[PSTR - 1] += d2.z;
             }
-#ifdef GI2D_DEV_NO_TAG
-            store_partial_row<PSTR>(dst, acc, 0);
-#else
             store_partial_row<PSTR>(dst, acc, tid + 1);
-#endif
         }
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);

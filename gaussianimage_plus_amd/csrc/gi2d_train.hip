@@ -489,13 +489,10 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     }
 }
 
-#ifndef GI2D_INBOX_SINGLE
-#define GI2D_INBOX_SINGLE 1 /* development aid: 0 = the header's returning atomics everywhere */
-#endif
 template <int KIND, bool FILL_NEXT, bool ADAN>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(UpdateArgs u, AdamStep a_xyz, AdamStep a_chol,
                                                                   AdamStep a_feat, int step) {
-    train_reduce_update_body<KIND, FILL_NEXT, ADAN, FILL_NEXT && GI2D_INBOX_SINGLE>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz,
+    train_reduce_update_body<KIND, FILL_NEXT, ADAN, FILL_NEXT>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz,
                                                                a_chol, a_feat, step);
 }
 // K images in one launch (gi2d_batch.h): image k owns workgroups [pg_start[k], pg_start[k + 1]), the last of them its
@@ -1523,8 +1520,8 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         set_error("train steps: unknown optimizer, or Adan without its extra state (d_*, pg_*)");
         return GI2D_ERR_INVALID_ARGUMENT;
     }
-    // a large image's tile passes run as two launches while the previous call on this workspace saw no row above the
-    // small form's capacity (gi2d_fast.hip: pass_form_begin)
+    // a large image's tile passes run as two launches while the previous call on this workspace saw at most one row in
+    // sixteen above the small form's capacity (gi2d_fast.hip: pass_form_begin)
     const long long tiles = (long long)tx * ty;
     const int form = single_pass_begin(s->workspace, tiles, st) ? 1 : 0;
     if (s->quant) {

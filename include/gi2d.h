@@ -324,8 +324,9 @@ size_t gi2d_batch_bytes(int num_images);
 /* The tile pass of a batch takes one of two forms, with the same results bit for bit: one launch of the general
  * workgroup (256 staged candidates per tile; six workgroups per CU), or two launches -- a small workgroup (128 staged
  * candidates, eight per CU) on every tile it can serve and the general one on the rest -- which is 5 ... 10 % faster
- * while NO tile is that full and slower otherwise (the second launch is as long as one tile's whole dependent chain as
- * soon as it has one tile to serve).  The library picks per call from what the PREVIOUS call on the same table reported
+ * while few tiles are that full (at most one in sixteen: the second launch runs at lower occupancy and is as long as
+ * one tile's whole dependent chain as soon as it has a tile to serve) and slower otherwise.  The library picks per call
+ * from what the PREVIOUS call on the same table reported
  * (the number of fuller tiles travels to pinned memory behind that call's kernels: no call ever waits for it); the
  * first call on a table, a call inside a stream capture and a batch of fewer than 12288 tiles (eight 768x512 images) take
  * the general form.  gi2d_train_steps does the same for a single image of more than 1536 tiles, keyed by its workspace.

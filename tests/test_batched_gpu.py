@@ -385,12 +385,21 @@ def _crowd(fitters, count=600):
         f._xyz[:count] = torch.from_numpy(np.arctanh(u).astype(np.float32)).to(DEV)
 
 
+def _swell(fitters, count=160):
+    """Make the first `count` gaussians of every given fitter cover the whole image: every tile's row then holds more
+    candidates than the small form stages."""
+    for f in fitters:
+        f._chol[:count] = torch.tensor([300.0, 0.0, 300.0], device=DEV)
+
+
 def test_batched_tile_pass_forms_give_the_same_bits_and_follow_the_reported_row_sizes():
     """gi2d_batch_tile_pass_form (include/gi2d.h): the first call on a table runs the general form; its report -- the
-    number of tiles with more than 128 candidates -- decides the next call's.  Eight 768x512 images with short rows take
-    the two-launch form from the second call on.  Then 600 gaussians of one image move into one tile BETWEEN two calls:
-    the next call still runs as two launches (its answer is one call old) and its second launch has real work; the
-    call after that is back to one launch.  Every image's state equals the single-image calls' bit for bit throughout."""
+    number of tiles with more than 128 candidates -- decides the next call's: two launches while at most one tile in
+    sixteen is that full.  Eight 768x512 images with short rows take the two-launch form from the second call on.  Then
+    600 gaussians of one image move into one tile BETWEEN two calls: the second launch has real work from then on, and
+    the form stays (one crowded tile in 12 288).  Then 160 gaussians of that image grow to cover all its 1 536 tiles: the
+    next call still runs as two launches (its answer is one call old), the call after that is back to one launch.
+    Every image's state equals the single-image calls' bit for bit throughout."""
     from gaussianimage_plus_amd import _lib
     from gaussianimage_plus_amd.trainer import BatchFitter
     lib = _lib.load()
@@ -415,9 +424,14 @@ def test_batched_tile_pass_forms_give_the_same_bits_and_follow_the_reported_row_
     assert [run(2), run(3)] == [1, 1]  # i.e. the call of 3 iterations ran as two launches
     same("two launches, nothing for the second")
     _crowd([alone[0], together[0]])
-    assert run(2) == 0  # ran as two launches (decided from the report before), reports a fuller tile
+    assert run(2) == 1  # ran as two launches (decided from the report before), reports ONE fuller tile: the form stays
     same("two launches, a crowded tile for the second")
     assert int(together[0].status[3]) >= 512, "the crowded tile is what the second launch was for"
+    assert run(2) == 1
+    same("two launches again")
+    _swell([alone[0], together[0]])
+    assert run(2) == 0  # ran as two launches, an eighth of the batch's tiles for the second: the next call takes one
+    same("two launches, a whole image for the second")
     assert run(2) == 0
     same("one launch")
 

@@ -383,7 +383,8 @@ def test_large_image_fit_switches_to_two_launches_and_equals_a_single_call():
     """A single image of more than one residency round of tiles (1040x1040: 4225) fitted by gi2d_train_steps: the first
     call on its workspace runs the tile pass as one launch, reports no tile above the small form's capacity, and later
     calls run it as two launches (include/gi2d.h: gi2d_batch_tile_pass_form, keyed by the workspace) -- the state equals
-    the same iterations issued as ONE call (all general form) bit for bit.  Once a tile is crowded the form goes back."""
+    the same iterations issued as ONE call (all general form) bit for bit.  One crowded tile does not change the form
+    (two launches while at most one tile in sixteen is too full for the small one); a tenth of the tiles does."""
     import ctypes as C
     from gaussianimage_plus_amd import _lib
     from gaussianimage_plus_amd.launch import synthetic_image
@@ -413,10 +414,20 @@ def test_large_image_fit_switches_to_two_launches_and_equals_a_single_call():
     a.check_status(), b.check_status()
     for nm in ("_xyz", "_chol", "_feat", "m_xyz", "v_chol", "out_img", "tile_sse"):
         assert torch.equal(getattr(a, nm), getattr(b, nm)), nm
-    # 600 gaussians into one tile: the next call (still two launches) reports it, the one after runs as one launch
+    # 600 gaussians into one tile: the second launch has work, the form stays
     rng = np.random.default_rng(77)
     u = np.stack([(rng.uniform(40, 48, 600) + 0.5) / (0.5 * w) - 1.0, (rng.uniform(40, 48, 600) + 0.5) / (0.5 * h) - 1.0], 1)
     a._xyz[:600] = torch.from_numpy(np.arctanh(u).astype(np.float32)).to(DEV)
     a.train(2)
     torch.cuda.synchronize()
-    assert form(a) == 0 and int(a.status[3]) >= 512
+    a.check_status()
+    assert form(a) == 1 and int(a.status[3]) >= 512
+    # 160 gaussians over the top-left 320 x 320 pixels (400 of the 4 225 tiles get more than 128 candidates): the next
+    # call (still two launches) reports them, the one after runs as one launch
+    v = np.stack([(rng.uniform(150, 170, 160) + 0.5) / (0.5 * w) - 1.0, (rng.uniform(150, 170, 160) + 0.5) / (0.5 * h) - 1.0], 1)
+    a._xyz[600:760] = torch.from_numpy(np.arctanh(v).astype(np.float32)).to(DEV)
+    a._chol[600:760] = torch.tensor([60.0, 0.0, 60.0], device=DEV)
+    a.train(2)
+    torch.cuda.synchronize()
+    a.check_status()
+    assert form(a) == 0
