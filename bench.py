@@ -204,8 +204,10 @@ def run_rank(args):
         # (which of the two the timed calls took: gi2d_batch_tile_pass_form on the fitter's workspace -- two launches
         # while at most one row in sixteen is fuller than the small form's 128 candidates)
         two = bool(_lib.load().gi2d_batch_tile_pass_form(fit.ws.data_ptr()))
-        kernel = "gi2d::fast_fwdbwd_kernel<1, 1> + gi2d::fast_fwdbwd_kernel<1, 2>" if two else \
-            "gi2d::fast_fwdbwd_kernel<1, 0>"
+        # (third template argument: built with the code that takes entrants out of the tiles' inboxes -- every tile
+        # pass of a single-image call but its first; csrc/gi2d_fast_internal.h::Inbox)
+        kernel = "gi2d::fast_fwdbwd_kernel<1, 1, false> + gi2d::fast_fwdbwd_kernel<1, 2, false>" if two else \
+            ("gi2d::fast_fwdbwd_kernel<1, 0, true>" if fit.tx * fit.ty <= 1536 else "gi2d::fast_fwdbwd_kernel<1, 0, false>")
         traffic, traffic_src = pmc_traffic(kernel, n, h, w)
         line = {
             "metric": f"training iters/sec (fwd+bwd rasterize) at N Gaussians, {w}x{h}",

@@ -173,20 +173,22 @@ void write_batch_table(const BatchTable &table, const BatchImage *imgs, int k_im
                        hipStream_t st);
 // gi2d_fast.hip: the batched single-pass tile kernel (MODE 1: L2-loss gradient against t.vsrc = target) over
 // `total_blocks` = head->tile_start[K] workgroups; uniform_tiles > 0: every image has that many tiles.
-// `two_phase`: small form on every tile it can serve, general form on the rest (batch_pass_begin says when).
+// `form` (batch_pass_begin says which): 0 one launch of the general form; 1 / 2 the small form on every tile it can serve,
+// then the general form on the rest -- 2: the last pass that reported found such tiles (the second launch is shaped for work).
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
-                             bool two_phase, hipStream_t st);
-// Bracket of one C-ABI call's batched tile passes on table `batch`: _begin answers "two-phase?" from what the previous
-// call on the same table reported (without waiting for anything), _end queues the read-back of this call's report.
-// (the same bracket for a single image of more than one residency round of tiles, keyed by its workspace; _begin is
-// false for smaller images, which never run as two launches)
-bool single_pass_begin(const void *ws, long long tiles, hipStream_t st);
+                             int form, hipStream_t st);
+// Bracket of one C-ABI call's batched tile passes on table `batch`: _begin answers "which form?" (as above) from what the
+// previous call on the same table reported (without waiting for anything), _end queues the read-back of this call's
+// report.  (The same bracket for a single image of more than one residency round of tiles, keyed by its workspace;
+// _begin is 0 for smaller images, which never run as two launches.)
+int single_pass_begin(const void *ws, long long tiles, hipStream_t st);
 void single_pass_end(const void *ws, const FastWs &w, long long tiles, hipStream_t st);
-// gi2d_fast_rasterize_forward_backward with the form given: 1 two launches, 0 one, -1 the C entry's own rule
+// gi2d_fast_rasterize_forward_backward with the form given: 1 / 2 two launches, 0 one, -1 the C entry's own rule
 int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned img_w, unsigned img_h, const float *background,
                                const float *v_output, const float *target, float grad_scale, float *tile_sse, void *ws,
-                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form);
-bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st);
+                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form,
+                               bool inbox = false);  // inbox: see fast_fwdbwd_kernel
+int batch_pass_begin(const void *batch, int total_blocks, hipStream_t st);
 void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st);
 
 }  // namespace gi2d

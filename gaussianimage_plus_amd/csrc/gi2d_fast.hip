@@ -278,10 +278,21 @@ static_assert(GI2D_INBOX_MAX_TILES <= GI2D_TWO_PHASE_TILES, "the inboxes are for
 // alive across tiles (80 registers and a few dwords of scratch at six per CU -- and a kernel with ANY scratch pays
 // ~200 us per dispatch here while the runtime re-arms the queue's scratch: measured) -- so it is built for four (five still left one of the four kernels with 12 bytes of it)
 #define GI2D_PHASE_OCC(PHASE) ((PHASE) == 1 ? GI2D_SMALL_OCC : (PHASE) == 2 ? 4 : GI2D_FUSED_OCC)
-static inline unsigned phase2_blocks(long long slots) { return (unsigned)((slots + GI2D_PHASE2_STRIP - 1) / GI2D_PHASE2_STRIP); }
+// `busy`: the last pass that reported found tiles for this launch -- a strip of 8 then (eight times the workgroups, each
+// with fewer tiles to handle one after the other: on a Kodak batch the second launch served ~4 tiles per workgroup in
+// turn at 64).  The kernels derive the strip from the grid.
+#define GI2D_PHASE2_STRIP_BUSY 8 /* measured on the Kodak leg: 1.41-1.43 images/s at 64, 1.45 at 16 and 8, 1.44 at 2 */
+static inline unsigned phase2_blocks(long long slots, bool busy = false) {
+    const int strip = busy ? GI2D_PHASE2_STRIP_BUSY : GI2D_PHASE2_STRIP;
+    return (unsigned)((slots + strip - 1) / strip);
+}
+__device__ __forceinline__ int phase2_strip(int slots) { return (slots + (int)gridDim.x - 1) / (int)gridDim.x; }
 
-template <int MODE, int PHASE>
+// INBOX: the launch right behind an update kernel that delivers through the inboxes (gi2d_train_steps, iterations 2 ...
+// of a call on one image of at most GI2D_INBOX_MAX_TILES tiles); every other launch runs the kernel built without.
+template <int MODE, int PHASE, bool INBOX = false>
 __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel(TilePassArgs a) {
+    static_assert(PHASE == 0 || !INBOX, "the small form has no room for the entrants' bookkeeping");
     if (PHASE == 2) {
         // which slots of the strip were passed over: lane i looks at slot i (ONE round of two dependent loads for the
         // whole strip -- slot by slot it was sixteen), a ballot makes the answer scalar
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
         // tiles is dealt to as many workgroups as it has tiles instead of queueing up in one)
         const int tiles = a.tiles_x * a.tiles_y, lane = threadIdx.x & 63;
         const int s0 = (int)blockIdx.x, stride = (int)gridDim.x, mine = s0 + lane * stride;
-        const bool big = lane < GI2D_PHASE2_STRIP && mine < tiles && a.big_tile[a.tile_order[mine]] != 0;
+        const bool big = lane < phase2_strip(tiles) && mine < tiles && a.big_tile[a.tile_order[mine]] != 0;
         unsigned long long todo = __ballot(big);
         while (todo) {  // workgroup-uniform: every wave computed the same mask
             const int slot = s0 + __builtin_ctzll(todo) * stride;
@@ -299,8 +310,8 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
         }
     } else {
         // (a large image in the general form marks its fuller tiles too: single_pass_end counts them)
-        tile_pass_workgroup<MODE, PHASE, PHASE == 0>(a, (int)blockIdx.x, blockIdx.x == 0,
-                                                     a.tiles_x * a.tiles_y > GI2D_TWO_PHASE_TILES);
+        tile_pass_workgroup<MODE, PHASE, INBOX>(a, (int)blockIdx.x, blockIdx.x == 0,
+                                                a.tiles_x * a.tiles_y > GI2D_TWO_PHASE_TILES);
     }
 }
 
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_batche
         const int total = uniform_tiles > 0 ? k_images * uniform_tiles : tile_start[k_images], lane = threadIdx.x & 63;
         const int s0 = (int)blockIdx.x, stride = (int)gridDim.x, mine = s0 + lane * stride;  // (strided: see above)
         bool big = false;
-        if (lane < GI2D_PHASE2_STRIP && mine < total) {
+        if (lane < phase2_strip(total) && mine < total) {
             batched_slot_of_lane(mine, tile_start, k_images, uniform_tiles, xcd_map, k, local);
             const TilePassArgs &t = imgs[k].t;
             big = t.big_tile[t.tile_order[local]] != 0;
@@ -578,15 +589,15 @@ static void launch_between(K kernel, dim3 grid, dim3 block, hipStream_t st, hipE
         hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
 }
 int launch_tile_pass_batched(int mode, const BatchTable &b, int k_images, int total_blocks, int uniform_tiles,
-                             bool two_phase, hipStream_t st) {
+                             int form, hipStream_t st) {
     if (total_blocks <= 0) return GI2D_OK;
     int xcd_map = 0;  // images placed on the XCDs whole (see the kernel): a multiple of 8
     if (uniform_tiles > 0) xcd_map = k_images & ~7;
     const dim3 grid((unsigned)total_blocks), block(256);
     const BatchImage *imgs = (const BatchImage *)b.img;
-    if (two_phase) {
+    if (form != 0) {
         KernelTimer *tm = next_timer();
-        const dim3 grid2(phase2_blocks(total_blocks));
+        const dim3 grid2(phase2_blocks(total_blocks, form == 2));
         if (mode == 0) {
             launch_between((fast_fwdbwd_batched_kernel<0, 1>), grid, block, st, tm ? tm->begin : nullptr, nullptr, imgs,
                            b.head, k_images, uniform_tiles, xcd_map);
@@ -656,15 +667,18 @@ static void hint_poll(PassHint &h) {
 // reported.  Measured on the Kodak leg (24 images, 50 000 iterations, three batches of eight): 1.376 / 1.396 images/s
 // with "none at all" (round 4's rule), 1.408-1.413 with 1/64, 1/16 and 1/6 alike -- a fit spends a stretch of its
 // schedule with a handful of crowded tiles per image; tools/batch_time.py's scenes (9 % of the tiles too full) lose 6 %
-// in two launches, hence not more than 1/16.
+// in two launches with round 4's second launch, hence not more than 1/16 then; with the second launch shaped for work
+// (GI2D_PHASE2_STRIP_BUSY) 1/8 and 1/4 measure the same as 1/16 on both, 1/2 loses 1 % on the Kodak leg.
 #define GI2D_TWO_PHASE_BIG_DIV 16
-static bool hint_says_two_phase(const PassHint &h, long long total, long long min_total) {
-    return h.last >= 0 && (long long)h.last * GI2D_TWO_PHASE_BIG_DIV <= total && total >= min_total;
+// 0: one launch; 1: two launches, nothing expected for the second; 2: two launches, fuller tiles expected
+static int hint_says_two_phase(const PassHint &h, long long total, long long min_total) {
+    if (!(h.last >= 0 && (long long)h.last * GI2D_TWO_PHASE_BIG_DIV <= total && total >= min_total)) return 0;
+    return h.last > 0 ? 2 : 1;
 }
-static bool pass_form_begin(const void *key, long long total, long long min_total, hipStream_t st) {
+static int pass_form_begin(const void *key, long long total, long long min_total, hipStream_t st) {
     const int forced = pass_form_override();
-    if (forced >= 0) return forced == 1 && total >= 1;
-    if (total < min_total || stream_is_capturing(st)) return false;  // a captured call takes the form that is never slow
+    if (forced >= 0) return forced == 1 && total >= 1 ? 1 : 0;
+    if (total < min_total || stream_is_capturing(st)) return 0;  // a captured call takes the form that is never slow
     std::lock_guard<std::mutex> lock(g_hint_mu);
     PassHint &h = g_hints[key];
     hint_poll(h);
@@ -707,7 +721,7 @@ static bool hint_wanted(long long total, long long min_total, hipStream_t st) {
     return pass_form_override() < 0 && total >= min_total && !stream_is_capturing(st);
 }
 
-bool batch_pass_begin(const void *batch, int total_blocks, hipStream_t st) {
+int batch_pass_begin(const void *batch, int total_blocks, hipStream_t st) {
     return pass_form_begin(batch, total_blocks, GI2D_BATCH_TWO_PHASE_MIN, st);
 }
 void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st) {
@@ -720,7 +734,7 @@ void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int to
 // A single image of more than GI2D_TWO_PHASE_TILES tiles, fitted by gi2d_train_steps: key = its workspace, the count
 // lives in a spare word next to the record-set counters.
 #define GI2D_WS_BIG_COUNT 16 /* word of FastWs::ver */
-bool single_pass_begin(const void *ws, long long tiles, hipStream_t st) {
+int single_pass_begin(const void *ws, long long tiles, hipStream_t st) {
     return pass_form_begin(ws, tiles, GI2D_TWO_PHASE_TILES + 1, st);
 }
 void single_pass_end(const void *ws, const FastWs &w, long long tiles, hipStream_t st) {
@@ -911,7 +925,7 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
                                          float grad_scale, float *tile_sse, void *ws, size_t ws_bytes,
                                          int32_t *status, float *out_img, gi2d_stream_t st) {
     return gi2d::fast_forward_backward_form(n, tiles_x, tiles_y, w_, h, background, v_output, target, grad_scale, tile_sse,
-                                            ws, ws_bytes, status, out_img, st, -1);
+                                            ws, ws_bytes, status, out_img, st, -1, false);
 }
 }  // extern "C"
 
@@ -921,7 +935,7 @@ namespace gi2d {
 // when some tile is fuller than the small form; gi2d_train_steps asks single_pass_begin instead)
 int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *background,
                                const float *v_output, const float *target, float grad_scale, float *tile_sse, void *ws,
-                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form) {
+                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form, bool inbox) {
     int rc = check_ws("fast rasterize forward+backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     const long long t = (long long)tiles_x * tiles_y;
@@ -940,19 +954,22 @@ int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, uns
                                     v_output ? nullptr : tile_sse);
     const dim3 grid((unsigned)t), block(256);
     if (form < 0) form = pass_form_override() >= 0 ? pass_form_override() : 1;
-    if (two_phase_tile_pass(t) && form == 1) {
+    if (two_phase_tile_pass(t) && form >= 1) {
         KernelTimer *tm = next_timer();
+        const dim3 grid2(phase2_blocks(t, form == 2));
         if (v_output) {
             launch_between(fast_fwdbwd_kernel<0, 1>, grid, block, (hipStream_t)st, tm ? tm->begin : nullptr, nullptr, a);
-            launch_between(fast_fwdbwd_kernel<0, 2>, dim3(phase2_blocks(t)), block, (hipStream_t)st, nullptr,
+            launch_between(fast_fwdbwd_kernel<0, 2>, grid2, block, (hipStream_t)st, nullptr,
                            tm ? tm->end : nullptr, a);
         } else {
             launch_between(fast_fwdbwd_kernel<1, 1>, grid, block, (hipStream_t)st, tm ? tm->begin : nullptr, nullptr, a);
-            launch_between(fast_fwdbwd_kernel<1, 2>, dim3(phase2_blocks(t)), block, (hipStream_t)st, nullptr,
+            launch_between(fast_fwdbwd_kernel<1, 2>, grid2, block, (hipStream_t)st, nullptr,
                            tm ? tm->end : nullptr, a);
         }
     } else if (v_output) {
         GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<0, 0>), grid, block, (hipStream_t)st, a);
+    } else if (inbox && t <= GI2D_INBOX_MAX_TILES) {
+        GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<1, 0, true>), grid, block, (hipStream_t)st, a);
     } else {
         GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<1, 0>), grid, block, (hipStream_t)st, a);
     }
@@ -971,7 +988,7 @@ int gi2d_batch_tile_pass_form(const void *batch) {
     const auto it = g_hints.find(batch);
     if (it == g_hints.end()) return 0;
     hint_poll(it->second);
-    return hint_says_two_phase(it->second, it->second.total, it->second.min_total) ? 1 : 0;
+    return hint_says_two_phase(it->second, it->second.total, it->second.min_total) != 0 ? 1 : 0;
 }
 
 int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast_image *images, void *batch,
@@ -1020,7 +1037,7 @@ int gi2d_fast_rasterize_forward_backward_batched(int num_images, const gi2d_fast
     head.tile_start[num_images] = blocks;
     BatchTable b = carve_batch(batch, num_images);
     write_batch_table(b, host_imgs.data(), num_images, head, (hipStream_t)st);
-    const bool two_phase = batch_pass_begin(batch, blocks, (hipStream_t)st);
+    const int two_phase = batch_pass_begin(batch, blocks, (hipStream_t)st);
     const int rc = launch_tile_pass_batched(given ? 0 : 1, b, num_images, blocks, uniform ? tiles0 : 0, two_phase,
                                             (hipStream_t)st);
     batch_pass_end(batch, b, num_images, blocks, (hipStream_t)st);

@@ -458,9 +458,9 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         const BinRecs recs = recs_for_binning(next.recs, g == 0);
         if constexpr (INBOX) {
             inbox.ib.recs = next.inbox;
-            // (not on a large image; boxes of at most eight tiles: the ranks reduce_one kept)
+            // (boxes of at most eight tiles: the ranks reduce_one kept)
             const int old_w = (int)((unsigned)pbox.x >> 16) - (pbox.x & 0xffff), old_h = (int)((unsigned)pbox.y >> 16) - (pbox.y & 0xffff);
-            inbox.src.on = tiles_x * tiles_y <= GI2D_INBOX_MAX_TILES && old_w > 0 && old_h > 0 && old_w * old_h <= 8;
+            inbox.src.on = old_w > 0 && old_h > 0 && old_w * old_h <= 8;
         }
         // From the rows just computed, still in registers (no store -> load round trip).  The empty asm makes them
         // opaque values, as if loaded: otherwise the compiler fuses the optimizer's last multiply-add into the
@@ -489,11 +489,15 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     }
 }
 
-template <int KIND, bool FILL_NEXT, bool ADAN>
+// INBOX: an image of at most GI2D_INBOX_MAX_TILES tiles with another iteration to follow (the launch code picks: a
+// kernel of its own, not a run-time switch -- with the switch the box-changing lanes of a large image walked their
+// tiles twice, +0.6 us at 2040x1356)
+template <int KIND, bool FILL_NEXT, bool ADAN, bool INBOX = false>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(UpdateArgs u, AdamStep a_xyz, AdamStep a_chol,
                                                                   AdamStep a_feat, int step) {
-    train_reduce_update_body<KIND, FILL_NEXT, ADAN, FILL_NEXT>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz,
-                                                               a_chol, a_feat, step);
+    static_assert(FILL_NEXT || !INBOX, "only a binning update kernel has entrants to deliver");
+    train_reduce_update_body<KIND, FILL_NEXT, ADAN, INBOX>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz, a_chol,
+                                                           a_feat, step);
 }
 // K images in one launch (gi2d_batch.h): image k owns workgroups [pg_start[k], pg_start[k + 1]), the last of them its
 // tile-ordering workgroup.  All images are at the same optimizer step with the same learning rates.
@@ -1523,7 +1527,7 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
     // a large image's tile passes run as two launches while the previous call on this workspace saw at most one row in
     // sixteen above the small form's capacity (gi2d_fast.hip: pass_form_begin)
     const long long tiles = (long long)tx * ty;
-    const int form = single_pass_begin(s->workspace, tiles, st) ? 1 : 0;
+    const int form = single_pass_begin(s->workspace, tiles, st);
     if (s->quant) {
         QuantTrain Q;
         rc = quant_of(s, Q);
@@ -1570,15 +1574,25 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
     train_launch_project_fill(s, w, P, tx, ty, st);
     for (int it = 0; it < count; ++it) {
         const int step = first_step + it;
+        // (the inboxes: one image of at most GI2D_INBOX_MAX_TILES tiles, i.e. a tile pass of the general form throughout;
+        // the update kernel delivers through them when another iteration follows, and the tile pass of that iteration --
+        // never the first of a call, which follows the projection kernel -- is the one built to take entrants in)
+        const bool small_image = tiles <= GI2D_INBOX_MAX_TILES;
         rc = fast_forward_backward_form(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr, nullptr,
                                         s->gt, grad_scale, s->tile_sse, s->workspace, s->workspace_bytes, s->status,
-                                        s->out_img, st_, form);
+                                        s->out_img, st_, form, it > 0 && small_image);
         if (rc != GI2D_OK) return rc;
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s->beta3, eps, step, adan_opt);
         const bool more = it + 1 < count;
-#define GI2D_LAUNCH_RU(K, F, A) \
-    hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A>), gg, bb, 0, st, u, a[0], a[1], a[2], step)
+        const bool inbox = more && small_image;
+#define GI2D_LAUNCH_RU(K, F, A)                                                                                      \
+    do {                                                                                                             \
+        if (F && inbox)                                                                                              \
+            hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A, F>), gg, bb, 0, st, u, a[0], a[1], a[2], step);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((train_reduce_update_kernel<K, F, A>), gg, bb, 0, st, u, a[0], a[1], a[2], step);     \
+    } while (0)
         GI2D_DISPATCH_RU(s->kind, more, adan_opt);
 #undef GI2D_LAUNCH_RU
     }
@@ -1690,7 +1704,7 @@ int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *stat
     head.tile_start[num_images] = tile_blocks;
     head.pg_start[num_images] = pg_blocks;
     write_batch_table(b, host_imgs.data(), num_images, head, st);
-    const bool two_phase = batch_pass_begin(batch, tile_blocks, st);
+    const int two_phase = batch_pass_begin(batch, tile_blocks, st);
     const BatchImage *imgs = b.img;
     const int *pg_start = b.head->pg_start;
     const dim3 gg((unsigned)pg_blocks), bb(bs);

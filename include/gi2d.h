@@ -237,7 +237,10 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
  * index work; the same per-pair arithmetic).  Contract:
  *   - workspace: gi2d_fast_workspace_bytes(N, tiles_x, tiles_y) bytes, emptied ONCE with gi2d_fast_workspace_init.
  *     It holds STATE between calls: persistent per-tile id lists, the tile box every gaussian was last binned with,
- *     and one 64-byte record per gaussian (centre, conic, colour, opacity, cull extents, tile box).  A binning call
+ *     and one 64-byte record per gaussian (centre, conic, colour, opacity, cull extents, tile box); for an image of
+ *     at most 1536 tiles also 128 KB of sparsely used address space per tile (192 MiB at 768x512: the tiles' inboxes,
+ *     through which gi2d_train_steps delivers a gaussian that has entered a tile -- DESIGN.md 3.5; no call returns with
+ *     anything left in them).  A binning call
  *     (gi2d_fast_bin, gi2d_fast_project_bin, the ..._project_bin form of the reduce call) appends a gaussian only to
  *     the tiles it has ENTERED since the previous binning call and refreshes its record; the tile pass drops the
  *     entries that left and keeps every list in ascending id order.  Results are those of a from-scratch binning

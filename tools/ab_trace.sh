@@ -4,6 +4,7 @@
 #   gpurun -- 'bash tools/ab_trace.sh base product'          (BATCH=24: tools/batched_bench_scene.py 24 instead)
 cd ${GRAFT_REPO_ROOT:-.}; export TMPDIR=/tmp
 A="--no-cpu-baseline --images 0 --no-batched --no-static --no-dropin --steps ${STEPS:-500}"
+if [ -n "$C4" ]; then A="$A --height 1356 --width 2040"; fi   # C4=1: BASELINE config 4
 mkdir -p gpurun_out/ab_trace
 for name in "$@"; do
   if [ "$name" = product ]; then unset GI2D_LIB GI2D_ALLOW_DEV_BUILD; else export GI2D_LIB=$PWD/build/variants/$name/libgi2d_hip.so GI2D_ALLOW_DEV_BUILD=1; fi
