@@ -671,6 +671,10 @@ __device__ __forceinline__ int tile_list_head_rows(int *ids, int *grp, int tile,
             st_in = prep(ent_id, rin);
             if (ent_at < GI2D_FAST_C) ids[ent_at] = ent_id;
             ent_more = byte & (byte - 1u);
+#ifdef GI2D_INBOX_STATS /* development aid: entrants taken in / of them second and later ones of a lane's byte */
+            atomicAdd(&(row - (size_t)tile * GI2D_FAST_LROW)[5], 1);
+            if (ent_more) atomicAdd(&(row - (size_t)tile * GI2D_FAST_LROW)[6], __popc(ent_more));
+#endif
             int at = ent_at + 1;
             for (unsigned m = ent_more; m; m &= m - 1u, ++at)
                 if (at < GI2D_FAST_C) ids[at] = __float_as_int(inbox[4 * (size_t)(tid * 8 + __ffs((int)m) - 1) + 3].w);

@@ -98,6 +98,44 @@ def test_a_fit_that_changes_between_single_image_and_batched_calls_equals_the_fi
         _assert_same(a, b, f"alone / batched / alone, image {i}")
 
 
+def _wild_fitter():
+    """One 384x256 image whose gaussians use every way into a tile: 4 000 small ones that drift into neighbouring tiles
+    (the inbox), 600 piled into one tile (ranks beyond the 256-entry cap: no rank to go by), 400 large ones on ~25 tiles
+    (boxes of more than eight tiles keep the row header's atomic), and a learning rate that makes some of them jump more
+    than one tile per step (no neighbouring old tile)."""
+    from gaussianimage_plus_amd.launch import synthetic_image
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    h, w, n = 256, 384, 5000
+    rng = np.random.default_rng(321)
+    u = rng.uniform(-0.98, 0.98, (n, 2))
+    u[4000:4600, 0] = (rng.uniform(40, 48, 600) + 0.5) / (0.5 * w) - 1.0
+    u[4000:4600, 1] = (rng.uniform(40, 48, 600) + 0.5) / (0.5 * h) - 1.0
+    L = np.stack([rng.uniform(0.8, 1.6, n), rng.uniform(-0.3, 0.3, n), rng.uniform(0.8, 1.6, n)], 1)
+    L[4600:, 0] = L[4600:, 2] = rng.uniform(10, 14, 400)
+    init = {"xyz": torch.from_numpy(np.arctanh(u).astype(np.float32)), "chol": torch.from_numpy(L.astype(np.float32)),
+            "feat": torch.from_numpy(rng.uniform(0, 0.2, (n, 3)).astype(np.float32)), "bound": torch.tensor([0.5, 0.0, 0.5])}
+    return NativeFitter(synthetic_image(h, w, 75).to(DEV), n, kind="cholesky", lr=0.12, seed=5, init=init)
+
+
+def test_every_way_into_a_tile_gives_the_rows_of_the_plain_appends():
+    """A single-image call delivers entering gaussians through the tiles' inboxes where it can and through the row
+    headers where it cannot (csrc/gi2d_fast_internal.h::Inbox: no neighbouring old tile, no rank, an old box of more than
+    eight tiles), in one and the same update kernel; a batch of ONE image runs the kernels that only know the headers.
+    Same bits after 1 + 2 + 3 + 4 iterations of a scene that takes every way (_wild_fitter; tools/inbox_stats.py on this
+    scene: of ~3 900 entered tiles per step 3 200 go through an inbox -- 750 of them as a second or later entrant of one
+    lane's eight slots -- and 700 through the header, for each of the three reasons)."""
+    from gaussianimage_plus_amd.trainer import BatchFitter
+    alone, one = _wild_fitter(), _wild_fitter()
+    batch = BatchFitter([one])
+    for count in (1, 2, 3, 4):
+        alone.train(count)
+        batch.train(count)
+        assert _inbox_bits(alone) == 0
+    torch.cuda.synchronize()
+    alone.check_status(), one.check_status()
+    _assert_same(alone, one, "inboxes and headers / headers only")
+
+
 def _inbox_bits(fit) -> int:
     """Entrants waiting in the inboxes of a fitter's workspace: the set bits of the 64 bitmap words behind each tile
     row's 16 header words and 1024 ids (csrc/gi2d_fast_internal.h: GI2D_FAST_HDR, GI2D_FAST_C, GI2D_INBOX_WORDS)."""

@@ -14,13 +14,23 @@ from helpers import synth_cholesky, synth_gt  # noqa: E402
 import bench  # noqa: E402
 from gaussianimage_plus_amd import _lib  # noqa: E402
 
-n, h, w = 50000, 512, 768
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-xyz, L, col, op = synth_cholesky(n, h, w, 3047)
-gt = torch.from_numpy(synth_gt(h, w, 1)).cuda()
-fit = bench.make_fitter(gt, xyz, L, col, n, h, w)
+if len(sys.argv) > 2 and sys.argv[2] == "dense":  # the scene of tests/test_batched_gpu.py's BIG case: 39 gaussians per tile, lr 0.01
+    from gaussianimage_plus_amd.launch import synthetic_image  # noqa: E402
+    from gaussianimage_plus_amd.trainer import NativeFitter  # noqa: E402
+    n, h, w = 15000, 256, 384
+    fit = NativeFitter(synthetic_image(h, w, 60).cuda(), n, kind="cholesky", lr=0.01, seed=11)
+elif len(sys.argv) > 2 and sys.argv[2] == "wild":  # tests/test_batched_gpu.py::_wild_fitter: every way into a tile
+    import test_batched_gpu  # noqa: E402
+    fit = test_batched_gpu._wild_fitter()
+    n = fit.n
+else:
+    n, h, w = 50000, 512, 768
+    xyz, L, col, op = synth_cholesky(n, h, w, 3047)
+    gt = torch.from_numpy(synth_gt(h, w, 1)).cuda()
+    fit = bench.make_fitter(gt, xyz, L, col, n, h, w)
 fit.max_call = 1 << 30
-fit.train(50)
+fit.train(2 if n < 50000 else 50)
 torch.cuda.synchronize()
 import ctypes  # noqa: E402
 gp, bp = ctypes.c_void_p(), ctypes.c_void_p()
@@ -40,3 +50,4 @@ print(f"  waves holding such a lane      {d[15] / steps:9.1f}   (of {(n + 63) //
 print(f"  entered tiles via the inbox    {d[9] / steps:9.1f}")
 print(f"  entered tiles via the header   {d[10] / steps:9.1f}   (not a neighbour {d[11] / steps:.1f}, neighbour without rank {d[12] / steps:.1f})")
 print(f"  waves waiting for an atomic    {d[7] / steps:9.1f}")
+print(f"  entrants taken in by the tiles {(d[5] + d[6]) / steps:9.1f}   (second and later ones of a lane's eight slots: {d[6] / steps:.1f})")
