@@ -26,9 +26,7 @@ namespace gi2d {
 #define GI2D_FAST_HDR 16                             /* header words in front of a row's ids */
 #define GI2D_INBOX_WORDS 64                          /* bitmap of the tile's inbox behind its ids (below) */
 #define GI2D_INBOX_SLOTS (32 * GI2D_INBOX_WORDS)     /* 8 neighbour directions x 256 ranks */
-#ifndef GI2D_INBOX_MAX_TILES
 #define GI2D_INBOX_MAX_TILES 1536                    /* images of more tiles do without (Inbox below) */
-#endif
 #define GI2D_FAST_LROW (GI2D_FAST_C + GI2D_FAST_HDR + GI2D_INBOX_WORDS) /* words per row */
 #define GI2D_FAST_EPT (GI2D_FAST_C / 256)            /* list entries per lane of the 256-lane tile workgroup */
 #define GI2D_FAST_S 32                               /* gaussian-major partial rows per gaussian: a gaussian on <= 32
@@ -68,7 +66,8 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // THE INBOX OF A TILE -- how a gaussian enters a tile without waiting for an atomic's answer.  The update kernel of a
 // fit ends with the binning step of the next iteration, and a gaussian that has ENTERED a tile used to reserve its slot
 // in the tile's row with a returning atomic: a device-scope round trip at the very end of every lane's dependency
-// chain, 3 us of a 10 us kernel, paid by the whole launch because some lane of nearly every wave needs it.  A slot
+// chain, 1.2 us of a 10 us kernel, paid by the whole launch because a launch ends with its slowest
+// wave and one wave in five holds a gaussian whose tile box changes.  A slot
 // that needs no answer is one nobody else can want: a gaussian entering tile t is, one pass earlier, at a known rank
 // r < 256 in the staged list of some NEIGHBOUR s of t that it is in (the tile pass hands every staged entry its rank in
 // the spare word of the gradient row it writes anyway) -- slot (t, direction of s, r) is its alone.  It stores its
@@ -82,8 +81,9 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // image's tile pass runs the small form first (gi2d_fast.hip), which has no registers to spare for entrants.
 // WHO MAY FIND AN INBOX NON-EMPTY: only the tile pass that gi2d_train_steps issues right behind such an update kernel,
 // in the same call -- the update kernel only bins when another iteration follows in its call (FILL_NEXT), so every call
-// returns with all inboxes empty, and no other kernel ever writes to one.  That pass (fast_fwdbwd_kernel<MODE, 0>) is
-// the only kernel built with the code that takes entrants in; nobody else loads a bitmap word.  The ranks are good for
+// returns with all inboxes empty, and no other kernel ever writes to one.  That pass (fast_fwdbwd_kernel<1, 0, true>,
+// picked by the launch code like the update kernel's INBOX instantiation) is the only kernel built with the code that
+// takes entrants in; nobody else loads a bitmap word.  The ranks are good for
 // the same reason: the update kernel runs right behind the tile pass whose gradient rows it reduces.
 struct Inbox {
     float4 *recs;  // [T][GI2D_INBOX_SLOTS][4]: a record as write_record leaves it, its last word the gaussian's id
