@@ -51,3 +51,21 @@ def test_launch_ranks_sets_the_rendezvous_environment(tmp_path, monkeypatch):
     assert all(r[2] == "3" and r[3] == "127.0.0.1" and r[5] == "0" for r in rows)
     assert len({r[4] for r in rows}) == 1 and int(rows[0][4]) > 0
     assert all(r[-4:] == ["--gpus", "3", "--steps", "5"] for r in rows)
+
+
+def test_stored_counters_exist_for_the_kernels_bench_names():
+    """bench.py copies `roofline.traffic` (and the VALU counters) from profiles/traffic.json by KERNEL NAME; a kernel that
+    gains a template argument silently turns the figure into null.  The names the default run, BASELINE config 4 and the
+    24-image block use must have an entry with HBM bytes -- regenerate the profiles (tools/profile_rounds.sh,
+    tools/make_profiles_rounds.py) when this fails."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cases = [("gi2d::fast_fwdbwd_kernel<1, 0, true>", 50000, 512, 768, None),
+             ("gi2d::fast_fwdbwd_kernel<1, 1, false> + gi2d::fast_fwdbwd_kernel<1, 2, false>", 50000, 1356, 2040, None),
+             ("gi2d::fast_fwdbwd_batched_kernel<1, 1> + gi2d::fast_fwdbwd_batched_kernel<1, 2>", 50000, 512, 768, 24)]
+    for kernel, n, h, w, k in cases:
+        traffic, source = bench.pmc_traffic(kernel, n, h, w, k)
+        assert traffic and traffic > 1e6, (kernel, source)
+        assert source.startswith("stored:"), source
+    valu = bench.valu_roofline(cases[0][0], 50000, 512, 768, 18.0)
+    assert valu.get("insts_per_image", 0) > 1e6, valu
