@@ -98,7 +98,7 @@ def test_a_fit_that_changes_between_single_image_and_batched_calls_equals_the_fi
         _assert_same(a, b, f"alone / batched / alone, image {i}")
 
 
-def _wild_fitter():
+def _wild_fitter(**kw):
     """One 384x256 image whose gaussians use every way into a tile: 4 000 small ones that drift into neighbouring tiles
     (the inbox), 600 piled into one tile (ranks beyond the 256-entry cap: no rank to go by), 400 large ones on ~25 tiles
     (boxes of more than eight tiles keep the row header's atomic), and a learning rate that makes some of them jump more
@@ -114,7 +114,7 @@ def _wild_fitter():
     L[4600:, 0] = L[4600:, 2] = rng.uniform(10, 14, 400)
     init = {"xyz": torch.from_numpy(np.arctanh(u).astype(np.float32)), "chol": torch.from_numpy(L.astype(np.float32)),
             "feat": torch.from_numpy(rng.uniform(0, 0.2, (n, 3)).astype(np.float32)), "bound": torch.tensor([0.5, 0.0, 0.5])}
-    return NativeFitter(synthetic_image(h, w, 75).to(DEV), n, kind="cholesky", lr=0.12, seed=5, init=init)
+    return NativeFitter(synthetic_image(h, w, 75).to(DEV), n, kind="cholesky", lr=0.12, seed=5, init=init, **kw)
 
 
 def test_every_way_into_a_tile_gives_the_rows_of_the_plain_appends():

@@ -126,3 +126,54 @@ def test_quantize_schedule_follows_train_quantize(iterations, warmup, prune, gro
     got = [e for e in got if e not in extra]
     assert sorted(got) == sorted(want)
     assert probe.iteration == iterations - 1
+
+
+# ------------------------------------------------------------------ the reference's own prune / growth code (fixture)
+def _densify_fixture():
+    """tests/golden/densify_reference.npz: inputs and outputs of the REFERENCE's check_non_semi_definite /
+    non_semi_definite_prune / add_sample_positions / densification_postfix run on CPU
+    (tests/golden/make_densify_golden.py imports models/gaussianimage_covariance.py and train.py)."""
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "densify_reference.npz"))
+
+
+def test_prune_statement_equals_the_reference_run():
+    """models/gaussianimage_covariance.py:339-382: mask, compaction of parameters, both Adam moments and the bound."""
+    fx = _densify_fixture()
+    full = torch.from_numpy(fx["p0_cov2d"] + fx["p0_bound"])
+    valid = positive_definite_mask(full).numpy()
+    assert np.array_equal(valid, fx["prune_valid_mask"])
+    pruned, n1 = (int(v) for v in fx["prune_counts"])
+    assert pruned == int((~valid).sum()) and n1 == int(valid.sum())
+    for nm in ("xyz", "cov2d", "f_dc"):
+        for pre in ("", "m_", "v_"):
+            assert np.array_equal(fx[f"p0_{pre}{nm}"][valid], fx[f"p1_{pre}{nm}"]), (pre, nm)
+        assert fx[f"p0_step_{nm}"] == fx[f"p1_step_{nm}"]  # the step count survives the surgery
+    assert np.array_equal(fx["p0_bound"][valid], fx["p1_bound"])
+    assert fx["p1_opacity"].shape == (n1, 1) and np.all(fx["p1_opacity"] == 1)
+
+
+@__import__("pytest").mark.parametrize("tag,prev", [("g1", "p1"), ("g2", "g1"), ("g3", "g2")])
+def test_growth_statement_equals_the_reference_run(tag, prev):
+    """train.py:85-118 + densification_postfix (:307-337): budget, top-k pixels, draws, PD filter, appended rows, zero
+    moments, the new rows' bound from the NEW population size."""
+    import math
+    fx = _densify_fixture()
+    h, w, _, _, iterations, grow_iter = (int(v) for v in fx["dims"])
+    it, max_points, cur, k, new_n = (int(v) for v in fx[f"{tag}_args"])
+    assert fx[f"{prev}_xyz"].shape[0] == cur
+    assert growth_budget(it, iterations, grow_iter, cur, max_points) == k == fx[f"{tag}_rand3"].shape[0]
+    got = select_new_points(torch.from_numpy(fx[f"{tag}_render"]), torch.from_numpy(fx["gt"]), k,
+                            torch.from_numpy(fx[f"{tag}_rand3"]))
+    kept = new_n - cur
+    assert got["xyz"].shape[0] == kept and got["dropped"] == k - kept and 0 < kept < k
+    assert np.array_equal(got["xyz"].numpy(), fx[f"{tag}_xyz"][cur:])
+    assert np.array_equal(got["cov2d"].numpy(), fx[f"{tag}_cov2d"][cur:])
+    assert not fx[f"{tag}_f_dc"][cur:].any()
+    for nm in ("xyz", "cov2d", "f_dc"):  # the old rows and their moments stay, the new rows' moments are zero
+        for pre in ("", "m_", "v_"):
+            assert np.array_equal(fx[f"{tag}_{pre}{nm}"][:cur], fx[f"{prev}_{pre}{nm}"]), (pre, nm)
+        assert not fx[f"{tag}_m_{nm}"][cur:].any() and not fx[f"{tag}_v_{nm}"][cur:].any()
+    low = np.float32(min(h * w / (9 * math.pi * new_n), 300))
+    assert np.array_equal(fx[f"{tag}_bound"][:cur], fx[f"{prev}_bound"])
+    assert np.array_equal(fx[f"{tag}_bound"][cur:], np.tile(np.array([low, 0, low], np.float32), (kept, 1)))

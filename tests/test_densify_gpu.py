@@ -126,3 +126,70 @@ def test_device_resident_fit_equals_host_driven_fit():
     for nm in ("xyz", "chol", "feat", "bound", "m_chol", "v_feat"):
         assert torch.equal(getattr(a, nm), getattr(b, nm)), nm
     assert a.best()[1:] == b.best()[1:]
+
+
+# ------------------------------------------------------------------ against the reference's own prune / growth code
+_FX_ROWS = (("_xyz", "xyz"), ("_chol", "cov2d"), ("_feat", "f_dc"), ("_m_xyz", "m_xyz"), ("_v_xyz", "v_xyz"),
+            ("_m_chol", "m_cov2d"), ("_v_chol", "v_cov2d"), ("_m_feat", "m_f_dc"), ("_v_feat", "v_f_dc"),
+            ("_bound", "bound"), ("_opacity", "opacity"))
+
+
+@pytest.mark.parametrize("device_resident", [True, False])
+def test_prune_and_growth_equal_the_reference_run(device_resident, monkeypatch):
+    """tests/golden/densify_reference.npz holds the state of the REFERENCE's model + Adam before and after its own
+    non_semi_definite_prune (models/gaussianimage_covariance.py:354-370) and three add_sample_positions /
+    densification_postfix steps (train.py:85-118, :307-337) -- an ordinary one, one the cap clips, the last one that
+    releases the whole budget.  gi2d_train_prune / gi2d_train_grow (and the host-driven torch path) start from the
+    same rows, renders and uniform draws and must leave the same rows, bit for bit."""
+    import os
+    from gaussianimage_plus_amd.trainer import NativeFitter
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "densify_reference.npz"))
+    h, w, n0, cap, iterations, grow_iter = (int(v) for v in fx["dims"])
+    gt = torch.from_numpy(fx["gt"]).to(DEV)
+    fit = NativeFitter(gt, n0, kind="covariance", lr=0.018, eps=1e-15, seed=1, max_points=cap, track_best=True,
+                       device_resident=device_resident)
+    assert fit.per_point_bound
+    for attr, key in _FX_ROWS:
+        getattr(fit, attr)[:n0] = torch.from_numpy(fx["p0_" + key]).to(DEV)
+
+    def rows(n):
+        return {key: getattr(fit, attr)[:n].cpu().numpy() for attr, key in _FX_ROWS}
+
+    def same(tag, n):
+        got = rows(n)
+        for key in got:
+            assert np.array_equal(got[key], fx[f"{tag}_{key}"]), (tag, key)
+
+    # ---- prune
+    pruned, n1 = (int(v) for v in fx["prune_counts"])
+    res = fit.prune_non_definite()
+    assert (res is None) if device_resident else (res == pruned)
+    assert fit.sync_population() == n1
+    same("p1", n1)
+    # ---- growth: the render the reference was given, the uniform numbers it drew
+    real_rand = torch.rand
+    for tag in ("g1", "g2", "g3"):
+        it, max_points, cur, k, new_n = (int(v) for v in fx[f"{tag}_args"])
+        assert fit.sync_population() == cur
+        fit.out_img.copy_(torch.from_numpy(fx[f"{tag}_render"]).to(DEV))
+        draws = torch.from_numpy(fx[f"{tag}_rand3"])
+
+        def fake_rand(rows_, cols, generator=None):  # the first k rows are what the reference drew (train.py:111)
+            assert cols == 3 and rows_ >= k
+            out = real_rand(rows_, 3, generator=generator)
+            out[:k] = draws
+            return out
+
+        monkeypatch.setattr(torch, "rand", fake_rand)
+        try:
+            res = fit.add_sample_positions(it, iterations, grow_iter, max_points=max_points)
+        finally:
+            monkeypatch.setattr(torch, "rand", real_rand)
+        assert (res is None) if device_resident else (res == new_n - cur)
+        assert fit.sync_population() == new_n, tag
+        same(tag, new_n)
+    if device_resident:
+        assert fit.dens_counts.tolist() == [pruned, int(fx["g3_args"][4]) - n1]
+    fit.train(5)  # the fit goes on from the reference's state
+    fit.check_status()
+    assert np.isfinite(fit.psnr())
