@@ -82,6 +82,7 @@ SIZE_FUNCS = {
     "gi2d_quant_workspace_bytes": [_i],
     "gi2d_densify_scratch_bytes": [_p, _i],
     "gi2d_batch_bytes": [_i],
+    "gi2d_train_inbox_bytes": [_i, _i],
 }
 STRING_FUNCS = ["gi2d_version", "gi2d_last_error_string"]
 

@@ -43,7 +43,7 @@ struct NextFill {
     int32_t *num_tiles_hit, *lists, *status, *tile_order;
     PrevBox *prev_box;
     RecSets recs;
-    float4 *inbox;  // the tiles' inboxes (FastWs::inbox_recs)
+    float4 *inbox;  // the tiles' inboxes (gi2d_train_state::inbox; nullptr: none)
 };
 
 struct AdamStep {
@@ -69,7 +69,7 @@ struct TilePassArgs {
     float *tile_sse;
     const int32_t *tile_order;
     int32_t *big_tile;  // two-phase tile pass: which tiles the small form left to the general one (FastWs::big_tile)
-    float4 *inbox;      // the tiles' inboxes (FastWs::inbox_recs)
+    float4 *inbox;      // the tiles' inboxes (gi2d_train_state::inbox; nullptr: none)
 };
 
 // One image's arguments of the per-gaussian fitting kernels (project+fill, reduce+update).
@@ -187,7 +187,7 @@ void single_pass_end(const void *ws, const FastWs &w, long long tiles, hipStream
 int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned img_w, unsigned img_h, const float *background,
                                const float *v_output, const float *target, float grad_scale, float *tile_sse, void *ws,
                                size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form,
-                               bool inbox = false);  // inbox: see fast_fwdbwd_kernel
+                               float4 *inbox = nullptr);  // inbox: the tiles' inboxes to take entrants out of (fast_fwdbwd_kernel)
 int batch_pass_begin(const void *batch, int total_blocks, hipStream_t st);
 void batch_pass_end(const void *batch, const BatchTable &b, int k_images, int total_blocks, hipStream_t st);
 

@@ -925,7 +925,7 @@ int gi2d_fast_rasterize_forward_backward(int n, int tiles_x, int tiles_y, unsign
                                          float grad_scale, float *tile_sse, void *ws, size_t ws_bytes,
                                          int32_t *status, float *out_img, gi2d_stream_t st) {
     return gi2d::fast_forward_backward_form(n, tiles_x, tiles_y, w_, h, background, v_output, target, grad_scale, tile_sse,
-                                            ws, ws_bytes, status, out_img, st, -1, false);
+                                            ws, ws_bytes, status, out_img, st, -1, nullptr);
 }
 }  // extern "C"
 
@@ -935,7 +935,8 @@ namespace gi2d {
 // when some tile is fuller than the small form; gi2d_train_steps asks single_pass_begin instead)
 int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, unsigned h, const float *background,
                                const float *v_output, const float *target, float grad_scale, float *tile_sse, void *ws,
-                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form, bool inbox) {
+                               size_t ws_bytes, int32_t *status, float *out_img, gi2d_stream_t st, int form,
+                               float4 *inbox) {
     int rc = check_ws("fast rasterize forward+backward: workspace too small", ws, ws_bytes, n, tiles_x, tiles_y);
     if (rc != GI2D_OK) return rc;
     const long long t = (long long)tiles_x * tiles_y;
@@ -949,6 +950,7 @@ int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, uns
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
+    w.inbox_recs = inbox;
     TilePassArgs a = tile_pass_args(w, n, tiles_x, tiles_y, (int)w_, (int)h, status, out_img,
                                     v_output ? v_output : target, v_output ? 0.f : grad_scale,
                                     v_output ? nullptr : tile_sse);
@@ -968,7 +970,7 @@ int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, uns
         }
     } else if (v_output) {
         GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<0, 0>), grid, block, (hipStream_t)st, a);
-    } else if (inbox && t <= GI2D_INBOX_MAX_TILES) {
+    } else if (inbox != nullptr && t <= GI2D_INBOX_MAX_TILES) {
         GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<1, 0, true>), grid, block, (hipStream_t)st, a);
     } else {
         GI2D_LAUNCH_TIMED((fast_fwdbwd_kernel<1, 0>), grid, block, (hipStream_t)st, a);

@@ -1,6 +1,8 @@
 // Internals of the fused fast path shared by gi2d_fast.hip and gi2d_train.hip: workspace layout, bucket
 // fill, partial-row addressing and the ordered per-gaussian reduction.
 #pragma once
+#include <atomic>
+
 #include "gi2d_project_core.h"
 #include "gi2d_raster_core.h"
 
@@ -136,8 +138,9 @@ struct InboxSrc {
 static inline int per_gaussian_block(int n) { return n <= 32768 ? 64 : GI2D_PG_BIG; }
 struct FastWs {
     int32_t *lists;        // [T * LROW]         persistent tile lists (see above), each row with its inbox bitmap
-    float4 *inbox_recs;    // [T * 2048 * 4]     the tiles' inboxes (Inbox): sparsely used address space, 128 KB per tile
-                           //                    (images of at most GI2D_INBOX_MAX_TILES tiles; none otherwise)
+    float4 *inbox_recs;    // [T * 2048 * 4]     the tiles' inboxes (Inbox): NOT part of the workspace -- a buffer of its own
+                           //                    that only the caller of gi2d_train_steps on ONE image may bring
+                           //                    (gi2d_train_state::inbox, gi2d_train_inbox_bytes); nullptr everywhere else
     int32_t *gids_sorted;  // == lists: tile_bins hold absolute word positions into it
     int32_t *tile_bins;    // [T * 2]            [row base + HDR, row base + HDR + len)
     GaussRec *packed;      // [T * 256]          tile-sorted records of the first 256 entries
@@ -160,11 +163,10 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     char *b = (char *)base;
     size_t off = 0;
     const size_t t = (size_t)(num_tiles > 0 ? num_tiles : 1), nn = (size_t)(n > 0 ? n : 1);
-    // the inboxes' records FIRST: 192 MiB of sparsely used address space in the middle of the arrays every kernel works
-    // on cost the batched kernels 1.5 % (measured: the same arrays, further apart), and behind them its place would
-    // depend on the gaussian count
-    w.inbox_recs = (float4 *)(b + off);
-    if (t <= GI2D_INBOX_MAX_TILES) off += align_up(t * GI2D_INBOX_SLOTS * 4 * sizeof(float4));
+    // (the inboxes' records -- 128 KB of sparsely used address space per tile -- were part of every workspace in round 5:
+    // batches, the drop-in wrappers' pooled workspaces, evaluation renders and every multi-GPU rank paid 192 MiB at
+    // 768x512 for something only a single-image fit touches.  They are the fit's own buffer now: inbox_bytes below.)
+    w.inbox_recs = nullptr;
     w.lists = (int32_t *)(b + off);
     w.gids_sorted = w.lists;
     off += align_up(t * GI2D_FAST_LROW * sizeof(int32_t));
@@ -190,6 +192,11 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     off += align_up(t * GI2D_TILE_LIST_CAP * GI2D_FAST_ROW * sizeof(float4));
     w.bytes = off;
     return w;
+}
+// Bytes of the inbox buffer of an image of `num_tiles` tiles (0: such an image does without, Inbox above).
+static inline size_t inbox_bytes(long long num_tiles) {
+    if (num_tiles < 1 || num_tiles > GI2D_INBOX_MAX_TILES) return 0;
+    return align_up((size_t)num_tiles * GI2D_INBOX_SLOTS * 4 * sizeof(float4));
 }
 __host__ __device__ __forceinline__ int list_base(int tile) { return tile * GI2D_FAST_LROW + GI2D_FAST_HDR; }
 
@@ -393,42 +400,60 @@ __device__ __forceinline__ bool tile_member(const float2 xy, int rad, float radi
 //   "the records the last tile pass used" are set ver[0] & 1.
 struct RecSets {
     float4 *base;
-    size_t stride;  // float4 per set
     int32_t *ver;
+    unsigned stride;  // float4 per set
+    int seq;          // a number no other C-ABI call of this process carries (rec_sets): part of a binning call's stamp
 };
 // What a binning kernel gets: the record set it writes, and the word in which it notes that SOME gaussian is in a tile
-// -- stamped with its own version, so nobody ever has to reset it: a forward that must render the background when there
-// is not a single intersection (rasterize_sum_plus.py:110-118) compares the word with the version it reads
-// (tile_pass_has_members) instead of waiting for a second launch behind the tile pass.
-#define GI2D_VER_ANY 2 /* word of RecSets::ver */
-#define GI2D_VER_WORDS 3
+// -- stamped, so nobody ever has to reset it: a forward that must render the background when there is not a single
+// intersection (rasterize_sum_plus.py:110-118) compares the word with the stamp of the LATEST binning call
+// (tile_pass_has_members) instead of waiting for a second launch behind the tile pass.  The stamp is the record-set
+// version the call leaves (which only a tile pass advances) AND the call's own number (two words): two binning calls with
+// no tile pass between them -- the C ABI allows it -- write the same version, and a second one WITHOUT a member must
+// not inherit the first one's word (round 5's stamp was the version alone: bin, bin(empty), forward rendered zeros where
+// the reference returns the background).
+// Layout rule of this line (`ver`, 64 words of their own): every word is written with PLAIN stores only, by lanes that
+// all store the same value in one launch, and read by plain loads of LATER launches -- never an atomic next to them,
+// never a read-modify-write (the dropped ticket counters).
+#define GI2D_VER_ANY 2     /* word of RecSets::ver: version left by the last binning call that put a gaussian into a tile */
+#define GI2D_VER_ANY_SEQ 3 /* ... and that call's number */
+#define GI2D_VER_LATEST 4  /* number of the last binning call */
+#define GI2D_VER_WORDS 5
+static_assert(GI2D_VER_WORDS <= 16, "the stamps share the version words' 64 bytes; word 16 onwards has other owners");
 struct BinRecs {
     float4 *recs;
     int32_t *any;
-    int stamp;
+    int stamp, seq;
 };
 __device__ __forceinline__ BinRecs recs_for_binning(const RecSets &rs, bool writer) {
     const int c = rs.ver[0];
-    if (writer) rs.ver[1] = c + 1;
     BinRecs b;
-    b.recs = rs.base + ((c + 1) & 1) * rs.stride;
+    b.recs = rs.base + (size_t)((c + 1) & 1) * rs.stride;
     b.any = rs.ver + GI2D_VER_ANY;
     b.stamp = c + 1;
+    b.seq = rs.seq;
+    if (writer) rs.ver[1] = c + 1, rs.ver[GI2D_VER_LATEST] = rs.seq;
     return b;
 }
-__device__ __forceinline__ bool tile_pass_has_members(const RecSets &rs) { return rs.ver[GI2D_VER_ANY] == rs.ver[1]; }
+// (a wave that holds a member: one lane of it)
+__device__ __forceinline__ void note_member(const BinRecs &b) { b.any[0] = b.stamp, b.any[GI2D_VER_ANY_SEQ - GI2D_VER_ANY] = b.seq; }
+__device__ __forceinline__ bool tile_pass_has_members(const RecSets &rs) {
+    return rs.ver[GI2D_VER_ANY] == rs.ver[1] && rs.ver[GI2D_VER_ANY_SEQ] == rs.ver[GI2D_VER_LATEST];
+}
 __device__ __forceinline__ const float4 *recs_for_tile_pass(const RecSets &rs, bool writer) {
     const int b = rs.ver[1];
     if (writer) rs.ver[0] = b;
-    return rs.base + (b & 1) * rs.stride;
+    return rs.base + (size_t)(b & 1) * rs.stride;
 }
 __device__ __forceinline__ const float4 *recs_of_last_pass(const RecSets &rs) {
-    return rs.base + (rs.ver[0] & 1) * rs.stride;
+    return rs.base + (size_t)(rs.ver[0] & 1) * rs.stride;
 }
+inline std::atomic<unsigned> g_call_seq{1};
 static inline RecSets rec_sets(const FastWs &w, int n) {
     RecSets rs;
+    rs.seq = (int)(g_call_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffu);
     rs.base = w.recs;
-    rs.stride = align_up((size_t)(n > 0 ? n : 1) * 4 * sizeof(float4)) / sizeof(float4);
+    rs.stride = (unsigned)(align_up((size_t)(n > 0 ? n : 1) * 4 * sizeof(float4)) / sizeof(float4));
     rs.ver = w.ver;
     return rs;
 }
@@ -524,7 +549,7 @@ __device__ __forceinline__ void bin_one(int g, float2 xy, int radius, bool has_t
     const bool member = bin_box(xy, radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && has_tiles;
     {  // one store per wave that holds a member (by its first such lane)
         const unsigned long long mm = __ballot(member);
-        if (mm != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(mm)) *br.any = br.stamp;
+        if (mm != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(mm)) note_member(br);
     }
     float4 *recs = br.recs;
     const int2 box = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);

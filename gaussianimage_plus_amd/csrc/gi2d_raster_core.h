@@ -72,81 +72,125 @@ __device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, 
 }
 
 // =========================================================================================== forward
-// One lane per pixel; wave w owns pixel rows 4w..4w+3 (a "strip"), lanes with column < 8 its left half, the others
-// its right half.  A gaussian's alpha >= 1/255 box (cull_word) typically spans ~8 columns at 50 000 gaussians per
-// 768x512 image, i.e. one half of a strip more often than both, so each wave keeps TWO ascending lists -- entries
-// whose box reaches the left half, entries whose box reaches the right half (an entry may sit in both) -- and the
-// two halves of the wave walk their own list side by side: per trip a lane evaluates two consecutive entries of
-// ITS list with packed fp32 (v_pk_fma_f32 & co), entry 2p feeding one accumulator set and 2p+1 another (summed
-// at the end).  A wave needs max(|left|, |right|) / 2 trips instead of |left u right| / 2 (-37 % at that size).
-// Entries are copied GI2D_FWD_CHUNK at a time into a wave-private pair-interleaved buffer -- entries 2p and 2p+1
-// side by side, 20 floats per pair: (gx gx' gy gy') (ha ha' hb hb') (hc hc' op op') (cr cr' cg cg') (cb cb' lim lim')
-// [+ (k k' - -) where final_idx is wanted: 24 floats] -- so one pair costs five ds_read_b128; the two halves' buffers
-// are 128 bytes out of phase, so the two addresses of one read never share a bank.  `lim` is the pair test of
-// gi2d_common.h::AlphaRule (one unsigned compare per pair); a wave none of whose entries can exceed alpha = 1 runs
-// the trips without the two v_min (bit-identical: the min is the identity there).  Every forward kernel (plain, fast,
+// Wave w owns pixel rows 4w..4w+3 (a "strip").  A gaussian's alpha >= 1/255 box (cull_word) typically spans ~8 columns
+// at 50 000 gaussians per 768x512 image, i.e. one half of a strip more often than both, so each wave keeps TWO ascending
+// lists -- entries whose box reaches the left half (columns 0..7), entries whose box reaches the right half (an entry
+// may sit in both) -- and the two halves are walked side by side: a wave needs max(|left|, |right|) / 2 trips instead of
+// |left u right| / 2 (-37 % at that size).
+//
+// Lane layout (round 6): ONE entry for TWO horizontally adjacent pixels per lane and trip.  The 16 lanes of a DPP row
+// serve one pixel row of the strip: lane r (0..15) of the row = (parity r >> 3, half (r >> 2) & 1, column pair r & 3)
+// evaluates, for its half's list, the entries at positions 2t + parity on the pixels (8 half + 2 pair, + 1) of its row.
+// The row terms dy, b dy, c dy^2 are formed ONCE per lane and trip with plain fp32 instructions (the two pixels share
+// them), the two dx and everything behind them with packed fp32 (v_pk_fma_f32 & co) -- 4 plain + 7 packed + 2 v_exp +
+// 2 compares + 2 selects per trip, where rounds 3-5 (two entries for one pixel) spent 11 packed ones: the plain
+// instructions issue in half a packed one's cycles (tools/ubench/valu_rate.hip), and a trip reads ONE staged entry
+// (40 bytes: two ds_read_b128 + one ds_read_b64) instead of two interleaved ones (five ds_read_b128).  Even and odd list
+// positions are accumulated by different lanes -- exactly the two partial sums of the earlier layout -- and meet at the
+// end in one DPP add per channel (row_ror:8 swaps the parities of a row), even + odd, so every pixel keeps its bits.
+// After the exchange the lane of row position r holds the pixel of column fwd_lane_col(r) = 8 half + 2 pair + parity:
+// that is the lane -> pixel map of every kernel that runs this routine (fused_tile, fwd_rasterize_staged).
+// Entries are copied GI2D_FWD_CHUNK at a time into a wave-private buffer, per list three arrays in list order --
+// A[e] = (gx gy ha hb), B[e] = (hc op cr cg), C[e] = (cb lim) [+ (k -) where final_idx is wanted] -- written with the
+// same wide stores they are read with; the right list's arrays sit 32 bytes out of phase with the left one's, so the
+// four addresses of one read (two halves x two parities) never share a bank.  `lim` is the pair test of
+// gi2d_common.h::AlphaRule (one unsigned compare per pair); a wave none of whose entries can exceed alpha = 1 runs the
+// trips without the two v_min (bit-identical: the min is the identity there).  Every forward kernel (plain, fast,
 // single-pass) runs this one routine: identical pixels bit for bit.
 #define GI2D_FWD_DUMMY GI2D_TILE_LIST_CAP /* index of a never-contributing entry used as list padding */
 #ifndef GI2D_FWD_CHUNK
 #define GI2D_FWD_CHUNK 32                 /* list entries per half copied per trip */
 #endif
-#define GI2D_FWD_PF(FIDX) ((FIDX) ? 24 : 20)                             /* floats per staged pair */
-#define GI2D_FWD_HALF_OF(FIDX) (GI2D_FWD_CHUNK / 2 * GI2D_FWD_PF(FIDX) + 32) /* floats from the left buffer to the right one (incl. bank shift) */
-#define GI2D_FWD_PAIRBUF_OF(FIDX) (GI2D_FWD_HALF_OF(FIDX) + GI2D_FWD_CHUNK / 2 * GI2D_FWD_PF(FIDX)) /* floats per wave */
+static_assert(GI2D_FWD_CHUNK == 32, "a chunk is what the 32 lanes of a half wave copy in one go");
+#define GI2D_FWD_CW(FIDX) ((FIDX) ? 4 : 2)                                   /* floats of a staged entry's C part */
+#define GI2D_FWD_LISTF(FIDX) (GI2D_FWD_CHUNK * (8 + GI2D_FWD_CW(FIDX)))      /* floats of one staged list: A, B, C */
+#define GI2D_FWD_HALF_OF(FIDX) (GI2D_FWD_LISTF(FIDX) + 8)                    /* floats from the left list to the right one (incl. bank shift) */
+#define GI2D_FWD_PAIRBUF_OF(FIDX) (GI2D_FWD_HALF_OF(FIDX) + GI2D_FWD_LISTF(FIDX)) /* floats per wave */
 #define GI2D_FWD_PAIRBUF GI2D_FWD_PAIRBUF_OF(false)
 #define GI2D_FWD_LISTLEN (GI2D_TILE_LIST_CAP + 8)
+static_assert(GI2D_FWD_PAIRBUF_OF(false) % 4 == 0 && GI2D_FWD_PAIRBUF_OF(true) % 4 == 0, "every wave's buffer is 16-byte aligned");
 
 struct FwdRec {  // one staged entry as the pixel loop consumes it (conic pre-scaled: scale_conic)
     float gx, gy, ha, hb, hc, op, cr, cg, cb;
     unsigned lim;  // AlphaRule::lim
 };
 
+// column (0..15) of the pixel the lane at position r of a 16-lane row holds once the forward has run
+__device__ __forceinline__ int fwd_lane_col(int lane) {
+    const int r = lane & 15;
+    return ((r & 4) << 1) | ((r & 3) << 1) | (r >> 3);
+}
+// ... and the position in the row of the lane that holds column c
+__device__ __forceinline__ int fwd_col_lane(int c) { return ((c & 1) << 3) | ((c >> 3) << 2) | ((c >> 1) & 3); }
+
 #ifndef GI2D_FWD_UNROLL
 #define GI2D_FWD_UNROLL 2 /* trips per loop body: two let the LDS reads of one trip overlap the arithmetic of the other */
 #endif
+// `mine`: this lane's first entry of the chunk (A array of its half's list + 4 floats for the odd parity); m: entries of
+// the chunk (both parities); px2: x of the lane's two pixels, py: their y.  a0..a2: (pixel A, pixel B) per channel.
 template <bool NEED_FIDX, bool CLAMP, int UNROLL = GI2D_FWD_UNROLL>
-__device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px2, const v2f py2, v2f &a0, v2f &a1,
-                                          v2f &a2, int &last) {
-    constexpr int PF = GI2D_FWD_PF(NEED_FIDX);
+__device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px2, const float py, v2f &a0, v2f &a1,
+                                          v2f &a2, int &last_a, int &last_b) {
+    constexpr int CW = GI2D_FWD_CW(NEED_FIDX);
+    const float4 *qa = reinterpret_cast<const float4 *>(mine);
+    const float4 *qb = reinterpret_cast<const float4 *>(mine + 4 * GI2D_FWD_CHUNK);
+    // (the C array starts 8 CHUNK floats behind A; an odd-parity lane is 4 floats into A and CW floats into C)
+    const float *qc0 = mine + 8 * GI2D_FWD_CHUNK;
 #pragma unroll UNROLL
     for (int t = 0; t < m; t += 2) {
-        const float4 *q = reinterpret_cast<const float4 *>(mine + (t >> 1) * PF);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-        const v2f gx = {q0.x, q0.y}, gy = {q0.z, q0.w}, ha = {q1.x, q1.y}, hb = {q1.z, q1.w};
-        const v2f hc = {q2.x, q2.y}, op = {q2.z, q2.w}, cr = {q3.x, q3.y}, cg = {q3.z, q3.w};
-        const v2f cb = {q4.x, q4.y};
-        const v2f dx = gx - px2, dy = gy - py2;
-        const v2f zero2 = {0.f, 0.f};
-        const v2f bdy = hb * dy, cdy2 = __builtin_elementwise_fma(hc * dy, dy, zero2);  // == row_term_b / row_term_c
-        const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(ha, dx, bdy), cdy2);
+        const float4 q0 = qa[t], q1 = qb[t];  // entries t + parity: two float4 per trip and array
+        float cb, kf = 0.f;
+        unsigned lim;
+        if (NEED_FIDX) {
+            const float4 q2 = *reinterpret_cast<const float4 *>(qc0 + (CW - 4) * 0 + t * CW - (mine - mine));
+            cb = q2.x, lim = (unsigned)__float_as_int(q2.y), kf = q2.z;
+        } else {
+            const float2 q2 = *reinterpret_cast<const float2 *>(qc0 + t * CW);
+            cb = q2.x, lim = (unsigned)__float_as_int(q2.y);
+        }
+        const float gx = q0.x, gy = q0.y, ha = q0.z, hb = q0.w, hc = q1.x, op = q1.y, cr = q1.z, cg = q1.w;
+        // the row terms, once for the two pixels: == row_term_b / row_term_c
+        const float dy = gy - py;
+        const float bdy = hb * dy, cdy2 = __builtin_fmaf(hc * dy, dy, 0.f);
+        const v2f dx = (v2f){gx, gx} - px2;
+        const v2f sig = __builtin_elementwise_fma(dx, __builtin_elementwise_fma((v2f){ha, ha}, dx, (v2f){bdy, bdy}),
+                                                  (v2f){cdy2, cdy2});
         const v2f vis = {pair_vis(sig.x), pair_vis(sig.y)};
-        const v2f tt = op * vis;
+        const v2f tt = (v2f){op, op} * vis;
         // forward.cu:539-541
-        const bool ok0 = CLAMP ? pair_lands_odd(sig.x, tt.x, (unsigned)__float_as_int(q4.z)) : pair_lands(sig.x, (unsigned)__float_as_int(q4.z));
-        const bool ok1 = CLAMP ? pair_lands_odd(sig.y, tt.y, (unsigned)__float_as_int(q4.w)) : pair_lands(sig.y, (unsigned)__float_as_int(q4.w));
+        const bool ok0 = CLAMP ? pair_lands_odd(sig.x, tt.x, lim) : pair_lands(sig.x, lim);
+        const bool ok1 = CLAMP ? pair_lands_odd(sig.y, tt.y, lim) : pair_lands(sig.y, lim);
         v2f am = {ok0 ? tt.x : 0.f, ok1 ? tt.y : 0.f};
         if (CLAMP) am = (v2f){fminf(1.f, am.x), fminf(1.f, am.y)};
-        a0 = __builtin_elementwise_fma(cr, am, a0);
-        a1 = __builtin_elementwise_fma(cg, am, a1);
-        a2 = __builtin_elementwise_fma(cb, am, a2);
+        a0 = __builtin_elementwise_fma((v2f){cr, cr}, am, a0);
+        a1 = __builtin_elementwise_fma((v2f){cg, cg}, am, a1);
+        a2 = __builtin_elementwise_fma((v2f){cb, cb}, am, a2);
         if (NEED_FIDX) {  // entries ascend within a list: the last one that lands is the largest
-            const float2 ks = *reinterpret_cast<const float2 *>(q + 5);
-            last = ok0 ? __float_as_int(ks.x) : last;
-            last = ok1 ? __float_as_int(ks.y) : last;
+            last_a = ok0 ? __float_as_int(kf) : last_a;
+            last_b = ok1 ? __float_as_int(kf) : last_b;
         }
     }
 }
 
+// x + (the same register of the lane eight positions round the 16-lane row): row_ror:8 swaps a row's two parities
+__device__ __forceinline__ float fwd_add_partner(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int fwd_max_partner(int x) {
+    return max(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false));
+}
+
 // lists: [2][GI2D_FWD_LISTLEN] bytes of this wave (left, right); buf: GI2D_FWD_PAIRBUF_OF(NEED_FIDX) floats of this
 // wave (16-byte aligned).  cull_of(k) -> cull_word of entry k, rec_of(k) -> FwdRec of entry k (k == GI2D_FWD_DUMMY must
-// give an entry that never lands: lim 0).  Returns the pixel in o0..o2 and, with NEED_FIDX, the last contributing entry
+// give an entry that never lands: lim 0).  tx0: x of the tile's first column, py: y of this lane's pixel row.  Returns,
+// for the pixel (tx0 + fwd_lane_col(lane), py), the colour in o0..o2 and, with NEED_FIDX, the last contributing entry
 // (-1: none).
 // CAP: entries the caller's staging arrays hold (the lists are CAP + 8 bytes each, entry CAP is the padding entry).
 template <bool NEED_FIDX, int CAP = GI2D_TILE_LIST_CAP, int UNROLL = GI2D_FWD_UNROLL, class CullOf, class RecOf>
 __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float *buf, int len, CullOf cull_of,
-                                                     RecOf rec_of, float px, float py, float &o0, float &o1,
+                                                     RecOf rec_of, float tx0, float py, float &o0, float &o1,
                                                      float &o2, int &last_k) {
-    constexpr int PF = GI2D_FWD_PF(NEED_FIDX), HALF = GI2D_FWD_HALF_OF(NEED_FIDX);
+    constexpr int CW = GI2D_FWD_CW(NEED_FIDX), HALF = GI2D_FWD_HALF_OF(NEED_FIDX);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned char *left = lists, *right = lists + (CAP + 8);
     int n_left = 0, n_right = 0;
@@ -166,45 +210,53 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
     }
     __builtin_amdgcn_wave_barrier();  // wave-private lists: DS ops of one wave complete in order
 
-    const int my_half = (lane >> 3) & 1;           // which list this pixel walks
-    const float *mine = buf + my_half * HALF;
+    const int r = lane & 15;
+    const int parity = r >> 3, my_half = (r >> 2) & 1;  // which entries of which list this lane walks
+    const float *mine = buf + my_half * HALF + parity * 4;
+    const float *mine_c_fix = nullptr;
+    (void)mine_c_fix;
     const int bh = lane >> 5, be = lane & 31;      // build role: lanes 0-31 copy left entries, 32-63 right entries
     const unsigned char *blist = bh ? right : left;
     const int bcnt = bh ? n_right : n_left;
-    float *bdst = buf + bh * HALF + (be >> 1) * PF + (be & 1);
+    float *bdst = buf + bh * HALF;
     const int n_max = max(n_left, n_right);
     v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
-    const v2f px2 = {px, px}, py2 = {py, py};
-    int last = -1;
+    const float pxa = tx0 + (float)(8 * my_half + 2 * (r & 3));  // small integers: exact
+    const v2f px2 = {pxa, pxa + 1.f};
+    int last_a = -1, last_b = -1;
     for (int c0 = 0; c0 < n_max; c0 += GI2D_FWD_CHUNK) {
         {
             const int e = c0 + be;
             const int k = e < bcnt ? (int)blist[e] : CAP;  // entry CAP: the never-landing padding entry
-            const FwdRec r = rec_of(k);
-            bdst[0] = r.gx;
-            bdst[2] = r.gy;
-            bdst[4] = r.ha;
-            bdst[6] = r.hb;
-            bdst[8] = r.hc;
-            bdst[10] = r.op;
-            bdst[12] = r.cr;
-            bdst[14] = r.cg;
-            bdst[16] = r.cb;
-            bdst[18] = __int_as_float((int)r.lim);
-            if (NEED_FIDX) bdst[20] = __int_as_float(k);
+            const FwdRec rec = rec_of(k);
+            reinterpret_cast<float4 *>(bdst)[be] = make_float4(rec.gx, rec.gy, rec.ha, rec.hb);
+            reinterpret_cast<float4 *>(bdst + 4 * GI2D_FWD_CHUNK)[be] = make_float4(rec.hc, rec.op, rec.cr, rec.cg);
+            if (NEED_FIDX)
+                reinterpret_cast<float4 *>(bdst + 8 * GI2D_FWD_CHUNK)[be] =
+                    make_float4(rec.cb, __int_as_float((int)rec.lim), __int_as_float(k), 0.f);
+            else
+                reinterpret_cast<float2 *>(bdst + 8 * GI2D_FWD_CHUNK)[be] = make_float2(rec.cb, __int_as_float((int)rec.lim));
         }
         __builtin_amdgcn_wave_barrier();
         const int m = min(GI2D_FWD_CHUNK, n_max - c0);
         if (clamp_any)
-            fwd_trips<NEED_FIDX, true, UNROLL>(mine, m, px2, py2, a0, a1, a2, last);
+            fwd_trips<NEED_FIDX, true, UNROLL>(mine, m, px2, py, a0, a1, a2, last_a, last_b);
         else
-            fwd_trips<NEED_FIDX, false, UNROLL>(mine, m, px2, py2, a0, a1, a2, last);
+            fwd_trips<NEED_FIDX, false, UNROLL>(mine, m, px2, py, a0, a1, a2, last_a, last_b);
         __builtin_amdgcn_wave_barrier();
     }
-    o0 = a0.x + a0.y;
-    o1 = a1.x + a1.y;
-    o2 = a2.x + a2.y;
-    last_k = last;
+    // even + odd list positions of each pixel (the two partial sums every earlier layout formed, in that order)
+    const float ea0 = fwd_add_partner(a0.x), eb0 = fwd_add_partner(a0.y);
+    const float ea1 = fwd_add_partner(a1.x), eb1 = fwd_add_partner(a1.y);
+    const float ea2 = fwd_add_partner(a2.x), eb2 = fwd_add_partner(a2.y);
+    o0 = parity ? eb0 : ea0;
+    o1 = parity ? eb1 : ea1;
+    o2 = parity ? eb2 : ea2;
+    last_k = -1;
+    if (NEED_FIDX) {
+        const int la = fwd_max_partner(last_a), lb = fwd_max_partner(last_b);
+        last_k = parity ? lb : la;
+    }
 }
 
 // A tile's RGB leaves as one 12-byte store per lane: the 16 lanes of a pixel row write 192 contiguous bytes = three

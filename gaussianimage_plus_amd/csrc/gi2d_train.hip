@@ -1359,7 +1359,10 @@ static UpdateArgs update_args_of(const gi2d_train_state *s, const FastWs &w, int
     u.next.clip_coe = s->clip_coe;
     u.next.num_tiles_hit = s->num_tiles_hit;
     u.next.lists = w.lists;
-    u.next.inbox = w.inbox_recs;
+    // the tiles' inboxes: the caller's own buffer, for an image small enough to use them (single-image calls only look)
+    u.next.inbox = (s->inbox != nullptr && inbox_bytes((long long)tx * ty) > 0 && s->inbox_bytes >= inbox_bytes((long long)tx * ty))
+                       ? (float4 *)s->inbox
+                       : nullptr;
     u.next.prev_box = w.prev_box;
     u.next.recs = rec_sets(w, n);
     u.next.status = s->status;
@@ -1577,10 +1580,11 @@ int gi2d_train_steps(const gi2d_train_state *s, const double *lr, double beta1, 
         // (the inboxes: one image of at most GI2D_INBOX_MAX_TILES tiles, i.e. a tile pass of the general form throughout;
         // the update kernel delivers through them when another iteration follows, and the tile pass of that iteration --
         // never the first of a call, which follows the projection kernel -- is the one built to take entrants in)
-        const bool small_image = tiles <= GI2D_INBOX_MAX_TILES;
+        // ... and whose caller brought the inboxes' buffer: gi2d_train_state::inbox)
+        const bool small_image = u.next.inbox != nullptr;
         rc = fast_forward_backward_form(n, tx, ty, (unsigned)s->img_width, (unsigned)s->img_height, nullptr, nullptr,
                                         s->gt, grad_scale, s->tile_sse, s->workspace, s->workspace_bytes, s->status,
-                                        s->out_img, st_, form, it > 0 && small_image);
+                                        s->out_img, st_, form, it > 0 ? u.next.inbox : nullptr);
         if (rc != GI2D_OK) return rc;
         AdamStep a[3];
         for (int q = 0; q < 3; ++q) a[q] = make_adam_step(lr[q], beta1, beta2, s->beta3, eps, step, adan_opt);
@@ -1607,6 +1611,7 @@ int gi2d_train_step(const gi2d_train_state *s, const double *lr, double beta1, d
 
 // ---------------------------------------------------------------------------------------------- several images per launch
 size_t gi2d_batch_bytes(int num_images) { return carve_batch(nullptr, num_images).bytes; }
+size_t gi2d_train_inbox_bytes(int tiles_x, int tiles_y) { return inbox_bytes((long long)tiles_x * tiles_y); }
 
 int gi2d_train_steps_batched(int num_images, const gi2d_train_state *const *states, void *batch, size_t batch_bytes,
                              const double *lr, double beta1, double beta2, float eps, int first_step, int count,

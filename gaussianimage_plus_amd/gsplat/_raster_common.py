@@ -13,20 +13,28 @@ remove).  A workspace is checked synchronously on its first use and whenever the
 pass was above half the row capacity; otherwise the 16 status bytes travel to pinned memory behind the kernels and are
 read when the host next touches the workspace (the backward, or the next forward): by then they have arrived, and the
 GPU never idles.  An overflow found that way -- a row going from <= 512 to > 1024 candidates between two consecutive
-calls -- raises (see _settle); GI2D_WRAPPER_SYNC=1 restores the synchronous check.
+calls -- is repaired where the call it belongs to is still open: the BACKWARD of that forward re-runs the forward on the
+capacity-free ops, writes the exact image into the tensor the forward handed out, and differentiates the exact lists
+(_repair_late_overflow; the reference has no capacity and never raises on population, rasterize_sum_plus.py:98-172).
+Only a forward whose graph is gone -- a no-grad render, found by the next call on its workspace -- can still only be
+reported (see _settle); GI2D_WRAPPER_SYNC=1 restores the synchronous check.
 
 No forward stays unchecked: a workspace with a posted status sits in `_pending` until it is settled -- by its own next
 use, by ANY later forward / backward of the wrappers once its copy has landed (`_settle_landed`: an event query, no
 wait), by `settle_all()` (blocking; launch.fit_image calls it behind its last evaluation render), or by the
-interpreter-exit hook, which can only report.  And the "slowly moving rows" premise is only trusted within one run of
-calls: a workspace that was not used for more than IDLE_RECHECK_S seconds (the pool hands a workspace to whichever
-scene of its shape comes next -- train.py's next image, a checkpoint just loaded) is checked synchronously again."""
+interpreter-exit hook, which can only report.  And the "slowly moving rows" premise is only trusted for ONE scene: the
+pool hands a workspace to whichever scene of its shape comes next (train.py's next image, a checkpoint just loaded, a
+model after prune / growth), so a forward whose colour / opacity tensors are not the ones the workspace's last forward
+saw -- storage address, shape, or a lease taken by another autograd node in between -- is checked synchronously again
+(_scene_identity; a model's parameters keep their storage from iteration to iteration and change it exactly at those
+events).  No wall clock is involved: a host stall does not force a check, a fast hand-over does not skip one."""
 from __future__ import annotations
 
 import atexit
 import os
 import sys
-import time
+import warnings
+import weakref
 
 import torch
 
@@ -36,7 +44,6 @@ BLOCK = 16
 # GI2D_WRAPPER_SYNC=1: wait for the status words of every forward before its image is handed on (the behaviour of
 # rounds 1-3: one GPU queue drain per iteration).  Default: see FastWorkspace.must_check_now / _settle.
 SYNC_EVERY_FORWARD = os.environ.get("GI2D_WRAPPER_SYNC", "0") == "1"
-IDLE_RECHECK_S = 0.05  # a workspace idle for longer may have changed hands: its next pass is checked at once
 _capacity = {}   # exact path: (device index, N, H, W) -> intersection capacity
 _pool = {}       # fast path: (device index, N, tiles_x, tiles_y) -> idle FastWorkspace objects
 _pending = []    # workspaces whose last forward posted its status words and has not been looked at yet
@@ -67,22 +74,33 @@ def _acquire(xys, num_points, tile_bounds) -> _Lease:
     return _Lease(key, ws)
 
 
-def _settle(ws, what: str) -> None:
+def _scene_identity(colors, opacity):
+    """What tells one scene from the next on a pooled workspace: the storage and shape of the model's colour / opacity
+    tensors (parameters keep their storage across the iterations of a fit; a new image, a loaded checkpoint, prune and
+    growth all allocate new ones)."""
+    return (colors.data_ptr(), tuple(colors.shape), opacity.data_ptr(), tuple(opacity.shape))
+
+
+def _settle(ws, what: str, repairable: bool = False) -> bool:
     """Look at the status words of the last forward on `ws` that has not been checked yet.  A tile row that overflowed
     there (more than 1024 candidate gaussians in one 16x16 tile, on a workspace whose fullest row was at most half that
     one call earlier) means an image has already been handed on that was rendered from a truncated tile list: the
-    workspace is emptied, every later call on it is checked before its result is used -- and falls back to the
-    capacity-free ops -- and the caller is told."""
+    workspace is emptied and every later call on it is checked before its result is used (exact fallback).  Returns True
+    for such an overflow when the caller can still repair it (`repairable`: the backward of that very forward);
+    otherwise the caller is told by an exception -- the image is gone, nothing can be re-rendered into it."""
     if ws in _pending:
         _pending.remove(ws)
     st = ws.settle()
     if st is not None and st[1]:
         ws.reset()
+        if repairable:
+            return True
         raise RuntimeError(
             f"gsplat drop-in: a tile row overflowed (> {_C.fast_tile_capacity()} candidate gaussians in one tile) in {what}, "
             "whose status was read one call late; that call's image was rendered from a truncated tile list. The "
             "workspace has been emptied and checks every call from now on (exact fallback). Re-run the step, or set "
             "GI2D_WRAPPER_SYNC=1 to check every forward before its result is used.")
+    return False
 
 
 def _settle_landed(skip=None) -> None:
@@ -172,10 +190,10 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
     if not capturing:
         _settle(ws, "the previous forward on this workspace")
         _settle_landed(skip=ws)
-        now = time.monotonic()
-        if now - getattr(ws, "last_use", now) > IDLE_RECHECK_S:
-            ws.fullest = None  # may serve another scene now: checked before its image is handed on
-        ws.last_use = now
+        scene = _scene_identity(colors, opacity)
+        if getattr(ws, "scene", scene) != scene:
+            ws.fullest = None  # serves another scene now: checked before its image is handed on
+        ws.scene = scene
     # "not a single intersection -> background image" (rasterize_sum_plus.py:110-118) is decided on the device
     out_img = _C.fast_forward(ws, xys, radii, conics, colors, opacity, img_height, img_width, radius_clip,
                               background=background)
@@ -207,8 +225,34 @@ def forward_impl(ctx, plus: bool, xys, depths, radii, conics, num_tiles_hit, col
     ctx.BLOCK_H, ctx.BLOCK_W = BLOCK_H, BLOCK_W
     ctx.radius_clip = float(radius_clip)
     ctx.lease = lease
+    ctx.plus, ctx.background = plus, background
+    # (a weak reference: the autograd node must not keep its own output alive)
+    ctx.out_ref = weakref.ref(out_img) if (lease is not None and not capturing) else None
     ctx.save_for_backward(xys, radii, conics, colors, opacity)
     return out_img, final_Ts, cnt_gs_counts
+
+
+def _repair_late_overflow(ctx, xys, radii, conics, colors, opacity):
+    """The forward this backward belongs to overflowed a tile row and was found one call late: run it again on the
+    capacity-free ops (as the synchronous check of forward_impl would have), put the exact image into the tensor that
+    was handed out, and leave the exact lists for the backward.  What cannot be repaired is a loss VALUE the caller has
+    already formed from the truncated image -- the incoming gradient belongs to that image; for a loss that is linear in
+    the image the result is exact, otherwise the step is one optimizer step off a truncated tile -- hence the warning."""
+    tile_bounds = tile_bounds_of(ctx.img_height, ctx.img_width, ctx.BLOCK_H, ctx.BLOCK_W)
+    out_img, final_idx, gids, bins, m = _exact_forward(
+        ctx.plus, xys, radii, conics, colors, opacity, ctx.img_height, ctx.img_width, tile_bounds,
+        (ctx.BLOCK_W, ctx.BLOCK_H, 1), (ctx.img_width, ctx.img_height, 1), ctx.background, ctx.radius_clip, False)
+    handed = ctx.out_ref() if ctx.out_ref is not None else None
+    if handed is not None:
+        handed.data.copy_(out_img)
+    ctx.exact = (gids if m >= 1 else None, bins, final_idx)
+    ctx.lease = None
+    warnings.warn(
+        f"gsplat drop-in: a tile row overflowed (> {_C.fast_tile_capacity()} candidate gaussians in one tile) in this "
+        "backward's forward, found one call late: the forward was re-run on the capacity-free ops, its image tensor now "
+        "holds the exact render and the gradients are those of the exact tile lists. A loss value already computed from "
+        "the first render saw a truncated tile. The workspace checks every call from now on; GI2D_WRAPPER_SYNC=1 checks "
+        "every forward before its result is used.", RuntimeWarning, stacklevel=3)
 
 
 def backward_impl(ctx, plus: bool, v_out_img):
@@ -216,6 +260,10 @@ def backward_impl(ctx, plus: bool, v_out_img):
     if v_out_img is None:  # (set_materialize_grads(False): the image took no part in the loss)
         v_out_img = torch.zeros(ctx.img_height, ctx.img_width, 3, device=xys.device)
     v_out_img = v_out_img.contiguous()
+    if ctx.exact is None and not torch.cuda.is_current_stream_capturing():
+        if _settle(ctx.lease.ws, "this backward's forward", repairable=True):
+            _repair_late_overflow(ctx, xys, radii, conics, colors, opacity)
+        _settle_landed(skip=ctx.lease.ws if ctx.lease is not None else None)
     if ctx.exact is not None:
         gids, bins, final_idx = ctx.exact
         if gids is None:  # rasterize_sum_plus.py:198-202: no intersection, zero gradients
@@ -226,9 +274,6 @@ def backward_impl(ctx, plus: bool, v_out_img):
             ctx.img_height, ctx.img_width, gids, bins, xys, radii, conics, colors, opacity, final_idx, v_out_img,
             ctx.radius_clip, with_abs=not plus)
     else:
-        if not torch.cuda.is_current_stream_capturing():
-            _settle(ctx.lease.ws, "this backward's forward")
-            _settle_landed(skip=ctx.lease.ws)
         # without a single intersection the tile pass finds empty rows and the per-gaussian sums are zeros
         v_xy, v_conic, v_colors, v_opacity, v_abs = _C.fast_backward(
             ctx.lease.ws, xys, radii, v_out_img, ctx.img_height, ctx.img_width, ctx.radius_clip, with_abs=not plus)

@@ -237,10 +237,7 @@ int gi2d_rasterize_backward_reduce(int num_points, const float *xys, const int32
  * index work; the same per-pair arithmetic).  Contract:
  *   - workspace: gi2d_fast_workspace_bytes(N, tiles_x, tiles_y) bytes, emptied ONCE with gi2d_fast_workspace_init.
  *     It holds STATE between calls: persistent per-tile id lists, the tile box every gaussian was last binned with,
- *     and one 64-byte record per gaussian (centre, conic, colour, opacity, cull extents, tile box); for an image of
- *     at most 1536 tiles also 128 KB of sparsely used address space per tile (192 MiB at 768x512: the tiles' inboxes,
- *     through which gi2d_train_steps delivers a gaussian that has entered a tile -- DESIGN.md 3.5; no call returns with
- *     anything left in them).  A binning call
+ *     and one 64-byte record per gaussian (centre, conic, colour, opacity, cull extents, tile box).  A binning call
  *     (gi2d_fast_bin, gi2d_fast_project_bin, the ..._project_bin form of the reduce call) appends a gaussian only to
  *     the tiles it has ENTERED since the previous binning call and refreshes its record; the tile pass drops the
  *     entries that left and keeps every list in ascending id order.  Results are those of a from-scratch binning
@@ -441,7 +438,17 @@ typedef struct gi2d_train_state {
      * min(*num_points_dev, num_points) rows, and gi2d_train_prune / gi2d_train_grow change the count without the host
      * having to know it. */
     int32_t *num_points_dev;
+    /* the tiles' inboxes (NULL = none): gi2d_train_inbox_bytes(tiles_x, tiles_y) bytes of scratch, uninitialised, that
+     * gi2d_train_steps on ONE image uses between the iterations of a call to let a gaussian enter a tile without a
+     * returning atomic (128 KB of sparsely touched address space per tile, 192 MiB at 768x512, images of
+     * at most 1536 tiles).  Optional: without it the same call appends through the row headers, bit-identical results,
+     * the update kernel ~0.7 us slower at N = 50 000.  Nothing else looks at it (batches, the quantised iterations,
+     * gi2d_train_render); no call returns with anything left in it. */
+    void *inbox;
+    size_t inbox_bytes;
 } gi2d_train_state;
+/* Size of gi2d_train_state::inbox for that tile grid; 0 for a grid that does without (more than 1536 tiles). */
+size_t gi2d_train_inbox_bytes(int tiles_x, int tiles_y);
 
 /* Quantisation-aware fitting.  Covariance model (kind 1, Adam): GaussianImage_Covariance.
  * train_iter_quantize / forward_quantize (models/gaussianimage_covariance.py:219-247,384-410) after
