@@ -209,6 +209,10 @@ def run_rank(args):
         kernel = "gi2d::fast_fwdbwd_kernel<1, 1, false> + gi2d::fast_fwdbwd_kernel<1, 2, false>" if two else \
             ("gi2d::fast_fwdbwd_kernel<1, 0, true>" if fit.tx * fit.ty <= 1536 else "gi2d::fast_fwdbwd_kernel<1, 0, false>")
         traffic, traffic_src = pmc_traffic(kernel, n, h, w)
+        # the counters were collected at the intersection count of THAT run (the scene drifts while it trains, and a
+        # 20-step run sits at another M than a 200-step one): the wasted-traffic ratio is formed like for like
+        traffic_m = stored_num_intersects(n, h, w)
+        traffic_ratio = (traffic / (80 * traffic_m + 36 * h * w + 36 * n)) if (traffic and traffic_m) else None
         line = {
             "metric": f"training iters/sec (fwd+bwd rasterize) at N Gaussians, {w}x{h}",
             "value": value,
@@ -239,6 +243,7 @@ def run_rank(args):
             "roofline": {
                 "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_measured_at_num_intersects": traffic_m, "traffic_over_algorithmic_at_that_count": traffic_ratio,
                 "algorithmic_bytes_per_launch": pair_bytes, "avg_kernel_us": avg_us,
                 "min_kernel_us": float(np.min(kernel_us)), "kernel_samples": len(kernel_us),
                 "note": "not HBM-bound: each staged gaussian is reused by up to 256 pixels, so the tile pass is bound by "
@@ -527,6 +532,20 @@ def pmc_traffic(kernel, n, h, w, images_per_launch=None):
                      (f", {images_per_launch} images per launch" if images_per_launch else "")
     except (OSError, KeyError, ValueError, TypeError) as e:
         return None, f"none: profiles/traffic.json unreadable ({type(e).__name__})"
+
+
+def stored_num_intersects(n, h, w, images_per_launch=None):
+    """The intersection count M of the run whose counters profiles/traffic.json holds for this workload (None: unknown)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for wl in t["workloads"]:
+            c = wl.get("config") or {}
+            if (c.get("num_points"), c.get("height"), c.get("width")) == (n, h, w) and \
+                    c.get("images_per_launch") == images_per_launch:
+                return c.get("num_intersects_rank0")
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None
 
 
 def _stored_kernel(kernel, n, h, w, images_per_launch=None):

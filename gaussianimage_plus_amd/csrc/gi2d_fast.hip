@@ -234,8 +234,13 @@ __global__ __launch_bounds__(256) void fast_ws_init_kernel(int num_tiles, int n,
 // `mark_big` (batched launches): the general form marks the rows above GI2D_SMALL_CAP too -- batch_pass_end counts them.
 // INBOX: the head takes entrants out of the tile's inbox (gi2d_fast_internal.h::Inbox) -- the one launch of one image,
 // which is what follows the one kernel that puts any in; every other form is built without that code.
-template <int MODE, int PHASE, bool INBOX = false>
-__device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int slot, bool first, bool mark_big = false) {
+// WTMODE: gradient rows and image leave as write-through stores (gi2d_raster_core.h::store16) -- 0 never (batches, large
+// images: their stores overlap other tiles' work and compete for the memory system's slots: +28 % at K = 24), 1 always
+// (the INBOX instantiation: one image of at most one residency round), 2 when `wt` says so (the general-form kernel of a
+// single image: the launch code knows the tile count).
+template <int MODE, int PHASE, bool INBOX = false, int WTMODE = 0>
+__device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int slot, bool first, bool mark_big = false,
+                                                    bool wt = false) {
     constexpr int CAP = PHASE == 1 ? GI2D_SMALL_CAP : GI2D_TILE_LIST_CAP;
     __shared__ FusedLdsT<CAP> sm;
     int tile;
@@ -257,8 +262,14 @@ __device__ __forceinline__ void tile_pass_workgroup(const TilePassArgs &a, int s
         if (PHASE == 1 && big) return;
     }
     // (phase 2 loops over tiles: its loop keeps the lane's invariants alive, so the forward's trips are not unrolled there)
-    fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL, INBOX>(sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g,
-                          a.partial_big, a.status, a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr, ib);
+    if (WTMODE == 1 || (WTMODE == 2 && wt))  // workgroup-uniform (launch-uniform)
+        fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL, INBOX, WTMODE != 0>(
+            sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g, a.partial_big, a.status,
+            a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr, ib);
+    else
+        fused_tile<MODE, CAP, PHASE == 2 ? 1 : GI2D_FWD_UNROLL, INBOX, false>(
+            sm, tile, a.tiles_x, a.tiles_y, a.img_w, a.img_h, recs, a.lists, a.tile_bins, a.partial_g, a.partial_big, a.status,
+            a.out_img, a.vsrc, a.grad_scale, a.tile_sse, hr, ib);
 }
 
 // Phase 2 finds nothing to do on the scenes the two-phase form is for (large images: sparse rows), and ten thousand
@@ -310,8 +321,10 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
         }
     } else {
         // (a large image in the general form marks its fuller tiles too: single_pass_end counts them)
-        tile_pass_workgroup<MODE, PHASE, INBOX>(a, (int)blockIdx.x, blockIdx.x == 0,
-                                                a.tiles_x * a.tiles_y > GI2D_TWO_PHASE_TILES);
+        // (written through where the whole launch is one residency round of the chip: see tile_pass_workgroup)
+        const int tiles = a.tiles_x * a.tiles_y;
+        tile_pass_workgroup<MODE, PHASE, INBOX, INBOX ? 1 : (PHASE == 0 ? 2 : 0)>(
+            a, (int)blockIdx.x, blockIdx.x == 0, tiles > GI2D_TWO_PHASE_TILES, tiles <= GI2D_TWO_PHASE_TILES);
     }
 }
 

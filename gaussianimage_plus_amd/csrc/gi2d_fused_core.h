@@ -121,7 +121,8 @@ static_assert(offsetof(FusedLdsSmall, slot) >= offsetof(FusedLdsSmall, part) &&
 //         grad_scale * (clamp(out) - gt) where the clamp passes gradient (models/gaussianimage_cholesky.py:307-310
 //         with loss_type "L2"), and tile_sse[tile] receives the tile's sum of squared errors (fixed order).
 // INBOX: see tile_list_head.
-template <int MODE, int CAP = GI2D_TILE_LIST_CAP, int FWD_UNROLL = GI2D_FWD_UNROLL, bool INBOX = false>
+// WT: gradient rows and image leave as write-through stores (gi2d_raster_core.h::store16): the single-image launches.
+template <int MODE, int CAP = GI2D_TILE_LIST_CAP, int FWD_UNROLL = GI2D_FWD_UNROLL, bool INBOX = false, bool WT = false>
 __device__ __forceinline__ void fused_tile(
     FusedLdsT<CAP> &sm, int tile, int tiles_x, int tiles_y, int img_w, int img_h, const float4 *__restrict__ recs,
     int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
@@ -132,7 +133,9 @@ __device__ __forceinline__ void fused_tile(
     const int pool_rows = tiles_x * tiles_y * GI2D_TILE_LIST_CAP;  // rows of `partial_big`, the row pool (PrevBox)
     static_assert(CAP <= GI2D_TILE_LIST_CAP, "at most the reference's 256 entries of a tile are rasterized");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int lx = tid & 15, ly = tid >> 4;  // == (lane & 15, wv * 4 + (lane >> 4)): wave wv owns pixel rows 4wv..4wv+3
+    // wave wv owns pixel rows 4wv..4wv+3; within a row of 16 lanes the pixel a lane holds after the forward is
+    // fwd_lane_col (gi2d_raster_core.h: one entry for two adjacent pixels per lane, the parities meet at the end)
+    const int lx = fwd_lane_col(tid), ly = tid >> 4;
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
     const bool inside = (i < img_h) && (j < img_w);
     const size_t pix = (size_t)i * img_w + j;
@@ -184,9 +187,9 @@ __device__ __forceinline__ void fused_tile(
             } else if (float4 *row = partial_row(s.slot, partial_g, partial_big, pool_rows, status)) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                row[0] = z;
-                row[1] = z;
-                row[2] = z;
+                store16<WT>(row, z, partial_g);  // (the row pool lies behind the gaussian-major rows: carve_fast)
+                store16<WT>(row + 1, z, partial_g);
+                store16<WT>(row + 2, z, partial_g);
             }
         }, ib, head_row);
     GI2D_TRACE(2);
@@ -213,7 +216,7 @@ __device__ __forceinline__ void fused_tile(
             r.cb = c.x, r.lim = (unsigned)__float_as_int(c.y);
             return r;
         },
-        (float)j, (float)i, o0, o1, o2, last_unused);
+        tx0, (float)i, o0, o1, o2, last_unused);
     GI2D_TRACE(5);
 #if defined(GI2D_STOP_AFTER) && GI2D_STOP_AFTER == 2
     if (L >= 0) {
@@ -221,7 +224,10 @@ __device__ __forceinline__ void fused_tile(
         return;
     }
 #endif
-    fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
+    if (WT && (img_w & 3) == 0 && (tx + 1) * GI2D_TILE <= img_w && (ty + 1) * GI2D_TILE <= img_h)  // tile-uniform
+        fwd_store_pixels_wt(o0, o1, o2, tx, ty, img_w, mybuf, out_img);
+    else
+        fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
 
     // ---- this pixel's gradient
     float v0 = p0, v1 = p1, v2 = p2, sse = 0.f;
@@ -240,6 +246,9 @@ __device__ __forceinline__ void fused_tile(
             }
             v0 = v[0], v1 = v[1], v2 = v[2];
         }
+        // summed in COLUMN order within each pixel row, as every round has (the per-tile squared errors decide the
+        // best-model snapshot: a fit stays bit-identical to round 5's): lane r of a row fetches column r's term
+        sse = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * ((tid & 48) | fwd_col_lane(tid & 15)), __float_as_int(sse)));
         sse = wave_sum_dpp(sse);
         if (lane == 0) sm.sse_w[wv] = sse;
     }
@@ -259,7 +268,7 @@ __device__ __forceinline__ void fused_tile(
     bwd_publish_pixel(sm, lx, ly, v0, v1, v2, 0.f);
     float4 *dst = nullptr;
     if (tid < len) dst = partial_row(sm.slot[tid], partial_g, partial_big, pool_rows, status);
-    bwd_run_tile<false, false, true>(sm, len, cull, 0, tx0, ty0, dst, scan_incl, sm.scan_w);
+    bwd_run_tile<false, false, true, WT>(sm, len, cull, 0, tx0, ty0, dst, scan_incl, sm.scan_w, partial_g);
     GI2D_TRACE(10);
     GI2D_TRACE_VALUE(14, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_REG_HW_ID
     GI2D_TRACE_VALUE(15, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));  // HW_REG_XCC_ID

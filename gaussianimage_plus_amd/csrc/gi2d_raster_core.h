@@ -71,6 +71,41 @@ __device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, 
     return cull_word_of(box, tx0, ty0, img_h, clamp);
 }
 
+// WT: WRITE-THROUGH stores (`sc1`: the 16 bytes go to memory now and the line is dropped from this XCD's L2).  A
+// kernel's dirty L2 lines are written back when it ends and the next kernel of the stream waits for that (the guide's
+// price list: + bytes / 6 TB/s per dependent boundary -- 2 us behind the ~12 MB of gradient rows and image a single-image
+// tile pass leaves); written through, the bytes leave while the kernel still computes.  The consumer of the rows (the
+// update kernel: other CUs, all XCDs) reads them from memory either way.  Measured (tools/ab_trace.sh): the single-image
+// tile pass -0.56 us, the update kernel behind it -0.24 us -- and a 24-image launch, whose stores already overlap
+// other tiles' work and which is short of memory-system slots, +28 %: the batched kernels store plainly.
+// The stores are raw BUFFER stores with the sc1 cache-policy bit (the compiler sees them: hazards and waits are its
+// business, which they are not with inline assembly); `base`: a wave-uniform pointer at or below every address stored to
+// (the buffer's resource lives in scalar registers), within 2 GB of it.
+typedef unsigned int wt_u4 __attribute__((ext_vector_type(4)));
+#define GI2D_WT_AUX 16 /* cache policy of the raw buffer store builtins on gfx94x / gfx950: bit 4 = sc1 */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_resource(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ unsigned wt_offset(const void *p, const void *base) {
+    return (unsigned)(reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(base));
+}
+template <bool WT>
+__device__ __forceinline__ void store16(float4 *p, const float4 v, const void *base) {
+    if constexpr (WT) {
+        const wt_u4 r = {(unsigned)__float_as_int(v.x), (unsigned)__float_as_int(v.y), (unsigned)__float_as_int(v.z),
+                         (unsigned)__float_as_int(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(r, wt_resource(base), (int)wt_offset(p, base), 0, GI2D_WT_AUX);
+    } else {
+        *p = v;
+    }
+}
+// (before a lane re-reads a row it stored write-through earlier in the same kernel: the store and the load travel
+// different ways)
+template <bool WT>
+__device__ __forceinline__ void wt_drain() {
+    if constexpr (WT) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+}
+
 // =========================================================================================== forward
 // Wave w owns pixel rows 4w..4w+3 (a "strip").  A gaussian's alpha >= 1/255 box (cull_word) typically spans ~8 columns
 // at 50 000 gaussians per 768x512 image, i.e. one half of a strip more often than both, so each wave keeps TWO ascending
@@ -126,26 +161,25 @@ __device__ __forceinline__ int fwd_col_lane(int c) { return ((c & 1) << 3) | ((c
 #ifndef GI2D_FWD_UNROLL
 #define GI2D_FWD_UNROLL 2 /* trips per loop body: two let the LDS reads of one trip overlap the arithmetic of the other */
 #endif
-// `mine`: this lane's first entry of the chunk (A array of its half's list + 4 floats for the odd parity); m: entries of
-// the chunk (both parities); px2: x of the lane's two pixels, py: their y.  a0..a2: (pixel A, pixel B) per channel.
+// `mine_a`, `mine_c`: this lane's first entry of the chunk in the A and C arrays of its half's list (the B array lies
+// 4 CHUNK floats behind A); m: entries of the chunk (both parities); px2: x of the lane's two pixels, py: their y.
+// a0..a2: (pixel A, pixel B) per channel.
 template <bool NEED_FIDX, bool CLAMP, int UNROLL = GI2D_FWD_UNROLL>
-__device__ __forceinline__ void fwd_trips(const float *mine, int m, const v2f px2, const float py, v2f &a0, v2f &a1,
-                                          v2f &a2, int &last_a, int &last_b) {
+__device__ __forceinline__ void fwd_trips(const float *mine_a, const float *mine_c, int m, const v2f px2, const float py,
+                                          v2f &a0, v2f &a1, v2f &a2, int &last_a, int &last_b) {
     constexpr int CW = GI2D_FWD_CW(NEED_FIDX);
-    const float4 *qa = reinterpret_cast<const float4 *>(mine);
-    const float4 *qb = reinterpret_cast<const float4 *>(mine + 4 * GI2D_FWD_CHUNK);
-    // (the C array starts 8 CHUNK floats behind A; an odd-parity lane is 4 floats into A and CW floats into C)
-    const float *qc0 = mine + 8 * GI2D_FWD_CHUNK;
+    const float4 *qa = reinterpret_cast<const float4 *>(mine_a);
+    const float4 *qb = reinterpret_cast<const float4 *>(mine_a + 4 * GI2D_FWD_CHUNK);
 #pragma unroll UNROLL
     for (int t = 0; t < m; t += 2) {
-        const float4 q0 = qa[t], q1 = qb[t];  // entries t + parity: two float4 per trip and array
+        const float4 q0 = qa[t], q1 = qb[t];  // entry t + parity: the arrays are in list order, one float4 per entry
         float cb, kf = 0.f;
         unsigned lim;
         if (NEED_FIDX) {
-            const float4 q2 = *reinterpret_cast<const float4 *>(qc0 + (CW - 4) * 0 + t * CW - (mine - mine));
+            const float4 q2 = *reinterpret_cast<const float4 *>(mine_c + t * CW);
             cb = q2.x, lim = (unsigned)__float_as_int(q2.y), kf = q2.z;
         } else {
-            const float2 q2 = *reinterpret_cast<const float2 *>(qc0 + t * CW);
+            const float2 q2 = *reinterpret_cast<const float2 *>(mine_c + t * CW);
             cb = q2.x, lim = (unsigned)__float_as_int(q2.y);
         }
         const float gx = q0.x, gy = q0.y, ha = q0.z, hb = q0.w, hc = q1.x, op = q1.y, cr = q1.z, cg = q1.w;
@@ -212,9 +246,8 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
 
     const int r = lane & 15;
     const int parity = r >> 3, my_half = (r >> 2) & 1;  // which entries of which list this lane walks
-    const float *mine = buf + my_half * HALF + parity * 4;
-    const float *mine_c_fix = nullptr;
-    (void)mine_c_fix;
+    const float *mine_a = buf + my_half * HALF + parity * 4;
+    const float *mine_c = buf + my_half * HALF + 8 * GI2D_FWD_CHUNK + parity * CW;
     const int bh = lane >> 5, be = lane & 31;      // build role: lanes 0-31 copy left entries, 32-63 right entries
     const unsigned char *blist = bh ? right : left;
     const int bcnt = bh ? n_right : n_left;
@@ -240,9 +273,9 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
         __builtin_amdgcn_wave_barrier();
         const int m = min(GI2D_FWD_CHUNK, n_max - c0);
         if (clamp_any)
-            fwd_trips<NEED_FIDX, true, UNROLL>(mine, m, px2, py, a0, a1, a2, last_a, last_b);
+            fwd_trips<NEED_FIDX, true, UNROLL>(mine_a, mine_c, m, px2, py, a0, a1, a2, last_a, last_b);
         else
-            fwd_trips<NEED_FIDX, false, UNROLL>(mine, m, px2, py, a0, a1, a2, last_a, last_b);
+            fwd_trips<NEED_FIDX, false, UNROLL>(mine_a, mine_c, m, px2, py, a0, a1, a2, last_a, last_b);
         __builtin_amdgcn_wave_barrier();
     }
     // even + odd list positions of each pixel (the two partial sums every earlier layout formed, in that order)
@@ -260,18 +293,35 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
 }
 
 // A tile's RGB leaves as one 12-byte store per lane: the 16 lanes of a pixel row write 192 contiguous bytes = three
-// whole 64-byte lines in one instruction, which is as good for the memory system as 16-byte stores of rows transposed
-// through LDS (the form of rounds 1-3) and costs a third of its instructions.
+// whole 64-byte lines in one instruction (in the lane order of fwd_lane_col), which is as good for the memory system as
+// 16-byte stores of rows transposed through LDS (the form of rounds 1-3) and costs a third of its instructions.
 __device__ __forceinline__ void fwd_store_pixels(float o0, float o1, float o2, int tx, int ty, int img_w, int img_h,
                                                  float *__restrict__ out_img) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
+    const int lx = fwd_lane_col(lane), ly = wv * 4 + (lane >> 4);
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
     if (i < img_h && j < img_w) {
         const size_t pix = (size_t)i * img_w + j;
         out_img[3 * pix + 0] = o0;
         out_img[3 * pix + 1] = o1;
         out_img[3 * pix + 2] = o2;
+    }
+}
+// The same WRITTEN THROUGH (store16<true>): whole 16-byte pieces, so the wave's four pixel rows (4 x 192 bytes) go
+// through `buf` -- 192 floats of the wave's own pair buffer, free once its trips are done -- and lanes 0..47 store one
+// float4 each.  Needs rows that start on 16 bytes and a tile that lies inside the image (the caller checks: img_w % 4 == 0,
+// full tile); otherwise fwd_store_pixels.
+__device__ __forceinline__ void fwd_store_pixels_wt(float o0, float o1, float o2, int tx, int ty, int img_w,
+                                                    float *buf, float *__restrict__ out_img) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *mine = buf + 48 * (lane >> 4) + 3 * fwd_lane_col(lane);
+    mine[0] = o0, mine[1] = o1, mine[2] = o2;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 48) {
+        const int row = lane / 12, piece = lane - 12 * row;
+        const float4 v = *reinterpret_cast<const float4 *>(buf + 48 * row + 4 * piece);
+        const size_t pix = (size_t)(ty * GI2D_TILE + wv * 4 + row) * img_w + tx * GI2D_TILE;
+        store16<true>(reinterpret_cast<float4 *>(out_img + 3 * pix) + piece, v, out_img);
     }
 }
 
@@ -311,7 +361,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
                                                      int32_t *__restrict__ final_idx,
                                                      float *__restrict__ out_img) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int lx = lane & 15, ly = wv * 4 + (lane >> 4);
+    const int lx = fwd_lane_col(lane), ly = wv * 4 + (lane >> 4);  // the pixel this lane holds after the forward
     const int j = tx * GI2D_TILE + lx, i = ty * GI2D_TILE + ly;
     const bool inside = (i < img_h) && (j < img_w);
     float *mybuf = reinterpret_cast<float *>(sm.pairbuf) + wv * GI2D_FWD_PAIRBUF_OF(NEED_FIDX);
@@ -327,7 +377,7 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
             r.cb = c.x, r.lim = (unsigned)__float_as_int(c.y);
             return r;
         },
-        (float)j, (float)i, o0, o1, o2, last_k);
+        (float)(tx * GI2D_TILE), (float)i, o0, o1, o2, last_k);
     int cur_idx = last_k < 0 ? 0 : list_base + last_k;  // forward.cu:497,550: 0 when nothing landed
     if (background_fill) {
         // rasterize_sum_plus.py:110-118: no intersections at all -> image = background
@@ -374,8 +424,9 @@ static_assert(GI2D_BWD_ITEMS == 256, "an item's row in the hand-off buffer is it
 #define GI2D_BWD_OCC 5 /* waves per SIMD the register allocator must leave room for; measured: 5 (96 VGPRs) beats 6 (80) */
 #endif
 
-template <int PSTR>
-__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR], int tag);
+template <int PSTR, bool WT = false>
+__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR], int tag,
+                                                  const void *wt_base = nullptr);
 
 // Pixel gradients in LDS: one 32-byte record per (row pair p, column c) at pix[2 * (16 p + c)]:
 //   (vox_A, vox_B, voy_A, voy_B) (voz_A, voz_B, fidx_A, fidx_B)        A = row 2p, B = row 2p + 1
@@ -574,10 +625,10 @@ __device__ __forceinline__ void bwd_item_columns(const BwdItemIn &in, BwdItemAcc
     } while (rec <= in.rec_end);
 }
 
-template <bool WITH_ABS, bool USE_FIDX = true, bool PRESCANNED = false, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
+template <bool WITH_ABS, bool USE_FIDX = true, bool PRESCANNED = false, bool WT = false, class Lds = BwdLds<WITH_ABS, USE_FIDX>>
 __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, int list_base, float tx0, float ty0,
                                              float4 *__restrict__ dst, unsigned long long prescan_incl = 0ull,
-                                             const int *prescan_wsum = nullptr) {
+                                             const int *prescan_wsum = nullptr, const void *wt_base = nullptr) {
     constexpr int PSTR = Lds::PSTR;
     static_assert(!USE_FIDX || Lds::HAS_FIDX, "final_idx is not staged in this LDS layout");
     static_assert(!WITH_ABS || Lds::HAS_RAW, "the |v_xy| sums need the conic as given");
@@ -759,13 +810,14 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
                 acc[8] = (acc[8] != 0.f) ? acc[8] / opac : 0.f;           // v_opacity = sum vis*v_alpha (backward.cu:961)
             }
             if (my_lo < round0) {  // an earlier round already stored part of this row
+                wt_drain<WT>();
                 const float4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
                 acc[0] += d0.x, acc[1] += d0.y, acc[2] += d0.z, acc[3] += d0.w;
                 acc[4] += d1.x, acc[5] += d1.y, acc[6] += d1.z, acc[7] += d1.w;
                 acc[8] += d2.x;
                 if (PSTR > 9) acc[PSTR - 2] += d2.y, acc[PSTR - 1] += d2.z;
             }
-            store_partial_row<PSTR>(dst, acc, tid + 1);
+            store_partial_row<PSTR, WT>(dst, acc, tid + 1, wt_base);
         }
         round0 += GI2D_BWD_ITEMS;
     } while (round0 < n_items);
@@ -774,11 +826,13 @@ __device__ __forceinline__ void bwd_run_tile(Lds &sm, int len, unsigned cull, in
 // `tag`: the entry's rank in its tile's staged list, plus one -- the spare word of the row hands it to the gaussian's
 // lane of the update kernel, which needs it to enter a neighbouring tile through that tile's inbox
 // (gi2d_fast_internal.h::Inbox); rows written as zeros elsewhere carry 0 = no rank.
-template <int PSTR>
-__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR], int tag) {
-    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    dst[2] = make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, __int_as_float(tag));
+template <int PSTR, bool WT>
+__device__ __forceinline__ void store_partial_row(float4 *__restrict__ dst, const float (&acc)[PSTR], int tag,
+                                                  const void *wt_base) {
+    store16<WT>(dst, make_float4(acc[0], acc[1], acc[2], acc[3]), wt_base);
+    store16<WT>(dst + 1, make_float4(acc[4], acc[5], acc[6], acc[7]), wt_base);
+    store16<WT>(dst + 2, make_float4(acc[8], PSTR > 9 ? acc[PSTR - 2] : 0.f, PSTR > 9 ? acc[PSTR - 1] : 0.f, __int_as_float(tag)),
+                wt_base);
 }
 
 __device__ __forceinline__ void add_partial_row(float acc[11], const float4 &p0, const float4 &p1, const float4 &p2);

@@ -340,6 +340,8 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         // what the dealing balances is the SUM of the six tiles a CU holds (371 .. 516 gaussians around a mean of 436
         // on the uniform bench scene when tiles are taken in index order: the slowest CU finishes the tile pass 1.8 us
         // after the median one), which is uneven long before a single tile stands out.
+        // (round 6, measured against the identity order, whose speculative row request in the head always hits: the tile
+        // pass is the same 18.4 us either way, the iteration 0.2 us slower without the dealing)
         if ((step & 15) == 1) compute_tile_order(u.tile_bins, tiles_x * tiles_y, u.next.tile_order, true);
         return;
     }
@@ -440,6 +442,7 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     // (train.py:137 copies it after train_iter returned), from the registers the update left, not read back through
     // memory, one 8- or 12-byte store per row.
     const auto store_rest = [&] {
+        // (stored right behind the update instead, or written through: both measured, neither faster -- DESIGN.md 3.5)
         if (!ADAN) adam_store_rows(P, g, rows);
         if (snapshot) {
             store_row2(best.xyz, g, new_xy.x, new_xy.y);
