@@ -97,6 +97,9 @@ struct FastFwdLds {
 };
 static_assert(sizeof(float4) * GI2D_FWD_PAIRBUF >= sizeof(int) * GI2D_FAST_C, "the id buffer of the list head overlays the pair buffers");
 
+// WT: packed records and image leave as write-through stores (gi2d_raster_core.h::store16): launches of at most one
+// residency round of the chip, whose dirty lines the next kernel of the stream would otherwise wait for.
+template <bool WT>
 __global__ __launch_bounds__(256) void fast_fwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, RecSets rs, const float *__restrict__ background,
     int32_t *__restrict__ lists, int2 *__restrict__ tile_bins,
@@ -126,9 +129,9 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
                 const unsigned mask = cull_word_ext(r.gx, r.gy, br.hx, br.hy, tx0, ty0, img_h, ar.clamp);
                 fwd_stage_entry(sm.f, rank, r, mask, ar.lim);
                 float4 *dst = reinterpret_cast<float4 *>(packed + (size_t)tile * GI2D_TILE_LIST_CAP + rank);
-                dst[0] = make_float4(r.gx, r.gy, r.a, r.b);
-                dst[1] = make_float4(r.c, r.opac, r.cr, r.cg);
-                dst[2] = make_float4(r.cb, __int_as_float(slot), __int_as_float(g), __int_as_float((int)mask));
+                store16<WT>(dst, make_float4(r.gx, r.gy, r.a, r.b), packed);
+                store16<WT>(dst + 1, make_float4(r.c, r.opac, r.cr, r.cg), packed);
+                store16<WT>(dst + 2, make_float4(r.cb, __int_as_float(slot), __int_as_float(g), __int_as_float((int)mask)), packed);
             } else if (row) {
                 // beyond the 256-entry cap: never rasterized, its gradient row must read as zero
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -146,11 +149,11 @@ __global__ __launch_bounds__(256) void fast_fwd_kernel(
     // background image of that corner case is written here, not by a second launch
     const bool nothing = background != nullptr && !tile_pass_has_members(rs);
     if (final_idx)
-        fwd_rasterize_staged<true>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, nothing, background,
-                                   final_Ts, final_idx, out_img);
+        fwd_rasterize_staged<true, WT>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, nothing, background,
+                                       final_Ts, final_idx, out_img);
     else
-        fwd_rasterize_staged<false>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, nothing, background,
-                                    final_Ts, final_idx, out_img);
+        fwd_rasterize_staged<false, WT>(sm.f, len, list_base(tile), tx, ty, img_w, img_h, nothing, background,
+                                        final_Ts, final_idx, out_img);
     if (tid == 0 && L > 0) status[0] = 1;
 }
 
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void fast_background_kernel(int img_w, int img
 }
 
 // ------------------------------------------------------------------------------------- backward
-template <bool WITH_ABS>
+template <bool WITH_ABS, bool WT>
 __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_kernel(
     int tiles_x, int tiles_y, int img_w, int img_h, const int2 *__restrict__ tile_bins,
     const GaussRec *__restrict__ packed, const int32_t *__restrict__ final_idx,
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256, WITH_ABS ? 4 : GI2D_BWD_OCC) void fast_bwd_ker
     float4 *dst = nullptr;
     if (tid < len && slot != GI2D_NO_ROW)  // validated by the forward kernel that wrote the code
         dst = slot >= 0 ? partial_g + GI2D_FAST_ROW * (size_t)slot : partial_big + GI2D_FAST_ROW * (size_t)(-slot - 1);
-    bwd_run_tile<WITH_ABS, false>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst);
+    bwd_run_tile<WITH_ABS, false, false, WT>(sm, len, mask, range.x, (float)(tx * GI2D_TILE), (float)(ty * GI2D_TILE), dst, 0ull,
+                                             nullptr, partial_g);
 }
 
 // Empty state of a workspace: every tile row empty, no gaussian binned, identity tile order.
@@ -927,9 +931,14 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
-    hipLaunchKernelGGL(fast_fwd_kernel, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
-                       (int)w_, (int)h, rec_sets(w, n), background, w.lists, (int2 *)w.tile_bins, w.packed,
-                       w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
+    if (t <= GI2D_TWO_PHASE_TILES)  // one residency round: written through (see the kernel)
+        hipLaunchKernelGGL(fast_fwd_kernel<true>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
+                           (int)w_, (int)h, rec_sets(w, n), background, w.lists, (int2 *)w.tile_bins, w.packed,
+                           w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
+    else
+        hipLaunchKernelGGL(fast_fwd_kernel<false>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
+                           (int)w_, (int)h, rec_sets(w, n), background, w.lists, (int2 *)w.tile_bins, w.packed,
+                           w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
     return check_launch("fast rasterize forward");
 }
 
@@ -1071,14 +1080,17 @@ int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
-    if (with_abs)
-        hipLaunchKernelGGL(fast_bwd_kernel<true>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x,
-                           tiles_y, (int)w_, (int)h, (const int2 *)w.tile_bins, w.packed, final_idx, v_output,
-                           w.partial_g, w.partial_big);
-    else
-        hipLaunchKernelGGL(fast_bwd_kernel<false>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x,
-                           tiles_y, (int)w_, (int)h, (const int2 *)w.tile_bins, w.packed, final_idx, v_output,
-                           w.partial_g, w.partial_big);
+#define GI2D_LAUNCH_BWD(ABS, WT)                                                                                       \
+    hipLaunchKernelGGL((fast_bwd_kernel<ABS, WT>), dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y, \
+                       (int)w_, (int)h, (const int2 *)w.tile_bins, w.packed, final_idx, v_output, w.partial_g,        \
+                       w.partial_big)
+    const bool wt = t <= GI2D_TWO_PHASE_TILES;  // one residency round: the gradient rows are written through
+    if (with_abs) {
+        if (wt) GI2D_LAUNCH_BWD(true, true); else GI2D_LAUNCH_BWD(true, false);
+    } else {
+        if (wt) GI2D_LAUNCH_BWD(false, true); else GI2D_LAUNCH_BWD(false, false);
+    }
+#undef GI2D_LAUNCH_BWD
     return check_launch("fast rasterize backward tiles");
 }
 

@@ -261,7 +261,12 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
         {
             const int e = c0 + be;
             const int k = e < bcnt ? (int)blist[e] : CAP;  // entry CAP: the never-landing padding entry
-            const FwdRec rec = rec_of(k);
+            FwdRec rec = rec_of(k);
+            // (all of the entry in registers before the first store: source and destination are both LDS, and left to
+            // itself the compiler copies in 8-byte pieces, each read waited for before its write is issued -- five
+            // dependent LDS round trips per chunk)
+            asm volatile("" : "+v"(rec.gx), "+v"(rec.gy), "+v"(rec.ha), "+v"(rec.hb), "+v"(rec.hc), "+v"(rec.op), "+v"(rec.cr),
+                         "+v"(rec.cg), "+v"(rec.cb), "+v"(rec.lim));
             reinterpret_cast<float4 *>(bdst)[be] = make_float4(rec.gx, rec.gy, rec.ha, rec.hb);
             reinterpret_cast<float4 *>(bdst + 4 * GI2D_FWD_CHUNK)[be] = make_float4(rec.hc, rec.op, rec.cr, rec.cg);
             if (NEED_FIDX)
@@ -353,7 +358,8 @@ __device__ __forceinline__ void fwd_stage_dummy(FwdLds &sm) {
 // phases 2-4 of the forward for one tile whose `len` (<= 256) entries are staged in ascending order.
 // Must be called by all 256 lanes after a __syncthreads() that follows the staging.
 // NEED_FIDX=false (fast path: nobody consumes final_idx) drops the per-pair index tracking and the store.
-template <bool NEED_FIDX = true>
+// WT: the image leaves written through (store16) where its rows allow 16-byte pieces.
+template <bool NEED_FIDX = true, bool WT = false>
 __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int list_base, int tx, int ty,
                                                      int img_w, int img_h, bool background_fill,
                                                      const float *__restrict__ background,
@@ -391,7 +397,10 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
         if (final_Ts) final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
         if (NEED_FIDX) final_idx[pix] = cur_idx;
     }
-    fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
+    if (WT && (img_w & 3) == 0 && (tx + 1) * GI2D_TILE <= img_w && (ty + 1) * GI2D_TILE <= img_h)  // tile-uniform
+        fwd_store_pixels_wt(o0, o1, o2, tx, ty, img_w, mybuf, out_img);
+    else
+        fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
 }
 
 // ========================================================================================== backward
