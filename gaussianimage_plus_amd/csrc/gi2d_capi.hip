@@ -36,6 +36,9 @@ static std::string dev_switches() {
 #ifdef GI2D_FUSED_TRACE
     add("GI2D_FUSED_TRACE", "");
 #endif
+#ifdef GI2D_UPDATE_STOP
+    add("GI2D_UPDATE_STOP", GI2D_STR(GI2D_UPDATE_STOP));
+#endif
 #ifdef GI2D_INBOX_STATS
     add("GI2D_INBOX_STATS", "");
 #endif

@@ -90,6 +90,18 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Inbox {
     float4 *recs;  // [T][GI2D_INBOX_SLOTS][4]: a record as write_record leaves it, its last word the gaussian's id
 };
+// Access rule of this workspace's shared words, which the bitmap, the row headers and the status words obey:
+//   * within ONE launch a WORD is touched either by atomics only or by plain accesses only -- the bitmap: atomicOr in the
+//     update kernel, plain load + plain store of 0 (behind the head's barrier) in the tile pass, the two kinds of launch
+//     alternating on one stream; a row header: atomicAdd in binning launches, plain in the tile pass; status[1..3]:
+//     atomicOr / atomicMax in tile passes, plain reset by lane 0 of a binning launch;
+//   * no word is reset, or read for a decision, by "whoever comes last" inside the launch that still bumps it: every
+//     reset belongs to a LATER launch (or sits behind a workgroup barrier of the only workgroup that touches the word);
+//   * DIFFERENT words of one 64-byte granule may mix the two kinds in one launch (an id stored plainly next to a bitmap
+//     word that takes an atomicOr: rows are 69 granules long, the bitmap starts on a granule of its own but shares its
+//     128-byte L2 line with the row's last ids) -- measured safe in both directions by tools/ubench/atomic_line_mix.hip.
+static_assert((GI2D_FAST_LROW * 4) % 64 == 0 && ((GI2D_FAST_HDR + GI2D_FAST_C) * 4) % 64 == 0,
+              "rows and their inbox bitmaps start on 64-byte granules");
 __device__ __forceinline__ int32_t *inbox_bits_of(int32_t *lists, int tile) {
     return lists + (size_t)tile * GI2D_FAST_LROW + GI2D_FAST_HDR + GI2D_FAST_C;
 }

@@ -126,7 +126,7 @@ __device__ __forceinline__ void wt_drain() {
 // After the exchange the lane of row position r holds the pixel of column fwd_lane_col(r) = 8 half + 2 pair + parity:
 // that is the lane -> pixel map of every kernel that runs this routine (fused_tile, fwd_rasterize_staged).
 // Entries are copied GI2D_FWD_CHUNK at a time into a wave-private buffer, per list three arrays in list order --
-// A[e] = (gx gy ha hb), B[e] = (hc op cr cg), C[e] = (cb lim) [+ (k -) where final_idx is wanted] -- written with the
+// A[e] = (gx gy ha hb), B[e] = (cr op cg hc), C[e] = (cb lim) [+ (k -) where final_idx is wanted] -- written with the
 // same wide stores they are read with; the right list's arrays sit 32 bytes out of phase with the left one's, so the
 // four addresses of one read (two halves x two parities) never share a bank.  `lim` is the pair test of
 // gi2d_common.h::AlphaRule (one unsigned compare per pair); a wave none of whose entries can exceed alpha = 1 runs the
@@ -182,7 +182,9 @@ __device__ __forceinline__ void fwd_trips(const float *mine_a, const float *mine
             const float2 q2 = *reinterpret_cast<const float2 *>(mine_c + t * CW);
             cb = q2.x, lim = (unsigned)__float_as_int(q2.y);
         }
-        const float gx = q0.x, gy = q0.y, ha = q0.z, hb = q0.w, hc = q1.x, op = q1.y, cr = q1.z, cg = q1.w;
+        // (B is staged as (cr, op, cg, hc): what a packed fma broadcasts sits in the low half of a register pair -- from
+        // the high half the compiler copies it first; the packed multiply takes `op` from either half)
+        const float gx = q0.x, gy = q0.y, ha = q0.z, hb = q0.w, cr = q1.x, op = q1.y, cg = q1.z, hc = q1.w;
         // the row terms, once for the two pixels: == row_term_b / row_term_c
         const float dy = gy - py;
         const float bdy = hb * dy, cdy2 = __builtin_fmaf(hc * dy, dy, 0.f);
@@ -207,11 +209,12 @@ __device__ __forceinline__ void fwd_trips(const float *mine_a, const float *mine
 }
 
 // x + (the same register of the lane eight positions round the 16-lane row): row_ror:8 swaps a row's two parities
+// (`old` = x: a rotation within the row always has a source lane, nothing is left to fill in)
 __device__ __forceinline__ float fwd_add_partner(float x) {
-    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x128, 0xf, 0xf, false));
 }
 __device__ __forceinline__ int fwd_max_partner(int x) {
-    return max(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false));
+    return max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
 }
 
 // lists: [2][GI2D_FWD_LISTLEN] bytes of this wave (left, right); buf: GI2D_FWD_PAIRBUF_OF(NEED_FIDX) floats of this
@@ -268,7 +271,7 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
             asm volatile("" : "+v"(rec.gx), "+v"(rec.gy), "+v"(rec.ha), "+v"(rec.hb), "+v"(rec.hc), "+v"(rec.op), "+v"(rec.cr),
                          "+v"(rec.cg), "+v"(rec.cb), "+v"(rec.lim));
             reinterpret_cast<float4 *>(bdst)[be] = make_float4(rec.gx, rec.gy, rec.ha, rec.hb);
-            reinterpret_cast<float4 *>(bdst + 4 * GI2D_FWD_CHUNK)[be] = make_float4(rec.hc, rec.op, rec.cr, rec.cg);
+            reinterpret_cast<float4 *>(bdst + 4 * GI2D_FWD_CHUNK)[be] = make_float4(rec.cr, rec.op, rec.cg, rec.hc);
             if (NEED_FIDX)
                 reinterpret_cast<float4 *>(bdst + 8 * GI2D_FWD_CHUNK)[be] =
                     make_float4(rec.cb, __int_as_float((int)rec.lim), __int_as_float(k), 0.f);

@@ -383,6 +383,16 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     reduce_one(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big, acc,
                FILL_NEXT && INBOX ? &inbox.src : nullptr);
     if (g >= n) return;
+#if defined(GI2D_UPDATE_STOP) && GI2D_UPDATE_STOP == 1 /* development aid: the kernel's time up to the end of its two load rounds */
+    {
+        float all = rows.x.x + rows.mx.x + rows.vx.y + rows.c.a + rows.f.b + rows.mc.c + rows.vc.a + rows.mf.b + rows.vf.c +
+                    conic[0] + conic[1] + conic[2] + opac_next + bound3[0] + (float)radius + (snapshot ? 1.f : 0.f);
+#pragma unroll
+        for (int q = 0; q < 11; ++q) all += acc[q];
+        if (all == 12345.678f) dbg_grads[0] = all;
+        return;
+    }
+#endif
     float2 mean;
     float par[3];
     if (ADAN)
@@ -437,6 +447,15 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         adam_update_rows(rows, gx, gy, gp, gf, a_xyz, a_chol, a_feat);
         new_xy = rows.x, new_chol = rows.c, new_feat = rows.f;
     }
+#if defined(GI2D_UPDATE_STOP) && GI2D_UPDATE_STOP == 2 /* ... up to the optimizer update (nothing stored) */
+    {
+        const float all = rows.x.x + rows.x.y + rows.mx.x + rows.mx.y + rows.vx.x + rows.vx.y + rows.c.a + rows.c.b + rows.c.c +
+                          rows.f.a + rows.f.b + rows.f.c + rows.mc.a + rows.mc.b + rows.mc.c + rows.vc.a + rows.vc.b + rows.vc.c +
+                          rows.mf.a + rows.mf.b + rows.mf.c + rows.vf.a + rows.vf.b + rows.vf.c + (snapshot ? 1.f : 0.f);
+        if (all == 12345.678f) dbg_grads[0] = all;
+        return;
+    }
+#endif
     // Everything this lane still has to store that does not wait for the binning step's atomics: the optimizer's rows
     // (Adam; Adan stored its own above) and the best-model snapshot -- the state dict after this step's update
     // (train.py:137 copies it after train_iter returned), from the registers the update left, not read back through
@@ -476,6 +495,14 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
         const ProjOut o =
             project_one<KIND>(0, next.clip_coe, &mean2, par2, rot_of<KIND>(par2), img_w, img_h, tiles_x, tiles_y,
                               radius_clip);
+#if defined(GI2D_UPDATE_STOP) && GI2D_UPDATE_STOP == 3 /* ... up to the next iteration's projection (nothing stored) */
+        {
+            const float all = o.xy.x + o.xy.y + o.k0 + o.k1 + o.k2 + (float)o.radius + (float)o.tiles_hit + rows.mx.x +
+                              rows.vx.y + rows.mc.c + rows.vc.a + rows.mf.b + rows.vf.c + new_feat.a + new_feat.b + new_feat.c;
+            if (all == 12345.678f) dbg_grads[0] = all;
+            return;
+        }
+#endif
         // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box).
         // Order of the tail: the binning step's returning atomics (gaussians that entered a tile), then every other
         // store of the lane, then the list stores that need the atomics' results.

@@ -21,7 +21,7 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "5")
+ROUND = os.environ.get("ROUND", "6")
 SRC = os.path.join(ROOT, "gpurun_out", "rp" + ROUND)
 DST = os.path.join(ROOT, "profiles")
 TAG = "round" + ROUND

@@ -14,7 +14,7 @@
 #            dropin  the drop-in autograd loop under cProfile (tools/profile_autograd_loop.py)
 set -e
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-5}
+ROUND=${ROUND:-6}
 OUT=$REPO/gpurun_out/rp$ROUND
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
