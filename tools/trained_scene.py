@@ -1,7 +1,9 @@
 """A TRAINED scene as the frozen input of cut-off / knock-out builds (development aid).
-  trained_scene.py fit [image] [iterations] [path] [grow_iter]   fit one Kodak picture with the adaptive covariance schedule of
-                                                    launch.py (5 000 -> 50 000 gaussians) and save the activated
-                                                    parameters + the picture
+  trained_scene.py fit [image] [iterations] [path] [grow_iter] [total]   fit one Kodak picture with the adaptive covariance
+                                                    schedule of launch.py (5 000 -> 50 000 gaussians) and save the activated
+                                                    parameters + the picture; `total`: the schedule's length when the fit
+                                                    stops early (10000 5000 50000 = the scene a fit works on for most of its
+                                                    time: 6 000 large gaussians)
   trained_scene.py steps [steps] [path]             HotPath.step() on that frozen scene (what static_steps.py does on
                                                     the uniform synthetic one)"""
 import os
@@ -23,10 +25,11 @@ if mode == "fit":
     image, iters = int(a[1]) if len(a) > 1 else 0, int(a[2]) if len(a) > 2 else 20000
     path = a[3] if len(a) > 3 else "/tmp/trained_scene.pt"
     grow = int(a[4]) if len(a) > 4 else max(iters // 10, 1)
+    total = int(a[5]) if len(a) > 5 else iters
     gt = bench.load_kodak(image + 1)[1][image].to(dev)
     fit = NativeFitter(gt, 5000, kind="covariance", lr=0.018, eps=1e-15, max_points=50000, track_best=True,
                        device_resident=True)
-    fit.fit(iters, prune_iter=100, grow_iter=grow)
+    fit.fit(iters, prune_iter=100, grow_iter=grow, total_iterations=total)
     fit.sync_population()
     torch.cuda.synchronize()
     torch.save({"means": fit.xyz.cpu(), "params": (fit.chol + fit.bound).cpu(), "colors": fit.feat.cpu(),
