@@ -400,7 +400,8 @@ __device__ __forceinline__ void fwd_rasterize_staged(FwdLds &sm, int len, int li
         if (final_Ts) final_Ts[pix] = 1.f;  // forward.cu:558: T is never updated
         if (NEED_FIDX) final_idx[pix] = cur_idx;
     }
-    if (WT && (img_w & 3) == 0 && (tx + 1) * GI2D_TILE <= img_w && (ty + 1) * GI2D_TILE <= img_h)  // tile-uniform
+    if (WT && (img_w & 3) == 0 && (reinterpret_cast<uintptr_t>(out_img) & 15) == 0 && (tx + 1) * GI2D_TILE <= img_w &&
+        (ty + 1) * GI2D_TILE <= img_h)  // tile-uniform: rows of 16-byte pieces, a tile inside the image
         fwd_store_pixels_wt(o0, o1, o2, tx, ty, img_w, mybuf, out_img);
     else
         fwd_store_pixels(o0, o1, o2, tx, ty, img_w, img_h, out_img);
