@@ -208,13 +208,13 @@ __device__ __forceinline__ void fwd_trips(const float *mine_a, const float *mine
     }
 }
 
-// x + (the same register of the lane eight positions round the 16-lane row): row_ror:8 swaps a row's two parities
-// (`old` = x: a rotation within the row always has a source lane, nothing is left to fill in)
-__device__ __forceinline__ float fwd_add_partner(float x) {
-    return x + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x128, 0xf, 0xf, false));
+// keep + (the partner's `send`): row_ror:8 swaps a row's two parities (`old` = send: a rotation within the row always
+// has a source lane, nothing is left to fill in)
+__device__ __forceinline__ float fwd_add_partner(float keep, float send) {
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(send), __float_as_int(send), 0x128, 0xf, 0xf, false));
 }
-__device__ __forceinline__ int fwd_max_partner(int x) {
-    return max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
+__device__ __forceinline__ int fwd_max_partner(int keep, int send) {
+    return max(keep, __builtin_amdgcn_update_dpp(send, send, 0x128, 0xf, 0xf, false));
 }
 
 // lists: [2][GI2D_FWD_LISTLEN] bytes of this wave (left, right); buf: GI2D_FWD_PAIRBUF_OF(NEED_FIDX) floats of this
@@ -286,18 +286,14 @@ __device__ __forceinline__ void fwd_pixel_half_lists(unsigned char *lists, float
             fwd_trips<NEED_FIDX, false, UNROLL>(mine_a, mine_c, m, px2, py, a0, a1, a2, last_a, last_b);
         __builtin_amdgcn_wave_barrier();
     }
-    // even + odd list positions of each pixel (the two partial sums every earlier layout formed, in that order)
-    const float ea0 = fwd_add_partner(a0.x), eb0 = fwd_add_partner(a0.y);
-    const float ea1 = fwd_add_partner(a1.x), eb1 = fwd_add_partner(a1.y);
-    const float ea2 = fwd_add_partner(a2.x), eb2 = fwd_add_partner(a2.y);
-    o0 = parity ? eb0 : ea0;
-    o1 = parity ? eb1 : ea1;
-    o2 = parity ? eb2 : ea2;
+    // even + odd list positions of each pixel (the two partial sums every earlier layout formed; the sum commutes).
+    // A lane keeps the pixel whose column has its parity and hands the other one's sum to its partner: one select
+    // each way and one DPP add per channel.
+    o0 = fwd_add_partner(parity ? a0.y : a0.x, parity ? a0.x : a0.y);
+    o1 = fwd_add_partner(parity ? a1.y : a1.x, parity ? a1.x : a1.y);
+    o2 = fwd_add_partner(parity ? a2.y : a2.x, parity ? a2.x : a2.y);
     last_k = -1;
-    if (NEED_FIDX) {
-        const int la = fwd_max_partner(last_a), lb = fwd_max_partner(last_b);
-        last_k = parity ? lb : la;
-    }
+    if (NEED_FIDX) last_k = fwd_max_partner(parity ? last_b : last_a, parity ? last_a : last_b);
 }
 
 // A tile's RGB leaves as one 12-byte store per lane: the 16 lanes of a pixel row write 192 contiguous bytes = three
