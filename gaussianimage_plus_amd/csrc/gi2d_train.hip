@@ -503,6 +503,21 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
             return;
         }
 #endif
+#if defined(GI2D_UPDATE_STOP) && GI2D_UPDATE_STOP == 6 /* ... up to the record and the box comparison (nothing stored) */
+        {
+            int mnx, mny, mxx, mxy;
+            const bool member = bin_box(o.xy, o.radius, radius_clip, tiles_x, tiles_y, mnx, mny, mxx, mxy) && o.tiles_hit > 0;
+            const int2 nw = member ? pack_box(mnx, mny, mxx, mxy) : make_int2(0, 0);
+            float4 q[4];
+            make_record(q, g, o.xy, o.k0, o.k1, o.k2, opac_next, new_feat.a, new_feat.b, new_feat.c, nw, o.radius, pbox.z);
+            float all = (nw.x != pbox.x || nw.y != pbox.y) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) all += q[k].x + q[k].y + q[k].z + q[k].w;
+            all += rows.mx.x + rows.vx.y + rows.mc.c + rows.vc.a + rows.mf.b + rows.vf.c + (float)o.tiles_hit;
+            if (all == 12345.678f) dbg_grads[0] = all;
+            return;
+        }
+#endif
         // `box` is what prev_box[g] holds: the binning step of THIS iteration left it there (prev_box == next.prev_box).
         // Order of the tail: the binning step's returning atomics (gaussians that entered a tile), then every other
         // store of the lane, then the list stores that need the atomics' results.
