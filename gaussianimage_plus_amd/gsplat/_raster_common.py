@@ -24,10 +24,9 @@ use, by ANY later forward / backward of the wrappers once its copy has landed (`
 wait), by `settle_all()` (blocking; launch.fit_image calls it behind its last evaluation render), or by the
 interpreter-exit hook, which can only report.  And the "slowly moving rows" premise is only trusted for ONE scene: the
 pool hands a workspace to whichever scene of its shape comes next (train.py's next image, a checkpoint just loaded, a
-model after prune / growth), so a forward whose colour / opacity tensors are not the ones the workspace's last forward
-saw -- storage address, shape, or a lease taken by another autograd node in between -- is checked synchronously again
-(_scene_identity; a model's parameters keep their storage from iteration to iteration and change it exactly at those
-events).  No wall clock is involved: a host stall does not force a check, a fast hand-over does not skip one."""
+model after prune / growth), so a forward whose opacity tensor / shapes are not the ones the workspace's last forward
+saw -- the opacity tensor's storage, the shapes -- is checked synchronously again (_scene_identity; a model's `_opacity`
+keeps its storage from iteration to iteration and changes it exactly at those events).  No wall clock is involved: a host stall does not force a check, a fast hand-over does not skip one."""
 from __future__ import annotations
 
 import atexit
@@ -75,10 +74,13 @@ def _acquire(xys, num_points, tile_bounds) -> _Lease:
 
 
 def _scene_identity(colors, opacity):
-    """What tells one scene from the next on a pooled workspace: the storage and shape of the model's colour / opacity
-    tensors (parameters keep their storage across the iterations of a fit; a new image, a loaded checkpoint, prune and
-    growth all allocate new ones)."""
-    return (colors.data_ptr(), tuple(colors.shape), opacity.data_ptr(), tuple(opacity.shape))
+    """What tells one scene from the next on a pooled workspace: the storage of the model's opacity tensor and the
+    shapes of colours and opacity.  The opacity is a parameter / buffer of every reference model (`_opacity`: it keeps its
+    storage across the iterations of a fit; a new image's model, prune and growth all allocate a new one), while the
+    colours a model hands over may be computed afresh every iteration (sigmoid of the features, de-quantised features):
+    their address says nothing.  A scene that changes without any of this changing (a checkpoint copied into the same
+    parameters) is caught late at worst, and a late overflow is repaired (_repair_late_overflow)."""
+    return (opacity.data_ptr(), tuple(opacity.shape), tuple(colors.shape))
 
 
 def _settle(ws, what: str, repairable: bool = False) -> bool:

@@ -208,6 +208,7 @@ class NativeFitter:
             *[(p(getattr(self, nm)) if optimizer == "adan" else None)
               for nm in ("_d_xyz", "_d_chol", "_d_feat", "_pg_xyz", "_pg_chol", "_pg_feat")], None, None, None, 0)
         self.inbox = None  # the tiles' inboxes (gi2d_train_state::inbox): this fitter's own, from its first multi-iteration call
+        self._inbox_looked = False
         if self.device_resident:
             self.n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
             self.dens_counts = i32(2)  # gaussians pruned / added so far (device-side tallies)
@@ -276,13 +277,14 @@ class NativeFitter:
         st = torch.cuda.current_stream(self.dev).cuda_stream
         b1, b2 = self.betas[0], self.betas[1]
         left = int(iterations)
-        if self.inbox is None and left > 1 and self.quant is None:
+        if self.inbox is None and not self._inbox_looked and left > 1 and self.quant is None:
             # Only a single-image call of more than one iteration delivers through the inboxes (csrc/gi2d_fast_internal.h::
             # Inbox), so only such a fitter owns the buffer -- members of a BatchFitter, quantised fits and evaluation
             # renders never allocate its 128 KB per tile (192 MiB at 768x512).  Uninitialised scratch.
+            self._inbox_looked = True
             nbytes = self.lib.gi2d_train_inbox_bytes(self.tx, self.ty)
-            self.inbox = torch.empty(nbytes, dtype=torch.uint8, device=self.dev) if nbytes else False
-            if nbytes:
+            if nbytes:  # (0: an image of more than 1 536 tiles does without)
+                self.inbox = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
                 self.state.inbox, self.state.inbox_bytes = self.inbox.data_ptr(), nbytes
         with torch.cuda.device(self.dev):
             while left > 0:
