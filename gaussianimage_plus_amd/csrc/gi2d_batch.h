@@ -70,6 +70,7 @@ struct TilePassArgs {
     const int32_t *tile_order;
     int32_t *big_tile;  // two-phase tile pass: which tiles the small form left to the general one (FastWs::big_tile)
     float4 *inbox;      // the tiles' inboxes (gi2d_train_state::inbox; nullptr: none)
+    int write_through;  // single-image launches of one residency round: rows and image leave as sc1 stores (store16)
 };
 
 // One image's arguments of the per-gaussian fitting kernels (project+fill, reduce+update).
@@ -98,6 +99,7 @@ static inline TilePassArgs tile_pass_args(const FastWs &w, int n, int tiles_x, i
     a.rs = rec_sets(w, n);
     a.lists = w.lists;
     a.inbox = w.inbox_recs;
+    a.write_through = 0;
     a.tile_bins = (int2 *)w.tile_bins;
     a.partial_g = w.partial_g;
     a.partial_big = w.partial_big;

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, GI2D_PHASE_OCC(PHASE)) void fast_fwdbwd_kernel
         // (written through where the whole launch is one residency round of the chip: see tile_pass_workgroup)
         const int tiles = a.tiles_x * a.tiles_y;
         tile_pass_workgroup<MODE, PHASE, INBOX, INBOX ? 1 : (PHASE == 0 ? 2 : 0)>(
-            a, (int)blockIdx.x, blockIdx.x == 0, tiles > GI2D_TWO_PHASE_TILES, tiles <= GI2D_TWO_PHASE_TILES);
+            a, (int)blockIdx.x, blockIdx.x == 0, tiles > GI2D_TWO_PHASE_TILES, a.write_through != 0);
     }
 }
 
@@ -931,7 +931,7 @@ int gi2d_fast_rasterize_forward(int n, int tiles_x, int tiles_y, unsigned w_, un
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
-    if (t <= GI2D_TWO_PHASE_TILES)  // one residency round: written through (see the kernel)
+    if (t <= GI2D_TWO_PHASE_TILES && wt_fits(w, (int)t, (size_t)w_ * h * 12))  // one residency round: written through
         hipLaunchKernelGGL(fast_fwd_kernel<true>, dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y,
                            (int)w_, (int)h, rec_sets(w, n), background, w.lists, (int2 *)w.tile_bins, w.packed,
                            w.partial_g, w.partial_big, status, final_Ts, final_idx, out_img);
@@ -972,10 +972,14 @@ int fast_forward_backward_form(int n, int tiles_x, int tiles_y, unsigned w_, uns
         return GI2D_ERR_INVALID_ARGUMENT;
     }
     FastWs w = carve_fast(ws, n, (int)t);
-    w.inbox_recs = inbox;
+    // (the inbox instantiation always stores write-through: it is only picked where that is possible)
+    const bool wt = t <= GI2D_TWO_PHASE_TILES && wt_fits(w, (int)t, (size_t)w_ * h * 12);
+    w.inbox_recs = wt ? inbox : nullptr;
+    inbox = w.inbox_recs;
     TilePassArgs a = tile_pass_args(w, n, tiles_x, tiles_y, (int)w_, (int)h, status, out_img,
                                     v_output ? v_output : target, v_output ? 0.f : grad_scale,
                                     v_output ? nullptr : tile_sse);
+    a.write_through = wt ? 1 : 0;
     const dim3 grid((unsigned)t), block(256);
     if (form < 0) form = pass_form_override() >= 0 ? pass_form_override() : 1;
     if (two_phase_tile_pass(t) && form >= 1) {
@@ -1084,7 +1088,7 @@ int gi2d_fast_rasterize_backward_tiles(int n, int tiles_x, int tiles_y, unsigned
     hipLaunchKernelGGL((fast_bwd_kernel<ABS, WT>), dim3((unsigned)t), dim3(256), 0, (hipStream_t)st, tiles_x, tiles_y, \
                        (int)w_, (int)h, (const int2 *)w.tile_bins, w.packed, final_idx, v_output, w.partial_g,        \
                        w.partial_big)
-    const bool wt = t <= GI2D_TWO_PHASE_TILES;  // one residency round: the gradient rows are written through
+    const bool wt = t <= GI2D_TWO_PHASE_TILES && wt_fits(w, (int)t, 0);  // one residency round: the gradient rows are written through
     if (with_abs) {
         if (wt) GI2D_LAUNCH_BWD(true, true); else GI2D_LAUNCH_BWD(true, false);
     } else {

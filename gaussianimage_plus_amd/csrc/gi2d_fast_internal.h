@@ -205,6 +205,15 @@ static FastWs carve_fast(void *base, int n, int num_tiles) {
     w.bytes = off;
     return w;
 }
+// May a launch on this workspace store write-through (gi2d_raster_core.h::store16)?  Its buffer stores address the
+// gradient rows -- gaussian-major rows and the row pool behind them -- by a 32-bit offset from `partial_g`, the image and
+// the packed records from their own bases: every one of those spans must stay below 4 GB (2 million gaussians' rows).
+static inline bool wt_fits(const FastWs &w, int num_tiles, size_t image_bytes) {
+    const size_t rows_span = (size_t)((const char *)w.partial_big - (const char *)w.partial_g) +
+                             (size_t)(num_tiles > 0 ? num_tiles : 1) * GI2D_TILE_LIST_CAP * GI2D_FAST_ROW * sizeof(float4);
+    const size_t packed_span = (size_t)(num_tiles > 0 ? num_tiles : 1) * GI2D_TILE_LIST_CAP * sizeof(GaussRec);
+    return rows_span < 0xffff0000ull && packed_span < 0xffff0000ull && image_bytes < 0xffff0000ull;
+}
 // Bytes of the inbox buffer of an image of `num_tiles` tiles (0: such an image does without, Inbox above).
 static inline size_t inbox_bytes(long long num_tiles) {
     if (num_tiles < 1 || num_tiles > GI2D_INBOX_MAX_TILES) return 0;

@@ -80,11 +80,13 @@ __device__ __forceinline__ unsigned cull_word_ext(float gx, float gy, float hx, 
 // other tiles' work and which is short of memory-system slots, +28 %: the batched kernels store plainly.
 // The stores are raw BUFFER stores with the sc1 cache-policy bit (the compiler sees them: hazards and waits are its
 // business, which they are not with inline assembly); `base`: a wave-uniform pointer at or below every address stored to
-// (the buffer's resource lives in scalar registers), within 2 GB of it.
+// (the buffer's resource lives in scalar registers), within 4 GB of it.
 typedef unsigned int wt_u4 __attribute__((ext_vector_type(4)));
 #define GI2D_WT_AUX 16 /* cache policy of the raw buffer store builtins on gfx94x / gfx950: bit 4 = sc1 */
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_resource(const void *base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+    // (num_records = the whole 32-bit offset range: the launch code only picks a write-through kernel where every address
+    // stored to lies within 4 GB of its base -- gi2d_fast_internal.h::wt_fits)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
 }
 __device__ __forceinline__ unsigned wt_offset(const void *p, const void *base) {
     return (unsigned)(reinterpret_cast<const char *>(p) - reinterpret_cast<const char *>(base));

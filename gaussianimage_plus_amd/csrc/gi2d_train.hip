@@ -1405,7 +1405,9 @@ static UpdateArgs update_args_of(const gi2d_train_state *s, const FastWs &w, int
     u.next.num_tiles_hit = s->num_tiles_hit;
     u.next.lists = w.lists;
     // the tiles' inboxes: the caller's own buffer, for an image small enough to use them (single-image calls only look)
-    u.next.inbox = (s->inbox != nullptr && inbox_bytes((long long)tx * ty) > 0 && s->inbox_bytes >= inbox_bytes((long long)tx * ty))
+    // (... and whose tile pass can store write-through, which the inbox instantiation always does: wt_fits)
+    u.next.inbox = (s->inbox != nullptr && inbox_bytes((long long)tx * ty) > 0 && s->inbox_bytes >= inbox_bytes((long long)tx * ty) &&
+                    wt_fits(w, tx * ty, (size_t)s->img_width * s->img_height * 12))
                        ? (float4 *)s->inbox
                        : nullptr;
     u.next.prev_box = w.prev_box;
