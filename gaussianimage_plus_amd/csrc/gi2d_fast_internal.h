@@ -2,6 +2,7 @@
 // fill, partial-row addressing and the ordered per-gaussian reduction.
 #pragma once
 #include <atomic>
+#include <type_traits>
 
 #include "gi2d_project_core.h"
 #include "gi2d_raster_core.h"
@@ -45,6 +46,9 @@ namespace gi2d {
 #define GI2D_REDUCE_BATCH 8                          /* partial rows a lane loads before it starts adding */
 #endif
 #define GI2D_BIG_TILES_F 32
+#ifndef GI2D_UPDATE_ROWS_AHEAD
+#define GI2D_UPDATE_ROWS_AHEAD 2                     /* gradient rows the update kernel requests before it knows the box (reduce_one) */
+#endif
 #define GI2D_FAST_ROW 4 /* float4 per partial row: 48 bytes of data padded to one 64-byte line */
 
 // What the binning step remembers per gaussian: (x, y) the packed tile box it is binned with (pack_box; 0/0 = none),
@@ -1027,9 +1031,31 @@ static_assert(GI2D_FAST_S == GI2D_BIG_TILES_F, "gaussian-major rows up to the si
 static_assert(GI2D_REDUCE_BATCH >= 8 && GI2D_TILE_LIST_CAP == 256, "reduce_one reads the ranks of a box of <= 8 tiles in its first trip, eight bits each");
 // `src` (optional): the ranks the tile pass left in the spare word of the rows (store_partial_row), for a box of at most
 // eight tiles -- what the gaussian needs to enter a neighbouring tile through its inbox (InboxSrc).
+// `ahead` (AHEAD > 0): the first AHEAD gaussian-major rows of g, requested by rows_ahead() together with the caller's
+// first round of loads -- their addresses depend on g alone, so they need not wait for the box that says how many of
+// them count (the bench scene's gaussians lie on 1, 2 or 4 tiles: the box -> rows round trip disappears for every wave
+// without a larger one).  What is added, and in which order, is the same with or without.
+template <int AHEAD>
+struct RowsAhead {
+    float4 r[AHEAD > 0 ? AHEAD : 1][3];
+};
+template <int AHEAD>
+__device__ __forceinline__ RowsAhead<AHEAD> rows_ahead(const float4 *__restrict__ partial_g, int g_in_rows) {
+    static_assert(AHEAD <= GI2D_REDUCE_BATCH && AHEAD <= GI2D_FAST_S, "rows of the first trip only");
+    RowsAhead<AHEAD> a;
+    const float4 *rows = partial_g + GI2D_FAST_ROW * ((size_t)g_in_rows * GI2D_FAST_S);
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) {
+        a.r[q][0] = rows[GI2D_FAST_ROW * q];
+        a.r[q][1] = rows[GI2D_FAST_ROW * q + 1];
+        a.r[q][2] = rows[GI2D_FAST_ROW * q + 2];
+    }
+    return a;
+}
+template <int AHEAD = 0>
 __device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_rows, const float4 *__restrict__ partial_g,
                                            const float4 *__restrict__ partial_big, float (&acc)[11],
-                                           InboxSrc *src = nullptr) {
+                                           InboxSrc *src = nullptr, const RowsAhead<AHEAD> *ahead = nullptr) {
     const int lane = threadIdx.x & 63;
     if (src) src->clear();
 #pragma unroll
@@ -1042,15 +1068,20 @@ __device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_r
         // GI2D_REDUCE_BATCH rows per trip: their loads are in flight together, the additions stay in ascending
         // tile order
         const float4 *rows = partial_g + GI2D_FAST_ROW * ((size_t)g * GI2D_FAST_S);
-        for (int k0 = 0; k0 < ntiles; k0 += GI2D_REDUCE_BATCH) {
+        // (the first trip is written out: rows [0, AHEAD) are in registers already)
+        const auto trip = [&](int k0, auto have) {
+            constexpr int HAVE = decltype(have)::value;
             float4 r[GI2D_REDUCE_BATCH][3];
 #pragma unroll
-            for (int q = 0; q < GI2D_REDUCE_BATCH; ++q)
-                if (k0 + q < ntiles) {
+            for (int q = 0; q < GI2D_REDUCE_BATCH; ++q) {
+                if (q < HAVE) {
+                    r[q][0] = ahead->r[q][0], r[q][1] = ahead->r[q][1], r[q][2] = ahead->r[q][2];
+                } else if (k0 + q < ntiles) {
                     r[q][0] = rows[GI2D_FAST_ROW * (k0 + q)];
                     r[q][1] = rows[GI2D_FAST_ROW * (k0 + q) + 1];
                     r[q][2] = rows[GI2D_FAST_ROW * (k0 + q) + 2];
                 }
+            }
 #pragma unroll
             for (int q = 0; q < GI2D_REDUCE_BATCH; ++q)
                 if (k0 + q < ntiles) add_partial_row(acc, r[q][0], r[q][1], r[q][2]);
@@ -1059,7 +1090,9 @@ __device__ __forceinline__ void reduce_one(int g, int2 box, int pool, int pool_r
                 for (int q = 0; q < 8; ++q)
                     if (q < ntiles) src->set(q, (unsigned)__float_as_int(r[q][2].w));
             }
-        }
+        };
+        trip(0, std::integral_constant<int, AHEAD>());
+        for (int k0 = GI2D_REDUCE_BATCH; k0 < ntiles; k0 += GI2D_REDUCE_BATCH) trip(k0, std::integral_constant<int, 0>());
     }
     // a run that does not lie inside the pool was never written (partial_row): the overflow status is up
     unsigned long long big = __ballot(mapped && ntiles > GI2D_BIG_TILES_F && pool >= 0 && pool + ntiles <= pool_rows);

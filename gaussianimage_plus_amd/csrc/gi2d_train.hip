@@ -368,6 +368,10 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     float conic[3] = {0.f, 0.f, 0.f};
     if (in_rows) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
     const float opac_next = (FILL_NEXT && in_rows) ? P.opacity[g] : 0.f;
+    // ... and the gaussian's first gradient rows, whose addresses need no box (reduce_one)
+    // (the single image's kernel only: a batch's launch is short of memory slots, not of things to wait for -- measured)
+    constexpr int AHEAD = INBOX ? GI2D_UPDATE_ROWS_AHEAD : 0;
+    const RowsAhead<AHEAD> ahead = rows_ahead<AHEAD>(u.partial_g, in_rows ? g : 0);
     // the additive bound of this gaussian (one row for all when bound_stride == 0): used by both activations and the snapshot
     const Row3 bound_row = in_rows ? load_row3(P.bound, P.bound_stride ? g : 0) : Row3{0.f, 0.f, 0.f};
     const float bound3[3] = {bound_row.a, bound_row.b, bound_row.c};
@@ -380,8 +384,8 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     // (FILL_NEXT: with the sums come the ranks the tile pass staged this gaussian at -- what it needs to enter a
     // neighbouring tile through that tile's inbox instead of waiting for an atomic's answer: gi2d_fast_internal.h::Inbox)
     InboxFill inbox;
-    reduce_one(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big, acc,
-               FILL_NEXT && INBOX ? &inbox.src : nullptr);
+    reduce_one<AHEAD>(g, box, pbox.z, tiles_x * u.tiles_y * GI2D_TILE_LIST_CAP, u.partial_g, u.partial_big,
+                                       acc, FILL_NEXT && INBOX ? &inbox.src : nullptr, &ahead);
     if (g >= n) return;
 #if defined(GI2D_UPDATE_STOP) && GI2D_UPDATE_STOP == 1 /* development aid: the kernel's time up to the end of its two load rounds */
     {

@@ -36,9 +36,11 @@ def test_bench_line_has_the_contract_fields():
     assert r["traffic"] is None  # the committed counters are for the default workload, not this one
     assert r["traffic_source"].startswith("none:")
     assert d["metric"].endswith("144x96")
-    # five timed regions of 24 steps each, every 2nd tile pass carries an event pair
+    # five timed regions of 24 steps each for `value`, none of whose dispatches carries an event pair; between them the
+    # same region five times more with a pair on every 2nd tile pass (the kernel time of `roofline`)
     assert d["repeats"] == 5 and len(d["ms_per_step_each_region"]) == 5
     assert sorted(d["ms_per_step_each_region"])[2] == d["ms_per_step"]  # the median region
+    assert d["event_stride"] == 2 and d["ms_per_step_event_regions"] > 0
     # (a call's first tile pass is another instantiation of the kernel and is reported beside the dominant one)
     fp = r["first_pass_of_a_call"]
     assert r["kernel_samples"] == 55 and fp["samples"] == 5 and fp["avg_kernel_us"] > 0 and fp["kernel"].endswith("<1, 0, false>")
