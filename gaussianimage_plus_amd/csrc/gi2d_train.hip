@@ -329,7 +329,8 @@ __device__ __forceinline__ bool best_decision(const BestSnap &best, const SseLoa
 // projection and binning step) of one image's gaussians: workgroup `block` of the image's launch share, or its extra
 // workgroup (`order_block`) that computes the next iteration's tile order (gi2d_fast_internal.h).
 // INBOX: entered tiles take the gaussian through their inbox where that is possible (the single-image kernel).
-template <int KIND, bool FILL_NEXT, bool ADAN, bool INBOX = false>
+// ALONE: the launch serves one image (its waves have things to wait for and nothing to do meanwhile).
+template <int KIND, bool FILL_NEXT, bool ADAN, bool INBOX = false, bool ALONE = INBOX>
 __device__ __forceinline__ void train_reduce_update_body(int block, bool order_block, const UpdateArgs &u,
                                                          const AdamStep &a_xyz, const AdamStep &a_chol,
                                                          const AdamStep &a_feat, int step) {
@@ -369,8 +370,9 @@ __device__ __forceinline__ void train_reduce_update_body(int block, bool order_b
     if (in_rows) conic[0] = conics[3 * g], conic[1] = conics[3 * g + 1], conic[2] = conics[3 * g + 2];
     const float opac_next = (FILL_NEXT && in_rows) ? P.opacity[g] : 0.f;
     // ... and the gaussian's first gradient rows, whose addresses need no box (reduce_one)
-    // (the single image's kernel only: a batch's launch is short of memory slots, not of things to wait for -- measured)
-    constexpr int AHEAD = INBOX ? GI2D_UPDATE_ROWS_AHEAD : 0;
+    // (a single image's kernels only: 9.05 -> 8.65 us at 768x512, 11.5 -> 11.05 at 2040x1356; a batch's launch is short
+    // of memory slots, not of things to wait for -- 15.1 -> 15.9 us per image-iteration at K = 24 with four rows ahead)
+    constexpr int AHEAD = ALONE ? GI2D_UPDATE_ROWS_AHEAD : 0;
     const RowsAhead<AHEAD> ahead = rows_ahead<AHEAD>(u.partial_g, in_rows ? g : 0);
     // the additive bound of this gaussian (one row for all when bound_stride == 0): used by both activations and the snapshot
     const Row3 bound_row = in_rows ? load_row3(P.bound, P.bound_stride ? g : 0) : Row3{0.f, 0.f, 0.f};
@@ -545,7 +547,7 @@ template <int KIND, bool FILL_NEXT, bool ADAN, bool INBOX = false>
 __global__ __launch_bounds__(256) void train_reduce_update_kernel(UpdateArgs u, AdamStep a_xyz, AdamStep a_chol,
                                                                   AdamStep a_feat, int step) {
     static_assert(FILL_NEXT || !INBOX, "only a binning update kernel has entrants to deliver");
-    train_reduce_update_body<KIND, FILL_NEXT, ADAN, INBOX>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz, a_chol,
+    train_reduce_update_body<KIND, FILL_NEXT, ADAN, INBOX, true>((int)blockIdx.x, blockIdx.x == gridDim.x - 1, u, a_xyz, a_chol,
                                                            a_feat, step);
 }
 // K images in one launch (gi2d_batch.h): image k owns workgroups [pg_start[k], pg_start[k + 1]), the last of them its
@@ -852,6 +854,7 @@ __device__ __forceinline__ void quant_range_body(int block, const UpdateArgs &u,
     wave_partial_row(sums, mn, cmn, mx, cmx, Q.partial + (size_t)quant_wave_row(block) * GI2D_QT_ROW);
 }
 
+template <bool ALONE>
 __device__ __forceinline__ void reduce_update_quant_body(int block, const UpdateArgs &u, const QuantTrain &Q,
                                                          const AdamStep &a_xyz, const AdamStep &a_chol,
                                                          const AdamStep &a_feat, int step) {
@@ -869,10 +872,15 @@ __device__ __forceinline__ void reduce_update_quant_body(int block, const Update
     best.step = step;
     const int g = block * blockDim.x + threadIdx.x;
     int32_t *status = u.next.status;
+    // (one image alone: its first gradient rows are asked for before the box says how many count -- reduce_one)
+    constexpr int AHEAD = ALONE ? GI2D_UPDATE_ROWS_AHEAD : 0;
+    const RowsAhead<AHEAD> ahead = rows_ahead<AHEAD>(partial_g, g < u.n ? g : 0);
+    const PrevBox box_ld = g < u.n ? prev_box[g] : no_box();
     const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
-    const PrevBox pbox = g < n ? prev_box[g] : no_box();
-    reduce_one(g, make_int2(pbox.x, pbox.y), pbox.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big, acc);
+    const PrevBox pbox = g < n ? box_ld : no_box();
+    reduce_one<AHEAD>(g, make_int2(pbox.x, pbox.y), pbox.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big,
+                      acc, nullptr, &ahead);
     float sums[14];
 #pragma unroll
     for (int k = 0; k < 14; ++k) sums[k] = 0.f;
@@ -1047,6 +1055,7 @@ __device__ __forceinline__ void project_fill_quant_rs_body(int block, const Upda
                   old_box, prev_box, lists, recs);
 }
 
+template <bool ALONE>
 __device__ __forceinline__ void reduce_update_quant_rs_body(int block, const UpdateArgs &u, const QuantTrain &Q,
                                                             const AdamStep &a_xyz, const AdamStep &a_chol,
                                                             const AdamStep &a_feat, int step) {
@@ -1063,12 +1072,18 @@ __device__ __forceinline__ void reduce_update_quant_rs_body(int block, const Upd
     BestSnap best = u.best;
     best.step = step;
     const int g = block * blockDim.x + threadIdx.x;
+    // first round of loads: for every row below the host's bound (the live count is itself one of these loads); one image
+    // alone also asks for its first gradient rows before the box says how many count (reduce_one)
     AdamRows rows;
-    if (g < n) rows = adam_load_rows(P, g);
+    if (g < u.n) rows = adam_load_rows(P, g);
+    constexpr int AHEAD = ALONE ? GI2D_UPDATE_ROWS_AHEAD : 0;
+    const RowsAhead<AHEAD> ahead = rows_ahead<AHEAD>(partial_g, g < u.n ? g : 0);
+    const PrevBox box_ld = g < u.n ? prev_box[g] : no_box();
     const bool snapshot = best_decision(best, best_sse_loads(best), n, g);
     float acc[11];
-    const PrevBox pbox = g < n ? prev_box[g] : no_box();
-    reduce_one(g, make_int2(pbox.x, pbox.y), pbox.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big, acc);
+    const PrevBox pbox = g < n ? box_ld : no_box();
+    reduce_one<AHEAD>(g, make_int2(pbox.x, pbox.y), pbox.z, tiles_x * tiles_y * GI2D_TILE_LIST_CAP, partial_g, partial_big,
+                      acc, nullptr, &ahead);
     float sums[GI2D_QT_RS_SUMS];
 #pragma unroll
     for (int k = 0; k < GI2D_QT_RS_SUMS; ++k) sums[k] = 0.f;
@@ -1211,9 +1226,9 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void train_reduce_update_quant_kernel(UpdateArgs u, QuantTrain Q, AdamStep a_xyz,
                                                                         AdamStep a_chol, AdamStep a_feat, int step) {
     if (MODEL == 2)
-        reduce_update_quant_rs_body((int)blockIdx.x, u, Q, a_xyz, a_chol, a_feat, step);
+        reduce_update_quant_rs_body<true>((int)blockIdx.x, u, Q, a_xyz, a_chol, a_feat, step);
     else
-        reduce_update_quant_body((int)blockIdx.x, u, Q, a_xyz, a_chol, a_feat, step);
+        reduce_update_quant_body<true>((int)blockIdx.x, u, Q, a_xyz, a_chol, a_feat, step);
 }
 template <int MODEL>
 __global__ __launch_bounds__(256) void train_reduce_update_quant_batched_kernel(const BatchImage *__restrict__ imgs,
@@ -1224,9 +1239,9 @@ __global__ __launch_bounds__(256) void train_reduce_update_quant_batched_kernel(
     const int k = batch_find(pg_start, k_images, (int)blockIdx.x);
     const int local = __builtin_amdgcn_readfirstlane((int)blockIdx.x - pg_start[k]);
     if (MODEL == 2)
-        reduce_update_quant_rs_body(local, imgs[k].u, imgs[k].q, a_xyz, a_chol, a_feat, step);
+        reduce_update_quant_rs_body<false>(local, imgs[k].u, imgs[k].q, a_xyz, a_chol, a_feat, step);
     else
-        reduce_update_quant_body(local, imgs[k].u, imgs[k].q, a_xyz, a_chol, a_feat, step);
+        reduce_update_quant_body<false>(local, imgs[k].u, imgs[k].q, a_xyz, a_chol, a_feat, step);
 }
 __global__ __launch_bounds__(256) void train_quant_range_kernel(UpdateArgs u, QuantTrain Q) {
     quant_range_body((int)blockIdx.x, u, Q);
