@@ -57,7 +57,9 @@ namespace gi2d {
 // iterations -- from 18 KB of LDS and 62 registers instead of 26 KB and 76: EIGHT workgroups per CU instead of six.
 // The tile pass is short of runnable waves, not of issue slots: launches with more tiles than the chip
 // holds at once run the small form first and the general one on the tiles it passed over (gi2d_fast.hip).
+#ifndef GI2D_SMALL_CAP
 #define GI2D_SMALL_CAP 128
+#endif
 template <int CAP>
 struct FusedLdsT {
     static constexpr int PSTR = 9;
@@ -102,7 +104,9 @@ struct FusedLdsT {
 };
 typedef FusedLdsT<GI2D_TILE_LIST_CAP> FusedLds;
 typedef FusedLdsT<GI2D_SMALL_CAP> FusedLdsSmall;
+#ifndef GI2D_SMALL_OCC
 #define GI2D_SMALL_OCC 8 /* workgroups per CU of the small form: 62 registers, 18.2 KB */
+#endif
 
 // measured: 26.5 KB still leaves room for six workgroups per CU, 27.1 KB does not
 static_assert(GI2D_FUSED_OCC < 6 || sizeof(FusedLds) <= 26624,
